@@ -1,0 +1,99 @@
+"""ctypes binding of ``libflooder_hip.so`` (C ABI declared in ``include/flooder_hip.h``).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded, every GPU
+entry point raises ``ImportError`` telling the user to build it (``python -m flooder_amd.build``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libflooder_hip.so")
+
+_lib = None
+_load_error: Exception | None = None
+
+# name -> (restype, argtypes); the single source the symbol test checks against the header
+SIGNATURES = {
+    "flooder_abi_version": (c_int, []),
+    "flooder_last_error": (c_char_p, []),
+    "flooder_device_arch": (c_int, [c_int, c_char_p, c_int]),
+    "flooder_set_option": (c_int, [c_char_p, c_int]),
+    "flooder_padded_dim": (c_int, [c_int]),
+    "flooder_ball_count_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_void_p, c_void_p]),
+    "flooder_ball_fill_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_sweep_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                  c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_face_max_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p]),
+    "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
+    "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Load the library once (after torch, so both share one HIP runtime) and type its symbols."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise ImportError(str(_load_error)) from _load_error
+    try:
+        import torch  # noqa: F401  (loads libamdhip64.so.7 first; our DT_NEEDED resolves to it)
+
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} not found")
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        from .build import ROOT  # noqa: F401
+
+        if lib.flooder_abi_version() != 1:
+            raise OSError(f"ABI version mismatch: library reports {lib.flooder_abi_version()}, binding expects 1")
+        _lib = lib
+        return lib
+    except Exception as exc:  # noqa: BLE001
+        _load_error = ImportError(
+            f"flooder_amd: the HIP kernel library could not be loaded ({exc}). "
+            "Build it with `python -m flooder_amd.build` (needs hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback for CUDA/ROCm tensors."
+        )
+        raise _load_error from exc
+
+
+def available() -> bool:
+    try:
+        load()
+        return True
+    except ImportError:
+        return False
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.flooder_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Raw device (or host) address of a contiguous torch tensor; None -> NULL."""
+    if t is None:
+        return 0
+    if not t.is_contiguous():
+        raise ValueError("tensor passed to the native library must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,78 @@
+"""In-tree build of the native pieces (hipcc for gfx950, g++ for host-only C++).
+
+``python -m flooder_amd.build`` or ``flooder_amd.build.build_all()``.  Outputs live next to the
+package (``flooder_amd/libflooder_hip.so``, ``flooder_amd/libflooder_host.so``); they are
+git-ignored but travel to the GPU box with the working tree.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
+HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
+
+HIP_SOURCES = ["flood_kernels.hip"]
+HOST_SOURCES = ["persistence.cpp"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libflooder_hip.so)")
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(ROOT, "include", "flooder_hip.h")]
+    if not force and _newer(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [
+        _hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+        "-DFLOODER_BUILD", "-Wl,-rpath,/opt/rocm/lib",
+        "-o", HIP_LIB + ".tmp",
+    ] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(HIP_LIB + ".tmp", HIP_LIB)
+    return HIP_LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not srcs:
+        return ""
+    if not force and _newer(HOST_LIB, srcs):
+        return HOST_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found")
+    cmd = [cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", HOST_LIB + ".tmp"] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(HOST_LIB + ".tmp", HOST_LIB)
+    return HOST_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,53 @@
+"""Point-sharded Flood complex across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference is single-device.  The path shards over the point cloud because
+``min_x |p - x|`` is associative: every rank holds all simplices (tiny) and ANY subset of the
+points, computes the per-sample minimum squared distance against its subset, and one
+``all_reduce(MIN)`` on the (S, R) buffer of squared-distance bit patterns gives the global minimum.
+The reduction has to happen on the per-sample minima, BEFORE the per-face maximum
+(``min_g max_r`` is not ``max_r min_g``), which is what the ``reduce_hook`` of
+``flood_complex`` provides.
+
+Shards are interleaved (rank r takes sorted rows r, r+W, r+2W, ...): every rank then sees 1/W of
+each simplex's candidates, so the heavy-tailed per-simplex work balances without any planning.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .core import flood_complex
+
+__all__ = ["shard_points", "min_reduce_hook", "flood_complex_sharded"]
+
+
+def shard_points(points: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+    """Rank ``rank``'s interleaved share of ``points`` (any partition gives the same result)."""
+    return points[rank::world_size].contiguous()
+
+
+def min_reduce_hook(group: Optional[dist.ProcessGroup] = None):
+    """``reduce_hook`` for ``flood_complex``: in-place ``all_reduce(MIN)`` over the process group.
+
+    On ROCm tensors the buffer is int32 bit patterns of non-negative float32 squared distances
+    (integer order == numeric order, +inf = 0x7f800000); on CPU it is the float distance matrix.
+    """
+
+    def hook(buf: torch.Tensor) -> None:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=group)
+
+    return hook
+
+
+def flood_complex_sharded(points_shard: torch.Tensor, landmarks: torch.Tensor, *args,
+                          group: Optional[dist.ProcessGroup] = None, **kwargs):
+    """``flood_complex`` where each rank passes its own shard of the cloud and the SAME landmark
+    tensor; every rank returns the full result.  Same arguments as ``flood_complex`` otherwise."""
+    if not isinstance(landmarks, torch.Tensor):
+        raise TypeError("flood_complex_sharded needs explicit landmark coordinates (identical on every "
+                        "rank); run generate_landmarks on the full cloud first")
+    return flood_complex(points_shard, landmarks, *args, reduce_hook=min_reduce_hook(group), **kwargs)

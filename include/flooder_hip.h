@@ -1,0 +1,132 @@
+/*
+ * flooder_hip.h - C ABI of the MI355X (gfx950) coverage-sweep library, libflooder_hip.so.
+ *
+ * The reference (plus-rkwitt/flooder) is a pure-Python package; the seam its hot path crosses is the
+ * pair of Triton kernel wrappers in flooder/triton_kernels.py and their call sites in
+ * flooder/core.py:200-226.  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless it says "host"; memory is owned by the caller, the
+ *     library never allocates, frees or synchronises; work is enqueued on `stream` (a hipStream_t,
+ *     passed as void*; NULL = the default stream) and the pointers must stay valid until that work
+ *     has completed;
+ *   - return value 0 = success, negative = error (FLOODER_E_*); flooder_last_error() gives the text
+ *     for the calling thread; nothing throws;
+ *   - points / candidates are float32, row-major, `ld` floats per row (ld >= dim);
+ *   - squared distances travel as the uint32 bit pattern of a non-negative float32 ("d2 bits"):
+ *     for non-negative floats unsigned integer order equals numeric order, so min/max over them are
+ *     exact integer atomics.  +inf (0x7f800000) means "no candidate seen" (triton_kernels.py:70).
+ */
+#ifndef FLOODER_HIP_H
+#define FLOODER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOODER_ABI_VERSION 1
+
+#define FLOODER_OK 0
+#define FLOODER_E_ARG (-1)    /* bad argument (null pointer, unsupported dim, ...) */
+#define FLOODER_E_LAUNCH (-2) /* HIP reported an error at launch                    */
+#define FLOODER_E_DEVICE (-3) /* no gfx950 device / wrong architecture              */
+
+#define FLOODER_MAX_DIM 8      /* ambient dimensions 1..8 are compiled              */
+#define FLOODER_MAX_VERTS 9    /* vertices per simplex: max_dimension + 1 <= 9      */
+#define FLOODER_CAND_ALIGN 8   /* each simplex's candidate list is padded to x8     */
+#define FLOODER_SWEEP_CHUNK 2048 /* candidates per sweep work item                   */
+#define FLOODER_TILE_SAMPLES 512 /* samples per sweep work item (64 lanes x 8)       */
+
+int flooder_abi_version(void);
+const char* flooder_last_error(void);
+
+/* Name of the GPU architecture of `device` copied into buf (e.g. "gfx950:sramecc+:xnack-"). */
+int flooder_device_arch(int device, char* buf, int buflen);
+
+/* Tuning switches (process-wide).  "sweep_variant": 0 = packed-fp32 inner loop (default),
+ * 1 = plain fp32 inner loop; both give bit-identical results. */
+int flooder_set_option(const char* name, int value);
+
+/* Row stride (floats) of a padded point / candidate row for ambient dimension `dim`:
+ * 1,2 -> 2; 3,4 -> 4; 5..8 -> 8.  Rows in this layout are read with one vector load. */
+int flooder_padded_dim(int dim);
+
+/*
+ * Ball membership count.  Replaces compute_mask + the per-row count of compute_mask_kernel
+ * (flooder/triton_kernels.py:99-158, call site flooder/core.py:210-217): point j is a candidate of
+ * simplex i iff sum_k (pts[j,k]-centers[i,k])^2 <= radii[i]^2 (squared, "<=", no sqrt; :137-148).
+ * Instead of materialising the (n, m+512) bool mask it only counts, per simplex, over that simplex's
+ * own slab [slab_lo[i], slab_hi[i]) of the cloud sorted along its widest axis (core.py:140-144,
+ * 201-208; the per-simplex slab is a subset of the reference's per-batch slab and still contains the
+ * whole ball, so the candidate sets are identical).
+ *   counts[i] (int32) must be zeroed by the caller; it receives the number of candidates.
+ */
+int flooder_ball_count_f32(const float* pts, int64_t n_pts, int dim, int ld,
+                           const float* centers /* n_simplices x dim */,
+                           const float* radii /* n_simplices */,
+                           const int64_t* slab_lo, const int64_t* slab_hi, int64_t n_simplices,
+                           int32_t* counts, void* stream);
+
+/*
+ * Candidate compaction.  Replaces torch.nonzero(mask) + the index casts + the gather
+ * y[w_idx] inside compute_filtration_kernel (core.py:218, triton_kernels.py:33,39,80-85): writes
+ * the coordinates of simplex i's candidates to cand rows [cand_off[i], cand_off[i]+counts[i]) and
+ * +inf rows up to cand_off[i+1] (the reference pads with indices that load +inf, :39), in
+ * unspecified order.  cand has padded rows (flooder_padded_dim(dim) floats).
+ *   cand_off: (n_simplices+1) int64, multiples of FLOODER_CAND_ALIGN;  cursor: n_simplices int32,
+ *   zeroed by the caller (scratch).
+ */
+int flooder_ball_fill_f32(const float* pts, int64_t n_pts, int dim, int ld,
+                          const float* centers, const float* radii,
+                          const int64_t* slab_lo, const int64_t* slab_hi, int64_t n_simplices,
+                          const int32_t* counts, const int64_t* cand_off, int32_t* cursor,
+                          float* cand, void* stream);
+
+/*
+ * Coverage sweep.  Replaces compute_filtration / compute_filtration_kernel
+ * (flooder/triton_kernels.py:12-96, call site core.py:219-226) fused with the sample generation
+ * points_on_simplex = weights @ simplex_vertices (core.py:188): for simplex s and sample r
+ *     p = sum_j weights[r,j] * verts[s,j,:]
+ *     out_d2[s,r] = min(out_d2[s,r], min_w sum_k (p_k - cand[w,k])^2)      (direct differences, :36-44)
+ * over the candidates w of s.  out_d2 (n_simplices x R uint32 d2 bits) must be pre-set to +inf bits
+ * (flooder_fill_u32); it is combined with atomic min so several launches (point shards) or several
+ * work items may target the same cell.  Work is split into items of (simplex, 512-sample tile,
+ * 2048-candidate chunk); item_prefix (n_simplices+1 int64) = exclusive prefix sum of
+ * tiles * ceil(count/2048) per simplex; queue = one int32 zeroed by the caller (work-queue head).
+ */
+int flooder_sweep_f32(const float* cand, const int64_t* cand_off, const int32_t* counts, int dim,
+                      const float* verts /* n_simplices x k1 x dim */, const float* weights /* R x k1 */,
+                      int k1, int R, int64_t n_simplices, const int64_t* item_prefix, int32_t* queue,
+                      uint32_t* out_d2, void* stream);
+
+/*
+ * Face maxima.  Replaces the extraction at core.py:251-276: out_face[s,f] =
+ * sqrt(max_{r in rows of face f} out_d2[s,r]) where face f's rows are
+ * face_rows[face_ptr[f] .. face_ptr[f+1]) (CSR over the concatenated faces of every codimension,
+ * grid mode) or all R rows (random mode: n_faces = 1, face_ptr = {0,R}, face_rows = 0..R-1).
+ * out_dist (n_simplices x R float32, may be NULL) receives sqrt of every cell (the reference's
+ * `distances` tensor, triton_kernels.py:44).
+ */
+int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const int32_t* face_ptr,
+                         const int32_t* face_rows, int n_faces, float* out_face, float* out_dist,
+                         void* stream);
+
+/* Set n uint32 words to `value` (used to initialise d2 buffers to +inf bits). */
+int flooder_fill_u32(uint32_t* buf, int64_t n, uint32_t value, void* stream);
+
+/*
+ * Farthest-point sampling.  Replaces fpsample.bucket_fps_kdline_sampling as called by
+ * generate_landmarks (flooder/core.py:337-343): exact FPS order starting at `start`.
+ *   out_idx: n_lms int64 (selection order, out_idx[0] = start);
+ *   work_min: n_pts float32 scratch (running squared distance to the selected set);
+ *   work_best: n_lms uint64 scratch, zeroed by the caller.
+ */
+int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms, int64_t start,
+                    int64_t* out_idx, float* work_min, uint64_t* work_best, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOODER_HIP_H */

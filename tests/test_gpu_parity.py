@@ -1,0 +1,197 @@
+"""Parity of the HIP path (through the C ABI in libflooder_hip.so) against the reference's golden
+outputs and against the oracle.  Runs on a real MI355X only (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import flooder_amd as fa
+from flooder_amd import _native, core
+from oracle import flood_oracle as fo
+from helpers import GOLDEN, assert_close_filtration, e2e_cases, load_e2e, dict_values
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    lib = _native.load()  # fails loudly when the HIP library is missing
+    buf = (b" " * 64)
+    import ctypes
+    cbuf = ctypes.create_string_buffer(64)
+    assert lib.flooder_device_arch(0, cbuf, 64) == 0
+    assert cbuf.value.decode().startswith("gfx950"), cbuf.value
+    return torch.device("cuda:0")
+
+
+def native_min_dist(points, centers, radii, samples, dev):
+    """compute_mask + compute_filtration replacement for explicit sample points: one pass per
+    simplex with verts = identity so that p = sum_j w_j e_j = the given sample exactly."""
+    lib = _native.load()
+    pts = torch.as_tensor(points, device=dev)
+    dim = pts.shape[1]
+    axis = 0
+    order = torch.argsort(pts[:, axis])
+    pad = core._pad_rows(pts[order], lib.flooder_padded_dim(dim))
+    search = pad[:, axis].contiguous()
+    out, cnts = [], []
+    for s in range(samples.shape[0]):
+        verts = torch.eye(dim, device=dev).unsqueeze(0)
+        w = torch.as_tensor(samples[s], device=dev)
+        faces = core._FaceTable(None, w.shape[0], dev)
+        core.LAST_STATS.reset()
+        _, dist = core._sweep_dimension_hip(pad, search, axis, dim, verts,
+                                            torch.as_tensor(centers[s:s + 1], device=dev),
+                                            torch.as_tensor(radii[s:s + 1], device=dev), w, faces, None,
+                                            want_dist=True)
+        out.append(dist.cpu().numpy()[0])
+        cnts.append(core.LAST_STATS.candidate_pairs)
+    return np.stack(out), np.array(cnts)
+
+
+@pytest.mark.parametrize("name", ["k2d", "k3d", "k5d"])
+def test_kernels_match_reference_triton_vectors(name, dev):
+    """Kernel-level golden vectors produced by the reference's own Triton kernels."""
+    z = np.load(os.path.join(GOLDEN, f"kernel_{name}.npz"))
+    d, cnts = native_min_dist(z["points"], z["centers"], z["radii"], z["samples"], dev)
+    assert np.array_equal(cnts, z["mask_rowsum"])  # integer work: exact
+    ref = z["min_dist"]
+    assert np.array_equal(np.isinf(d), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert_close_filtration(d[fin], ref[fin], z["points"], name)
+
+
+@pytest.mark.parametrize("name", e2e_cases())
+def test_e2e_matches_reference_goldens(name, dev):
+    z, kw, keys = load_e2e(name)
+    torch.manual_seed(int(z["weight_seed"]))
+    fc = fa.flood_complex(torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev), **kw)
+    assert set(keys) == set(fc)
+    assert_close_filtration(dict_values(fc, keys), z["filtration_f32"], z["points"], name)
+
+
+def test_plain_and_packed_variants_are_bit_identical(dev):
+    lib = _native.load()
+    z, kw, keys = load_e2e("torus3d_grid")
+    pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
+    try:
+        assert lib.flooder_set_option(b"sweep_variant", 1) == 0
+        a = fa.flood_complex(pts, lms, **kw)
+    finally:
+        assert lib.flooder_set_option(b"sweep_variant", 0) == 0
+    b = fa.flood_complex(pts, lms, **kw)
+    assert a == b
+
+
+def test_medium_cloud_against_kdtree_oracle(dev):
+    """100 k torus / 300 landmarks: HIP path vs the oracle (reference CPU algorithm) on the same input."""
+    pts = fo.noisy_torus(100_000, seed=42)
+    idx = fo.exact_fps(pts, 300, 0)
+    lms = pts[idx]
+    ref = fo.flood_complex_oracle(pts, lms, points_per_edge=12)
+    fc = fa.flood_complex(torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev), points_per_edge=12)
+    keys = sorted(ref)
+    assert set(keys) == set(fc)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), pts, "torus100k")
+    # vertices are witnesses of themselves: exactly zero
+    assert all(fc[(i,)] == 0.0 for i in range(300))
+
+
+def test_random_mode_and_landmark_count_gpu(dev):
+    pts = fo.noisy_torus(10_000, seed=1)
+    tp = torch.as_tensor(pts, device=dev)
+    torch.manual_seed(5)
+    fc = fa.flood_complex(tp, 200, points_per_edge=None, num_rand=512)
+    lms = pts[fo.exact_fps(pts, 200, 0)]
+    torch.manual_seed(5)
+    ref = fo.flood_complex_oracle(pts, lms, points_per_edge=None, num_rand=512)
+    keys = sorted(ref)
+    assert set(keys) == set(fc)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), pts, "rand512")
+
+
+def test_fps_matches_exact_fps(dev):
+    pts = fo.noisy_torus(50_000, seed=3)
+    ref = fo.exact_fps(pts, 256, 17)
+    got = core.fps_indices(torch.as_tensor(pts, device=dev), 256, 17).cpu().numpy()
+    assert np.array_equal(got, ref)
+    L = fa.generate_landmarks(torch.as_tensor(pts, device=dev), 64, start_idx=0)
+    assert L.shape == (64, 3) and L.dtype == torch.float32 and L.is_cuda
+
+
+def test_landmarks_clamped_to_point_count(dev):
+    pts = fo.noisy_torus(500, seed=9)
+    tp = torch.as_tensor(pts, device=dev)
+    fc = fa.flood_complex(tp, 2000, points_per_edge=6)  # more landmarks than points (reference test_triton)
+    ref = fo.flood_complex_oracle(pts, pts[fo.exact_fps(pts, 500, 0)], points_per_edge=6)
+    keys = sorted(ref)
+    assert set(keys) == set(fc)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), pts, "clamp")
+
+
+def test_workspace_grouping_is_invisible(dev, monkeypatch):
+    z, kw, keys = load_e2e("cheese3d_grid")
+    pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
+    a = fa.flood_complex(pts, lms, **kw)
+    monkeypatch.setattr(core, "CAND_WORKSPACE_BYTES", 1)  # floor of 2^20 rows per group
+    b = fa.flood_complex(pts, lms, batch_size=7, **kw)
+    assert a == b
+
+
+def test_float64_input_gpu(dev):
+    z, kw, keys = load_e2e("torus3d_grid")
+    with pytest.warns(RuntimeWarning):
+        fc = fa.flood_complex(torch.as_tensor(z["points"], device=dev).double(),
+                              torch.as_tensor(z["landmarks"], device=dev).double(), **kw)
+    assert_close_filtration(dict_values(fc, keys), z["filtration_f64"], z["points"], "f64 input")
+
+
+def test_shard_min_reduce_equals_unsharded(dev):
+    """Multi-GPU rule on one GPU: min over shards of the per-sample buffer == unsharded, bit for bit."""
+    pts = fo.noisy_torus(60_000, seed=11)
+    lms = pts[fo.exact_fps(pts, 150, 0)]
+    tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
+    full = fa.flood_complex(tp, tl, points_per_edge=10)
+    captured = []
+    for r in range(3):
+        fa.flood_complex(tp[r::3].contiguous(), tl, points_per_edge=10,
+                         reduce_hook=lambda buf, c=captured: c.append(buf.clone()))
+    merged = torch.minimum(torch.minimum(captured[0], captured[1]), captured[2])
+    out = fa.flood_complex(tp[0::3].contiguous(), tl, points_per_edge=10,
+                           reduce_hook=lambda buf: buf.copy_(merged))
+    assert out == full
+
+
+def test_full_size_properties_1m_gaussian(dev):
+    """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
+    vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""
+    torch.manual_seed(42)
+    pts = torch.randn(1_000_000, 3)
+    tp = pts.to(dev)
+    lms = fa.generate_landmarks(tp, 1000, start_idx=0)
+    st = fa.flood_complex(tp, lms, return_simplex_tree=True)
+    assert all(st.filtration([i]) == 0.0 for i in range(0, 1000, 37))
+    tets = st.simplices_of_dimension(3)
+    vals = st.filtrations_of_dimension(3)
+    assert np.isfinite(vals).all()
+    for d in (1, 2, 3):  # faces never above cofaces
+        rows = st.simplices_of_dimension(d)
+        own = st.filtrations_of_dimension(d)
+        for j in range(d + 1):
+            idx = st._locate(d - 1, np.delete(rows, j, axis=1))
+            assert (st.filtrations_of_dimension(d - 1)[idx] <= own).all()
+    # oracle on a sample of tetrahedra: their own value before monotonisation can only be lower, so
+    # compare max(own sweep value, faces) == tree value through the same rule
+    from scipy.spatial import KDTree
+    P = pts.numpy()
+    L = lms.cpu().numpy()
+    tree = KDTree(P)
+    w, v_idx, f_idx = fo.generate_grid(30, 3)
+    rng = np.random.default_rng(0)
+    pick = rng.choice(len(tets), size=40, replace=False)
+    samples = np.matmul(w[None], L[tets[pick]])
+    dist, _ = tree.query(samples)
+    ref = dist.max(axis=1)
+    assert_close_filtration(vals[pick], ref, P, "1M gaussian tetrahedra sample")

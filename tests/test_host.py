@@ -1,0 +1,142 @@
+"""Host logic of flooder_amd on CPU: API surface, error behaviour, the CPU branch against the
+reference's golden outputs, the simplex tree, and the C-ABI library's symbols."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import flooder_amd as fa
+from flooder_amd import _native, core
+from flooder_amd.simplex_tree import SimplexTree, delaunay_simplices
+from helpers import GOLDEN, e2e_cases, load_e2e, dict_values
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", e2e_cases())
+def test_cpu_branch_matches_reference(name):
+    z, kw, keys = load_e2e(name)
+    torch.manual_seed(int(z["weight_seed"]))
+    fc = fa.flood_complex(torch.as_tensor(z["points"]), torch.as_tensor(z["landmarks"]), **kw)
+    assert set(keys) == set(fc)
+    assert np.abs(dict_values(fc, keys) - z["filtration_f32"]).max() < 5e-7
+
+
+def test_cpu_branch_float64_matches_reference():
+    z, kw, keys = load_e2e("torus3d_grid")
+    with pytest.warns(RuntimeWarning):
+        fc = fa.flood_complex(torch.as_tensor(z["points"]).double(), torch.as_tensor(z["landmarks"]).double(), **kw)
+    assert np.abs(dict_values(fc, keys) - z["filtration_f64"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,dim", [(2, 1), (5, 2), (8, 3), (30, 3), (4, 4), (3, 6), (20, 2)])
+def test_generate_grid_matches_reference(n, dim):
+    g = np.load(os.path.join(GOLDEN, "grid_vectors.npz"))
+    w, v, f = fa.generate_grid(n, dim, torch.device("cpu"), torch.float32)
+    assert np.array_equal(w.numpy(), g[f"w_{n}_{dim}"])
+    for k in range(dim + 1):
+        assert np.array_equal(v[k].numpy(), g[f"v_{n}_{dim}_{k}"])
+        assert np.array_equal(f[k].numpy(), g[f"f_{n}_{dim}_{k}"])
+
+
+def test_uniform_weights_match_reference():
+    g = np.load(os.path.join(GOLDEN, "grid_vectors.npz"))
+    torch.manual_seed(42)
+    w = fa.generate_uniform_weights(64, 3, torch.device("cpu"), torch.float32)
+    assert np.array_equal(w.numpy(), g["u_64_3_seed42"])
+
+
+def test_landmarks_int_and_return_tree():
+    z, kw, keys = load_e2e("torus3d_grid")
+    pts = torch.as_tensor(z["points"])
+    st = fa.flood_complex(pts, 60, return_simplex_tree=True, **kw)  # FPS from index 0, as the golden
+    vals = {tuple(s): f for s, f in st.get_simplices()}
+    assert set(vals) == set(keys)
+    assert np.abs(dict_values(vals, keys) - z["filtration_f32"]).max() < 5e-7
+    for simplex, filtration in st.get_simplices():  # reference test_filtration_condition
+        faces = list(st.get_boundaries(simplex))
+        assert len(faces) == (len(simplex) if len(simplex) > 1 else 0)
+        for _, ff in faces:
+            assert ff <= filtration
+
+
+def test_generate_landmarks_contract():
+    torch.manual_seed(42)
+    X = torch.rand(2000, 2)
+    for n in (64, 256):
+        L = fa.generate_landmarks(X, n)
+        assert L.shape == (n, 2) and L.dtype == torch.float32 and L.device == X.device
+    L = fa.generate_landmarks(X, 5000)
+    assert L.shape == (2000, 2)  # clamped to the number of points (core.py:328)
+    with pytest.raises(RuntimeError):
+        fa.generate_landmarks(X, 0)
+    L0 = fa.generate_landmarks(X, 10, start_idx=7)
+    assert torch.equal(L0[0], X[7])
+
+
+def test_error_behaviour():
+    pts = torch.rand(100, 3)
+    with pytest.raises(RuntimeError):
+        fa.flood_complex(pts, torch.rand(10, 3).double())
+    with pytest.raises(TypeError):
+        fa.flood_complex(pts.half(), pts[:10].half())
+    if torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            fa.flood_complex(pts.cuda(), pts[:10])
+
+
+def test_simplex_tree_basics():
+    st = SimplexTree()
+    assert st.insert([0, 1, 2], 1.0)
+    assert st.num_simplices() == 7 and st.num_vertices() == 3 and st.dimension() == 2
+    assert not st.insert([0, 1], 2.0)  # present: keeps min(old, new)
+    assert st.filtration([0, 1]) == 1.0
+    st.assign_filtration([0, 1], 3.0)
+    assert st.filtration([0, 1]) == 3.0
+    assert st.make_filtration_non_decreasing()
+    assert st.filtration([0, 1, 2]) == 3.0
+    order = [tuple(s) for s, _ in st.get_simplices()]
+    assert order == [(0,), (0, 1), (0, 1, 2), (0, 2), (1,), (1, 2), (2,)]
+    assert [tuple(s) for s, _ in st.get_boundaries([0, 1, 2])] == [(1, 2), (0, 2), (0, 1)]
+    assert st.find([1, 2]) and not st.find([1, 3])
+
+
+def test_delaunay_buckets_are_closed_complex():
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(40, 3))
+    dims = delaunay_simplices(pts)
+    assert [a.shape[1] for a in dims] == [1, 2, 3, 4]
+    st = SimplexTree.from_arrays(dims)
+    for tet in dims[3][:20]:
+        assert len(list(st.get_boundaries(tet))) == 4
+    # Euler characteristic of a triangulated ball
+    assert dims[0].shape[0] - dims[1].shape[0] + dims[2].shape[0] - dims[3].shape[0] == 1
+
+
+def test_native_library_loads_and_exports_header_symbols():
+    """The C-ABI shared library loads and exports every function include/flooder_hip.h declares."""
+    import ctypes
+
+    header = open(os.path.join(ROOT, "include", "flooder_hip.h")).read()
+    declared = set(re.findall(r"\b(flooder_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_native.LIB_PATH), "libflooder_hip.so not built (python -m flooder_amd.build)"
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_native.SIGNATURES), "ctypes binding and header disagree"
+    assert lib.flooder_abi_version() == 1
+    assert [lib.flooder_padded_dim(d) for d in (1, 2, 3, 4, 5, 8)] == [2, 2, 4, 4, 8, 8]
+
+
+def test_rocm_tensor_without_library_fails_loudly(monkeypatch):
+    """No silent fallback: a missing library is an ImportError for GPU inputs."""
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_load_error", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libflooder_hip.so")
+    with pytest.raises(ImportError):
+        _native.load()
+    with pytest.raises(ImportError):
+        fa.flood_complex(torch.rand(10, 2), torch.rand(4, 2), use_triton=True)
