@@ -243,15 +243,57 @@ class SweepStats:
 LAST_STATS = SweepStats()
 
 
+class _KernelTimer:
+    """Optional HIP-event timing of the individual kernels (events on the launch stream)."""
+
+    def __init__(self):
+        self.spans: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
+
+    def span(self, name: str):
+        timer = self
+
+        class _Span:
+            def __enter__(self_inner):
+                self_inner.a = torch.cuda.Event(enable_timing=True)
+                self_inner.b = torch.cuda.Event(enable_timing=True)
+                self_inner.a.record()
+
+            def __exit__(self_inner, *exc):
+                self_inner.b.record()
+                timer.spans.setdefault(name, []).append((self_inner.a, self_inner.b))
+
+        return _Span()
+
+    def totals_ms(self) -> Dict[str, float]:
+        """Sum of elapsed ms per kernel name (call after a device synchronize)."""
+        return {k: float(sum(a.elapsed_time(b) for a, b in v)) for k, v in self.spans.items()}
+
+    def counts(self) -> Dict[str, int]:
+        return {k: len(v) for k, v in self.spans.items()}
+
+
+class _NullSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _span(timer: Optional[_KernelTimer], name: str):
+    return timer.span(name) if timer is not None else _NullSpan()
+
+
 def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int, dim: int,
                          verts: torch.Tensor, centers: torch.Tensor, radii: torch.Tensor,
                          weights: torch.Tensor, faces: _FaceTable,
                          reduce_hook: Optional[Callable[[torch.Tensor], None]],
-                         want_dist: bool = False):
+                         want_dist: bool = False, timer: Optional[_KernelTimer] = None):
     """All simplices of one dimension against one (sorted, padded) point set -> (S, F) face maxima.
 
     Steps: per-simplex slab by searchsorted (core.py:201-208) -> ball count -> offsets (cumsum) ->
     candidate fill -> sweep (atomic-min into d2 bits) -> [reduce_hook: cross-shard MIN] -> face max.
+    One device->host copy (three totals) sizes the candidate workspace.
     """
     lib = _native.load()
     dev = pts_pad.device
@@ -269,9 +311,10 @@ def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int,
     lo = torch.searchsorted(search, (centers[:, axis] - radii).contiguous(), right=False)
     hi = torch.searchsorted(search, (centers[:, axis] + radii).contiguous(), right=True)
     counts = torch.zeros(S, dtype=torch.int32, device=dev)
-    _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad), n, dim, dp, _native.ptr(centers),
-                                             _native.ptr(radii), _native.ptr(lo), _native.ptr(hi), S,
-                                             _native.ptr(counts), st), "flooder_ball_count_f32")
+    with _span(timer, "ball_count"):
+        _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad), n, dim, dp, _native.ptr(centers),
+                                                 _native.ptr(radii), _native.ptr(lo), _native.ptr(hi), S,
+                                                 _native.ptr(counts), st), "flooder_ball_count_f32")
     tiles = (R + TILE_SAMPLES - 1) // TILE_SAMPLES
     c64 = counts.to(torch.int64)
     padded = (c64 + (CAND_ALIGN - 1)) // CAND_ALIGN * CAND_ALIGN
@@ -280,56 +323,62 @@ def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int,
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     _native.check(lib.flooder_fill_u32(_native.ptr(d2), S * R, INF_BITS, st), "flooder_fill_u32")
 
-    # group simplices so that each group's candidate workspace fits the budget (one D->H sync)
     csum = torch.cumsum(padded, 0)
-    total_rows = int(csum[-1].item()) if S else 0
-    LAST_STATS.candidate_pairs += int(c64.sum().item())
-    LAST_STATS.slab_points += int((hi - lo).sum().item())
+    totals = torch.stack([csum[-1], c64.sum(), (hi - lo).sum()]).cpu().tolist()  # the one sync
+    total_rows = int(totals[0])
+    LAST_STATS.candidate_pairs += int(totals[1])
+    LAST_STATS.slab_points += int(totals[2])
+
+    # group simplices so that each group's candidate workspace fits the budget
     rows_budget = max(CAND_WORKSPACE_BYTES // (4 * dp), 1 << 20)
     bounds = [0]
+    group_rows: List[int] = []
     if total_rows > rows_budget:
         csum_h = csum.cpu().numpy()
         start_rows = 0
         while bounds[-1] < S:
             e = int(np.searchsorted(csum_h, start_rows + rows_budget, side="right"))
-            e = max(e, bounds[-1] + 1)
-            e = min(e, S)
+            e = min(max(e, bounds[-1] + 1), S)
             bounds.append(e)
+            group_rows.append(int(csum_h[e - 1]) - start_rows)
             start_rows = int(csum_h[e - 1])
     else:
         bounds.append(S)
+        group_rows.append(total_rows)
 
-    for b, e in zip(bounds[:-1], bounds[1:]):
+    for b, e, n_rows in zip(bounds[:-1], bounds[1:], group_rows):
         ns = e - b
-        g_pad = padded[b:e]
         cand_off = torch.zeros(ns + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(g_pad, 0, out=cand_off[1:])
+        torch.cumsum(padded[b:e], 0, out=cand_off[1:])
         item_prefix = torch.zeros(ns + 1, dtype=torch.int64, device=dev)
         torch.cumsum(items[b:e], 0, out=item_prefix[1:])
-        n_rows = int(csum[e - 1].item() - (csum[b - 1].item() if b > 0 else 0)) if ns else 0
         cand = torch.empty((max(n_rows, 1), dp), dtype=torch.float32, device=dev)
         cursor = torch.zeros(ns + 1, dtype=torch.int32, device=dev)  # [0:ns] fill cursors, [ns] sweep queue
         g_counts = counts[b:e]
-        _native.check(lib.flooder_ball_fill_f32(
-            _native.ptr(pts_pad), n, dim, dp, _native.ptr(centers[b:e]), _native.ptr(radii[b:e]),
-            _native.ptr(lo[b:e]), _native.ptr(hi[b:e]), ns, _native.ptr(g_counts),
-            _native.ptr(cand_off), _native.ptr(cursor), _native.ptr(cand), st), "flooder_ball_fill_f32")
-        _native.check(lib.flooder_sweep_f32(
-            _native.ptr(cand), _native.ptr(cand_off), _native.ptr(g_counts), dim,
-            _native.ptr(verts[b:e]), _native.ptr(weights), k1, R, ns, _native.ptr(item_prefix),
-            cursor[ns:].data_ptr(), d2[b:e].data_ptr(), st), "flooder_sweep_f32")
+        with _span(timer, "ball_fill"):
+            _native.check(lib.flooder_ball_fill_f32(
+                _native.ptr(pts_pad), n, dim, dp, _native.ptr(centers[b:e]), _native.ptr(radii[b:e]),
+                _native.ptr(lo[b:e]), _native.ptr(hi[b:e]), ns, _native.ptr(g_counts),
+                _native.ptr(cand_off), _native.ptr(cursor), _native.ptr(cand), st), "flooder_ball_fill_f32")
+        with _span(timer, "sweep"):
+            _native.check(lib.flooder_sweep_f32(
+                _native.ptr(cand), _native.ptr(cand_off), _native.ptr(g_counts), dim,
+                _native.ptr(verts[b:e]), _native.ptr(weights), k1, R, ns, _native.ptr(item_prefix),
+                cursor[ns:].data_ptr(), d2[b:e].data_ptr(), st), "flooder_sweep_f32")
         LAST_STATS.groups += 1
         del cand
 
     if reduce_hook is not None:
-        reduce_hook(d2)
+        with _span(timer, "reduce"):
+            reduce_hook(d2)
 
     out_face = torch.empty((S, faces.n_faces), dtype=torch.float32, device=dev)
     out_dist = torch.empty((S, R), dtype=torch.float32, device=dev) if want_dist else None
-    _native.check(lib.flooder_face_max_f32(_native.ptr(d2), S, R, _native.ptr(faces.ptr),
-                                           _native.ptr(faces.rows), faces.n_faces,
-                                           _native.ptr(out_face), _native.ptr(out_dist), st),
-                  "flooder_face_max_f32")
+    with _span(timer, "face_max"):
+        _native.check(lib.flooder_face_max_f32(_native.ptr(d2), S, R, _native.ptr(faces.ptr),
+                                               _native.ptr(faces.rows), faces.n_faces,
+                                               _native.ptr(out_face), _native.ptr(out_dist), st),
+                      "flooder_face_max_f32")
     return out_face, out_dist
 
 
@@ -356,6 +405,7 @@ def flood_complex(
     start_idx: Union[int, None] = 0,
     *,
     reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
+    sort_axis: Optional[int] = None,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -369,7 +419,9 @@ def flood_complex(
     grouping simplices against ``CAND_WORKSPACE_BYTES`` instead.  ``reduce_hook`` (keyword-only
     extension) is called with the (S, R) int32 tensor of minimum squared-distance bit patterns of every
     dimension pass before the per-face maxima are taken; ``flooder_amd.distributed`` uses it for the
-    cross-GPU ``all_reduce(MIN)``.
+    cross-GPU ``all_reduce(MIN)``.  ``sort_axis`` (keyword-only) fixes the coordinate axis used for the
+    cloud sort and the simplex order instead of deriving it from ``points`` (ranks holding different
+    shards must agree on the simplex order of the reduced buffer).
     """
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
@@ -413,7 +465,10 @@ def flood_complex(
     LAST_STATS.n_points = points.shape[0]
 
     # sort the cloud along its widest axis (core.py:140-144)
-    axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
+    if sort_axis is None:
+        axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
+    else:
+        axis = int(sort_axis)
     if on_gpu:
         pts32 = points.to(torch.float32)
         order = torch.argsort(pts32[:, axis])

@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from .core import flood_complex
 
-__all__ = ["shard_points", "min_reduce_hook", "flood_complex_sharded"]
+__all__ = ["shard_points", "min_reduce_hook", "global_widest_axis", "flood_complex_sharded"]
 
 
 def shard_points(points: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
@@ -43,6 +43,18 @@ def min_reduce_hook(group: Optional[dist.ProcessGroup] = None):
     return hook
 
 
+def global_widest_axis(points_shard: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> int:
+    """Axis of largest extent of the WHOLE cloud (what ``core.py:140-142`` computes on one device),
+    from per-shard extrema combined with two tiny all-reduces, so that every rank sorts its simplices
+    the same way."""
+    lo = points_shard.min(dim=0).values.to(torch.float32)
+    hi = points_shard.max(dim=0).values.to(torch.float32)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return int(torch.argmax(hi - lo).item())
+
+
 def flood_complex_sharded(points_shard: torch.Tensor, landmarks: torch.Tensor, *args,
                           group: Optional[dist.ProcessGroup] = None, **kwargs):
     """``flood_complex`` where each rank passes its own shard of the cloud and the SAME landmark
@@ -50,4 +62,6 @@ def flood_complex_sharded(points_shard: torch.Tensor, landmarks: torch.Tensor, *
     if not isinstance(landmarks, torch.Tensor):
         raise TypeError("flood_complex_sharded needs explicit landmark coordinates (identical on every "
                         "rank); run generate_landmarks on the full cloud first")
-    return flood_complex(points_shard, landmarks, *args, reduce_hook=min_reduce_hook(group), **kwargs)
+    axis = global_widest_axis(points_shard, group)
+    return flood_complex(points_shard, landmarks, *args, reduce_hook=min_reduce_hook(group),
+                         sort_axis=axis, **kwargs)

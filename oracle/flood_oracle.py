@@ -273,3 +273,38 @@ def noisy_torus(n: int, seed: int, R: float = 3.0, r: float = 1.0, noise_std: fl
     z = r * torch.sin(phi)
     p = torch.stack((x, y, z), dim=1)
     return (p + torch.randn_like(p) * noise_std).numpy()
+
+
+# --------------------------------------------------------------------------- timed CPU baseline
+def kdtree_sweep_sample(points: np.ndarray, landmarks: np.ndarray, simplices: np.ndarray,
+                        points_per_edge: int, d: int, n_sample: int, seed: int = 0, workers: int = 1):
+    """The reference CPU path (``core.py:127-128, 188, 197-199, 251-257``) on a random subset of the
+    top-dimensional ``simplices`` (rows of landmark ids, in the caller's order): kd-tree build,
+    ``weights @ vertices`` samples, ``KDTree.query`` (float64), per-face maxima with the faces of all
+    codimensions concatenated (codimension-major, the order of ``generate_grid``'s ``face_idxs``).
+
+    Returns ``picked`` (row indices, ascending), ``face_max`` (n_sample, F), and wall-clock seconds of
+    the tree build and of sample generation + query.  Used by ``bench.py`` as the CPU baseline and as
+    a parity check of the GPU result at full size.
+    """
+    import time
+    from scipy.spatial import KDTree
+
+    points = np.ascontiguousarray(points)
+    dt = points.dtype
+    rng = np.random.default_rng(seed)
+    picked = np.sort(rng.choice(simplices.shape[0], size=n_sample, replace=False))
+    t0 = time.perf_counter()
+    tree = KDTree(points)
+    build_s = time.perf_counter() - t0
+    weights, vertex_idxs, face_idxs = generate_grid(points_per_edge, d, dt.type)
+    t0 = time.perf_counter()
+    verts = landmarks[simplices[picked]]
+    samples = np.matmul(weights[None], verts).astype(dt)
+    dist, _ = tree.query(samples, workers=workers)
+    cols = []
+    for f_idx in face_idxs:
+        cols.append(dist[:, f_idx].max(axis=2))
+    face_max = np.concatenate(cols, axis=1)
+    query_s = time.perf_counter() - t0
+    return dict(picked=picked, face_max=face_max, build_s=build_s, query_s=query_s, n_sample=int(n_sample))

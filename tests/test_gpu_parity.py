@@ -154,12 +154,13 @@ def test_shard_min_reduce_equals_unsharded(dev):
     lms = pts[fo.exact_fps(pts, 150, 0)]
     tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
     full = fa.flood_complex(tp, tl, points_per_edge=10)
+    axis = int(np.argmax(pts.max(0) - pts.min(0)))
     captured = []
     for r in range(3):
-        fa.flood_complex(tp[r::3].contiguous(), tl, points_per_edge=10,
+        fa.flood_complex(tp[r::3].contiguous(), tl, points_per_edge=10, sort_axis=axis,
                          reduce_hook=lambda buf, c=captured: c.append(buf.clone()))
     merged = torch.minimum(torch.minimum(captured[0], captured[1]), captured[2])
-    out = fa.flood_complex(tp[0::3].contiguous(), tl, points_per_edge=10,
+    out = fa.flood_complex(tp[0::3].contiguous(), tl, points_per_edge=10, sort_axis=axis,
                            reduce_hook=lambda buf: buf.copy_(merged))
     assert out == full
 
