@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the CPU baseline sample")
     ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
+    ap.add_argument("--method", default="bvh", choices=["bvh", "ball"],
+                    help="bvh: hierarchically culled sweep (default); ball: the reference's formulation")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -110,19 +112,41 @@ def main():
     weights, vertex_idxs, face_idxs = core.generate_grid(w["ppe"], d, dev, torch.float32)
     faces = core._FaceTable(face_idxs, weights.shape[0], dev)
     order_p = torch.argsort(pts_full[:, axis])
-    sorted_pts = pts_full[order_p]
-    shard = sorted_pts[rank::world].contiguous()
+    shard_raw = pts_full[order_p][rank::world].contiguous()  # this rank's interleaved share (raw rows)
     dp = lib.flooder_padded_dim(w["dim"])
-    pts_pad = core._pad_rows(shard, dp)
-    search = pts_pad[:, axis].contiguous()
-    del pts_full, sorted_pts, shard
+    del pts_full
     hook = min_reduce_hook() if world > 1 else None
     S, R = verts.shape[0], weights.shape[0]
 
+    # reference-defined work of this input (untimed): candidate pairs P = sum_s |X n ball_s|
+    pts_pad0 = core._pad_rows(shard_raw, dp)
+    search0 = pts_pad0[:, axis].contiguous()
+    lo0 = torch.searchsorted(search0, (centers[:, axis] - radii).contiguous(), right=False)
+    hi0 = torch.searchsorted(search0, (centers[:, axis] + radii).contiguous(), right=True)
+    cnt0 = torch.zeros(S, dtype=torch.int32, device=dev)
+    _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad0), pts_pad0.shape[0], w["dim"], dp,
+                                             _native.ptr(centers.contiguous()), _native.ptr(radii.contiguous()),
+                                             _native.ptr(lo0), _native.ptr(hi0), S, _native.ptr(cnt0),
+                                             _native.current_stream_ptr(dev)), "ball_count")
+    P_local = int(cnt0.sum().item())
+    del pts_pad0, search0, lo0, hi0, cnt0
+    stats = torch.zeros(3, dtype=torch.int64, device=dev)
+
     def step(timer=None):
+        """raw (unsorted-for-this-method) shard in HBM -> per-face filtration values in HBM"""
         core.LAST_STATS.reset()
-        out, _ = core._sweep_dimension_hip(pts_pad, search, axis, w["dim"], verts, centers, radii, weights,
-                                           faces, hook, timer=timer)
+        if args.method == "bvh":
+            with core._span(timer, "index_total"):
+                index = core.PointIndex(shard_raw, timer)
+            stats.zero_()
+            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats)
+        else:
+            with core._span(timer, "index_total"):
+                o = torch.argsort(shard_raw[:, axis])
+                pts_pad = core._pad_rows(shard_raw[o], dp)
+                search = pts_pad[:, axis].contiguous()
+            out, _ = core._sweep_dimension_hip(pts_pad, search, axis, w["dim"], verts, centers, radii, weights,
+                                               faces, hook, timer=timer)
         return out
 
     def sync_all():
@@ -151,14 +175,20 @@ def main():
     k_ms = timer.totals_ms()
     k_n = timer.counts()
     sweep_ms = k_ms["sweep"] / k_n["sweep"]
-    P_local = core.LAST_STATS.candidate_pairs
     slab_local = core.LAST_STATS.slab_points
     # algorithmic bytes of one sweep launch on this rank: every candidate row read
     # once per simplex, vertices, weights, and the (S, R) minimum buffer written once
     alg_bytes = P_local * w["dim"] * 4 + S * (d + 1) * w["dim"] * 4 + R * (d + 1) * 4 + S * R * 4
     achieved_gbs = alg_bytes / (sweep_ms * 1e-3) / 1e9
-    pair_evals = P_local * R
-    valu_tflops = 10.0 * pair_evals / (sweep_ms * 1e-3) / 1e12  # 3d+1 flop per pair, d = 3
+    pair_evals = P_local * R                       # what the reference's formulation evaluates
+    if args.method == "bvh":
+        st_h = stats.cpu().tolist()
+        ks = 8 if R > 256 else (4 if R > 128 else (2 if R > 64 else 1))
+        done_evals = st_h[0] * 16 * 64 * ks        # leaves evaluated x 16 points x tile samples
+    else:
+        st_h = None
+        done_evals = pair_evals
+    valu_tflops = 10.0 * done_evals / (sweep_ms * 1e-3) / 1e12  # 3d+1 flop per evaluated pair, d = 3
 
     result = {
         "metric": "M points×simplices/s (coverage sweep)",
@@ -177,13 +207,16 @@ def main():
             "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S,
             "samples_per_simplex": R, "candidate_pairs_rank0": P_local, "pair_evals_rank0": pair_evals,
             "ball_tests_rank0": slab_local, "parallelism": f"point-shard x{world}" if world > 1 else "single GPU",
-            "sweep_variant": "plain" if args.variant == 1 else "packed",
+            "method": args.method, "pair_evals_done_rank0": done_evals,
+            "bvh_stats_rank0": None if st_h is None else {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1],
+                                                          "nodes_expanded": st_h[2]},
         },
         "roofline": {
-            "kernel": "sweep_kernel", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+            "kernel": "sweep_bvh_kernel" if args.method == "bvh" else "sweep_kernel", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes": alg_bytes, "avg_launch_ms": round(sweep_ms, 4),
-            "note": "arithmetic intensity ~4k flop/B: the kernel is fp32-VALU-bound, see valu",
+            "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + (S,R) minima "
+                    "(SURVEY.md 8d); the kernel itself is fp32-VALU/latency-bound, see valu",
             "valu": {"achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flop_per_pair": 10},
         },

@@ -31,6 +31,12 @@ SIGNATURES = {
                                   c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_face_max_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p]),
+    "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_bvh_node_count": (c_int64, [c_int64]),
+    "flooder_bvh_build_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
     "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),

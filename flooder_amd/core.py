@@ -47,6 +47,10 @@ INF_BITS = 0x7F800000
 CAND_ALIGN = 8
 SWEEP_CHUNK = 2048
 TILE_SAMPLES = 512
+BVH_LEAF = 16
+# device sweep: "bvh" = hierarchically culled exact nearest neighbour (default); "ball" = the
+# reference's formulation (bounding-ball candidate lists + exhaustive sweep of each list)
+SWEEP_METHOD = "bvh"
 # candidate workspace budget per group of simplices (bytes); bounds HBM use like the reference's
 # ``batch_size`` bounds its mask tensor
 CAND_WORKSPACE_BYTES = 16 << 30
@@ -382,6 +386,107 @@ def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int,
     return out_face, out_dist
 
 
+class PointIndex:
+    """Morton-sorted copy of a point set plus its implicit box tree (HBM resident).
+
+    ``pts``   (n_pad, DP) f32: rows in Morton order, padded with +inf rows to a multiple of 16
+    ``nodes`` (n_nodes, 2*DP) f32: box (lo, hi) of every node, leaves first (16 points each), then
+              one level per factor 64, every level padded to a multiple of 64 nodes
+    """
+
+    def __init__(self, points: torch.Tensor, timer: Optional[_KernelTimer] = None):
+        lib = _native.load()
+        dev = points.device
+        st = _native.current_stream_ptr(dev)
+        pts32 = points.detach().to(torch.float32).contiguous()
+        n, dim = pts32.shape
+        self.n, self.dim = n, dim
+        self.dp = lib.flooder_padded_dim(dim)
+        lo = pts32.min(dim=0).values
+        hi = pts32.max(dim=0).values
+        box = torch.stack([lo, hi]).cpu().numpy().astype(np.float32)  # host arrays for the C call
+        self.box_lo, self.box_hi = np.ascontiguousarray(box[0]), np.ascontiguousarray(box[1])
+        codes = torch.empty(n, dtype=torch.int64, device=dev)
+        with _span(timer, "morton"):
+            _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim,
+                                                 self.box_lo.ctypes.data, self.box_hi.ctypes.data,
+                                                 _native.ptr(codes), st), "flooder_morton_f32")
+        order = torch.argsort(codes)
+        n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
+        pts = torch.full((n_pad, self.dp), float("inf"), dtype=torch.float32, device=dev)
+        pts[:n, :dim] = pts32[order]
+        if self.dp > dim:
+            pts[:n, dim:] = 0.0
+        self.pts = pts
+        n_nodes = int(lib.flooder_bvh_node_count(n))
+        self.nodes = torch.empty((n_nodes, 2 * self.dp), dtype=torch.float32, device=dev)
+        with _span(timer, "bvh_build"):
+            _native.check(lib.flooder_bvh_build_f32(_native.ptr(self.pts), n, dim, _native.ptr(self.nodes), st),
+                          "flooder_bvh_build_f32")
+
+
+def sample_order(weights: torch.Tensor) -> np.ndarray:
+    """Permutation that lists the barycentric samples along a Morton curve of their weights, so that
+    every run of 512 consecutive samples (one tile of the sweep) is a compact patch of the simplex."""
+    w = weights.detach().cpu().numpy().astype(np.float64)
+    R, k1 = w.shape
+    if k1 <= 1 or R <= 64:
+        return np.arange(R, dtype=np.int64)
+    nd = k1 - 1
+    bits = max(1, min(10, 60 // nd))
+    q = np.clip((w[:, :nd] * ((1 << bits) - 1) + 0.5).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(R, dtype=np.int64)
+    for b in range(bits):
+        for k in range(nd):
+            code |= ((q[:, k] >> b) & 1) << (b * nd + k)
+    return np.argsort(code, kind="stable")
+
+
+def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
+                         reduce_hook: Optional[Callable[[torch.Tensor], None]],
+                         want_dist: bool = False, timer: Optional[_KernelTimer] = None,
+                         stats: Optional[torch.Tensor] = None):
+    """All simplices of one dimension against an indexed point set -> (S, F) face maxima.
+
+    sweep_bvh (plain stores into d2 bits, samples in Morton order of their weights) ->
+    [reduce_hook: cross-shard MIN] -> face max (face rows remapped to the permuted sample order).
+    No host synchronisation.
+    """
+    lib = _native.load()
+    dev = index.pts.device
+    st = _native.current_stream_ptr(dev)
+    S, k1, _ = verts.shape
+    R = weights.shape[0]
+    verts = verts.to(torch.float32).contiguous()
+    perm = sample_order(weights)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(R)
+    perm_t = torch.as_tensor(perm, device=dev)
+    w_perm = weights.to(torch.float32)[perm_t].contiguous()
+    rows_perm = torch.as_tensor(inv, device=dev)[faces.rows.long()].to(torch.int32).contiguous()
+
+    d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
+    queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    with _span(timer, "sweep"):
+        _native.check(lib.flooder_sweep_bvh_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_perm), k1, R, S, _native.ptr(queue), _native.ptr(d2), _native.ptr(stats), st),
+            "flooder_sweep_bvh_f32")
+    if reduce_hook is not None:
+        with _span(timer, "reduce"):
+            reduce_hook(d2)
+    out_face = torch.empty((S, faces.n_faces), dtype=torch.float32, device=dev)
+    out_dist = torch.empty((S, R), dtype=torch.float32, device=dev) if want_dist else None
+    with _span(timer, "face_max"):
+        _native.check(lib.flooder_face_max_f32(_native.ptr(d2), S, R, _native.ptr(faces.ptr),
+                                               _native.ptr(rows_perm), faces.n_faces,
+                                               _native.ptr(out_face), _native.ptr(out_dist), st),
+                      "flooder_face_max_f32")
+    if out_dist is not None:
+        out_dist = out_dist[:, torch.as_tensor(inv, device=dev)]  # back to the caller's sample order
+    return out_face, out_dist
+
+
 def _face_max_cpu(dist: torch.Tensor, faces: _FaceTable) -> torch.Tensor:
     ptr = faces.ptr.cpu().numpy()
     rows = faces.rows.cpu().numpy()
@@ -406,6 +511,7 @@ def flood_complex(
     *,
     reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
     sort_axis: Optional[int] = None,
+    method: Optional[str] = None,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -421,8 +527,16 @@ def flood_complex(
     dimension pass before the per-face maxima are taken; ``flooder_amd.distributed`` uses it for the
     cross-GPU ``all_reduce(MIN)``.  ``sort_axis`` (keyword-only) fixes the coordinate axis used for the
     cloud sort and the simplex order instead of deriving it from ``points`` (ranks holding different
-    shards must agree on the simplex order of the reduced buffer).
+    shards must agree on the simplex order of the reduced buffer).  ``method`` (keyword-only):
+    ``"bvh"`` (default) evaluates the exact nearest neighbour with hierarchical culling; ``"ball"``
+    runs the reference's formulation literally (bounding-ball candidates, exhaustive sweep).  Both give
+    the same values whenever the landmarks are points of the cloud (the reference's precondition for its
+    own GPU path); for other landmarks ``"bvh"`` returns the exact value of the
+    reference's CPU path.
     """
+    method = SWEEP_METHOD if method is None else method
+    if method not in ("bvh", "ball"):
+        raise ValueError(f"method must be 'bvh' or 'ball', got {method!r}")
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
     if use_triton and not _has_hip_kernels():
@@ -473,9 +587,12 @@ def flood_complex(
         pts32 = points.to(torch.float32)
         order = torch.argsort(pts32[:, axis])
         dp = _native.load().flooder_padded_dim(dim)
-        pts_pad = _pad_rows(pts32[order], dp)
-        search = pts_pad[:, axis].contiguous()
         lm32 = landmarks.to(torch.float32)
+        if method == "ball":
+            pts_pad = _pad_rows(pts32[order], dp)
+            search = pts_pad[:, axis].contiguous()
+        else:
+            index = PointIndex(pts32)
 
     results: List[Tuple[np.ndarray, np.ndarray]] = []  # (simplices (n,k), values (n,)) in update order
     for d in range(max_dimension + 1):
@@ -506,8 +623,11 @@ def flood_complex(
         LAST_STATS.samples_per_simplex = weights.shape[0]
 
         if on_gpu:
-            face_vals, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, simplex_vertices, centers,
-                                                radii, weights, faces, reduce_hook)
+            if method == "ball":
+                face_vals, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, simplex_vertices, centers,
+                                                    radii, weights, faces, reduce_hook)
+            else:
+                face_vals, _ = _sweep_dimension_bvh(index, simplex_vertices, weights, faces, reduce_hook)
             face_vals = face_vals.cpu().numpy().astype(np.float64)
         else:
             samples = weights.unsqueeze(0) @ simplex_vertices

@@ -1,0 +1,419 @@
+// flood_bvh.hip - coverage sweep with wave-cooperative hierarchical culling (gfx950).
+//
+// Same result as the brute-force sweep (min over ALL points of the direct-difference squared
+// distance, i.e. the exact nearest neighbour the reference's CPU path returns, core.py:197-199), but
+// a tile of samples only evaluates points whose bounding box can still beat its running minima.
+//
+//   morton          64-bit Morton code of every point (dim x floor(63/dim) bits); the host sorts by it.
+//   bvh_build       implicit tree over the Morton-sorted cloud: leaf = 16 consecutive points,
+//                   fan-out 64 (one child per lane), node = axis-aligned box (lo[DP], hi[DP]).
+//   sweep_bvh       one wave owns (simplex, tile of 64*KS samples).  Samples live in registers
+//                   (rebuilt from vertices x barycentric weights).  Traversal is wave-uniform and
+//                   nearest-first: at a node the 64 lanes each test one child box against the tile's
+//                   bounding box (lower bound lb), the closest unvisited child is taken next, and a
+//                   level is abandoned as soon as its closest child has lb >= M, M = the largest
+//                   running minimum in the tile.  At a leaf every lane first checks its own samples
+//                   against the leaf box; if no lane can improve the leaf is skipped, otherwise its 16
+//                   points stream through SGPRs (scalar loads) against all samples of the tile -
+//                   the same inner loop as the brute-force sweep.
+//
+// Bounds are computed in fp32 and compared with a 1e-5 relative safety margin, so culling never
+// removes a pair that could change a minimum: results are bit-identical to the exhaustive sweep.
+
+#include "flood_common.hpp"
+
+using namespace flooder;
+
+namespace {
+
+constexpr int LEAF = FLOODER_BVH_LEAF;        // points per leaf
+constexpr int FAN = FLOODER_BVH_FANOUT;       // children per inner node (= wave size)
+constexpr int MAXL = FLOODER_BVH_MAX_LEVELS;  // levels incl. leaves
+constexpr float SAFE = 0.99999f;
+
+struct Levels {
+  int n_levels;          // level 0 = leaves ... level n_levels-1 = top (<= 64 nodes)
+  int64_t off[MAXL];     // first node of the level in the node array (levels padded to x64)
+  int64_t count[MAXL];   // real nodes of the level
+};
+
+Levels make_levels(int64_t n_pts) {
+  Levels lv;
+  memset(&lv, 0, sizeof(lv));
+  int64_t c = (n_pts + LEAF - 1) / LEAF;
+  if (c < 1) c = 1;
+  int64_t off = 0;
+  int l = 0;
+  for (;;) {
+    lv.count[l] = c;
+    lv.off[l] = off;
+    off += (c + FAN - 1) / FAN * FAN;
+    ++l;
+    if (c <= FAN || l == MAXL) break;
+    c = (c + FAN - 1) / FAN;
+  }
+  lv.n_levels = l;
+  return lv;
+}
+
+int64_t total_nodes(const Levels& lv) {
+  const int t = lv.n_levels - 1;
+  return lv.off[t] + (lv.count[t] + FAN - 1) / FAN * FAN;
+}
+
+// ------------------------------------------------------------------------------------ morton
+struct Box {
+  float lo[FLOODER_MAX_DIM];
+  float scale[FLOODER_MAX_DIM];
+};
+
+template <int DIM>
+__global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
+                                                     Box box, int64_t* __restrict__ codes) {
+  constexpr int BITS = 63 / DIM > 21 ? 21 : 63 / DIM;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    uint32_t q[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      float t = (pts[j * ld + k] - box.lo[k]) * box.scale[k];
+      t = t < 0.f ? 0.f : t;
+      const float top = (float)((1u << BITS) - 1u);
+      t = t > top ? top : t;
+      q[k] = (uint32_t)t;
+    }
+    uint64_t code = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b)
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) code |= (uint64_t)((q[k] >> b) & 1u) << (b * DIM + k);
+    codes[j] = (int64_t)code;
+  }
+}
+
+// ------------------------------------------------------------------------------------ build
+// Node layout: lo[DP] then hi[DP] (2*DP floats).  Empty node: lo = +inf, hi = -inf.
+template <int DIM>
+__global__ __launch_bounds__(256) void bvh_leaf_kernel(const float* __restrict__ pts, int64_t n_pts,
+                                                       int64_t n_leaves_pad, float* __restrict__ nodes) {
+  constexpr int DP = padded_dim(DIM);
+  const int64_t leaf = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n_leaves_pad) return;
+  float lo[DP], hi[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
+  for (int u = 0; u < LEAF; ++u) {
+    const int64_t j = leaf * LEAF + u;
+    if (j < n_pts) {
+      float x[DP];
+      load_row<DP>(pts + j * DP, x);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        lo[k] = __builtin_fminf(lo[k], x[k]);
+        hi[k] = __builtin_fmaxf(hi[k], x[k]);
+      }
+    }
+  }
+  float* dst = nodes + leaf * 2 * DP;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void bvh_inner_kernel(const float* __restrict__ child, int64_t n_child,
+                                                        int64_t n_nodes_pad, float* __restrict__ nodes) {
+  constexpr int DP = padded_dim(DIM);
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= n_nodes_pad) return;
+  float lo[DP], hi[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
+  for (int u = 0; u < FAN; ++u) {
+    const int64_t c = node * FAN + u;
+    if (c < n_child) {
+      float a[DP], b[DP];
+      load_row<DP>(child + c * 2 * DP, a);
+      load_row<DP>(child + c * 2 * DP + DP, b);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        lo[k] = __builtin_fminf(lo[k], a[k]);
+        hi[k] = __builtin_fmaxf(hi[k], b[k]);
+      }
+    }
+  }
+  float* dst = nodes + node * 2 * DP;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+}
+
+// ------------------------------------------------------------------------------------ sweep
+template <int DIM, int KSV>
+__global__ __launch_bounds__(256) void sweep_bvh_kernel(
+    const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
+    const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
+    int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    unsigned long long* __restrict__ stats) {
+  constexpr int DP = padded_dim(DIM);
+  __shared__ float s_lb[4][MAXL][FAN];
+  __shared__ int64_t s_grp[4][MAXL];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tiles = (R + 64 * KSV - 1) / (64 * KSV);
+  const int64_t n_items = n_simplices * tiles;
+  const int top = lv.n_levels - 1;
+  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0;
+
+  for (;;) {
+    int g32 = 0;
+    if (lane == 0) g32 = atomicAdd(queue, 1);
+    const int64_t g = (int64_t)wave_uniform(g32);
+    if (g >= n_items) break;
+    const int64_t s = g / tiles;
+    const int tile = (int)(g - s * tiles);
+
+    // ---- this lane's KSV samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188)
+    float p[KSV][DIM];
+    float best[KSV];
+    const float* vs = verts + s * (int64_t)k1 * DIM;
+#pragma unroll
+    for (int i = 0; i < KSV; ++i) {
+      int r = tile * 64 * KSV + i * 64 + lane;
+      if (r >= R) r = R - 1;  // duplicate of the last sample, never stored
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
+      for (int j = 0; j < k1; ++j) {
+        const float w = weights[(int64_t)r * k1 + j];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
+      }
+      best[i] = __builtin_inff();
+    }
+    // ---- bounding box of the tile (wave-uniform)
+    float tlo[DIM], thi[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      float mn = p[0][k], mx = p[0][k];
+#pragma unroll
+      for (int i = 1; i < KSV; ++i) {
+        mn = __builtin_fminf(mn, p[i][k]);
+        mx = __builtin_fmaxf(mx, p[i][k]);
+      }
+      tlo[k] = wave_min_f32(mn);
+      thi[k] = wave_max_f32(mx);
+    }
+    float M = __builtin_inff();  // largest running minimum of the tile (wave-uniform)
+
+    // lower bound between the tile box and child `lane` of group `grp` at level `lvl`
+    auto child_bounds = [&](int lvl, int64_t grp) {
+      const int64_t idx = grp * FAN + lane;
+      float lb = __builtin_inff();
+      if (idx < lv.count[lvl]) {
+        float lo[DP], hi[DP];
+        const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
+        load_row<DP>(nb, lo);
+        load_row<DP>(nb + DP, hi);
+        lb = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
+          lb = __builtin_fmaf(gap, gap, lb);
+        }
+      }
+      s_lb[wv][lvl][lane] = lb;
+      if (lane == 0) s_grp[wv][lvl] = grp;
+    };
+
+    int lvl = top;
+    child_bounds(top, 0);
+    ++n_node_test;
+    for (;;) {
+      const float lbv = s_lb[wv][lvl][lane];
+      const float mn = wave_min_f32(lbv);
+      if (!(mn * SAFE < M)) {  // nothing left at this level can improve any sample of the tile
+        if (++lvl > top) break;
+        continue;
+      }
+      const unsigned long long eq = __ballot(lbv == mn);
+      const int j = __builtin_ctzll(eq);
+      if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
+      const int64_t c = s_grp[wv][lvl] * FAN + j;
+      if (lvl > 0) {
+        --lvl;
+        child_bounds(lvl, c);
+        ++n_node_test;
+        continue;
+      }
+      // ---- leaf c: can any sample of any lane still improve?
+      ++n_leaf_test;
+      const float* lb_ptr = nodes + (lv.off[0] + c) * 2 * DP;
+      const typename RowVec<DP>::type blo = load_uniform_row<DP>(lb_ptr);
+      const typename RowVec<DP>::type bhi = load_uniform_row<DP>(lb_ptr + DP);
+      bool need = false;
+#pragma unroll
+      for (int i = 0; i < KSV; ++i) {
+        float lbp = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[i][k], p[i][k] - bhi[k]), 0.f);
+          lbp = __builtin_fmaf(gap, gap, lbp);
+        }
+        need |= (lbp * SAFE < best[i]);
+      }
+      if (__ballot(need) == 0ull) continue;
+      ++n_leaf_eval;
+      const float* cp = pts + c * (int64_t)LEAF * DP;
+#pragma unroll
+      for (int h = 0; h < LEAF; h += 8) {
+        typename RowVec<DP>::type cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+          for (int i = 0; i < KSV; ++i) {
+            float da, db;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float ta = p[i][k] - cc[u][k];
+              const float tb = p[i][k] - cc[u + 1][k];
+              if (k == 0) {
+                da = ta * ta;
+                db = tb * tb;
+              } else {
+                da = __builtin_fmaf(ta, ta, da);
+                db = __builtin_fmaf(tb, tb, db);
+              }
+            }
+            best[i] = __builtin_fminf(best[i], __builtin_fminf(da, db));
+          }
+        }
+      }
+      float bm = best[0];
+#pragma unroll
+      for (int i = 1; i < KSV; ++i) bm = __builtin_fmaxf(bm, best[i]);
+      M = wave_max_f32(bm);
+    }
+
+#pragma unroll
+    for (int i = 0; i < KSV; ++i) {
+      const int r = tile * 64 * KSV + i * 64 + lane;
+      if (r < R) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
+    }
+  }
+  if (stats && lane == 0) {
+    atomicAdd(&stats[0], n_leaf_eval);
+    atomicAdd(&stats[1], n_leaf_test);
+    atomicAdd(&stats[2], n_node_test);
+  }
+}
+
+// ------------------------------------------------------------------------------------ host ops
+template <int DIM>
+struct MortonOp {
+  static int run(const float* pts, int64_t n, int ld, const Box& box, int64_t* codes, hipStream_t st) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes);
+    return check_launch("morton");
+  }
+};
+
+template <int DIM>
+struct BuildOp {
+  static int run(const float* pts, int64_t n_pts, const Levels& lv, float* nodes, hipStream_t st) {
+    constexpr int DP = padded_dim(DIM);
+    int64_t pad0 = (lv.count[0] + FAN - 1) / FAN * FAN;
+    hipLaunchKernelGGL((bvh_leaf_kernel<DIM>), dim3((unsigned)((pad0 + 255) / 256)), dim3(256), 0, st,
+                       pts, n_pts, pad0, nodes + lv.off[0] * 2 * DP);
+    for (int l = 1; l < lv.n_levels; ++l) {
+      int64_t pad = (lv.count[l] + FAN - 1) / FAN * FAN;
+      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, st,
+                         nodes + lv.off[l - 1] * 2 * DP, lv.count[l - 1], pad, nodes + lv.off[l] * 2 * DP);
+    }
+    return check_launch("bvh_build");
+  }
+};
+
+template <int DIM>
+struct SweepBvhOp {
+  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
+                 const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
+                 unsigned long long* stats, hipStream_t st) {
+    const int grid = 256 * 4;  // persistent blocks; 4 independent waves each
+    if (R <= 64)
+      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                         weights, k1, R, ns, queue, out, stats);
+    else if (R <= 128)
+      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                         weights, k1, R, ns, queue, out, stats);
+    else if (R <= 256)
+      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                         weights, k1, R, ns, queue, out, stats);
+    else
+      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                         weights, k1, R, ns, queue, out, stats);
+    return check_launch("sweep_bvh");
+  }
+};
+
+// self-test of the DPP reductions
+__global__ void selftest_kernel(const float* in, float* out) {
+  const float x = in[threadIdx.x];
+  out[threadIdx.x] = wave_min_f32(x);
+  out[64 + threadIdx.x] = wave_max_f32(x);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t flooder_bvh_node_count(int64_t n_pts) {
+  const Levels lv = make_levels(n_pts);
+  return total_nodes(lv);
+}
+
+int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box_lo,
+                       const float* box_hi, int64_t* codes, void* stream) {
+  if (n_pts == 0) return FLOODER_OK;
+  if (!pts || !box_lo || !box_hi || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
+    return fail(FLOODER_E_ARG, "flooder_morton_f32: bad argument");
+  Box box;
+  const int bits = 63 / dim > 21 ? 21 : 63 / dim;
+  for (int k = 0; k < FLOODER_MAX_DIM; ++k) {
+    box.lo[k] = 0.f;
+    box.scale[k] = 0.f;
+  }
+  for (int k = 0; k < dim; ++k) {
+    const float ext = box_hi[k] - box_lo[k];
+    box.lo[k] = box_lo[k];
+    box.scale[k] = ext > 0.f ? (float)((1u << bits) - 1u) / ext : 0.f;
+  }
+  return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, (hipStream_t)stream);
+}
+
+int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream) {
+  if (!pts_sorted || !nodes || n_pts < 1) return fail(FLOODER_E_ARG, "flooder_bvh_build_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<BuildOp>(dim, pts_sorted, n_pts, lv, nodes, (hipStream_t)stream);
+}
+
+int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                          const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                          int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || n_pts < 1 || k1 < 1 ||
+      k1 > FLOODER_MAX_VERTS || R < 0)
+    return fail(FLOODER_E_ARG, "flooder_sweep_bvh_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
+                                  out_d2, reinterpret_cast<unsigned long long*>(stats),
+                                  (hipStream_t)stream);
+}
+
+int flooder_selftest(const float* in64, float* out128, void* stream) {
+  if (!in64 || !out128) return fail(FLOODER_E_ARG, "flooder_selftest: bad argument");
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in64, out128);
+  return check_launch("selftest");
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// flood_common.hpp - helpers shared by the kernels of libflooder_hip.so (internal, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/flooder_hip.h"
+
+namespace flooder {
+
+constexpr uint32_t INF_BITS = 0x7f800000u;
+
+char* err_buf();
+int fail(int code, const char* msg);
+int check_launch(const char* what);
+
+__host__ __device__ constexpr int padded_dim(int dim) { return dim <= 2 ? 2 : (dim <= 4 ? 4 : 8); }
+
+// One padded row (DP floats) with a single vector load (per-lane address).
+template <int DP>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&out)[DP]) {
+  if constexpr (DP == 2) {
+    float2 t = *reinterpret_cast<const float2*>(p);
+    out[0] = t.x; out[1] = t.y;
+  } else if constexpr (DP == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+  } else {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+  }
+}
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int64_t wave_uniform64(int64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(v & 0xffffffffu));
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Wave-uniform rows come in through the scalar cache: the pointer is cast to the constant address
+// space so each padded row is one s_load_dwordx2/x4/x8 into SGPRs, and the VALU reads the
+// coordinates as scalar operands (no LDS staging, no barrier, no VGPR per candidate).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int DP>
+struct RowVec {
+  typedef float type __attribute__((ext_vector_type(DP)));
+};
+
+template <int DP>
+__device__ __forceinline__ typename RowVec<DP>::type load_uniform_row(const float* p) {
+  typedef typename RowVec<DP>::type vec_t;
+  typedef const __attribute__((address_space(4))) vec_t* cptr_t;
+  return *((cptr_t)(uintptr_t)p);
+}
+
+// ---- 64-lane reductions on the DPP network (no LDS): result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+__device__ __forceinline__ float wave_min_f32(float x) {
+  x = __builtin_fminf(x, dpp_move<0xB1, 0xF>(x));   // quad_perm [1,0,3,2]
+  x = __builtin_fminf(x, dpp_move<0x4E, 0xF>(x));   // quad_perm [2,3,0,1]
+  x = __builtin_fminf(x, dpp_move<0x141, 0xF>(x));  // row_half_mirror
+  x = __builtin_fminf(x, dpp_move<0x140, 0xF>(x));  // row_mirror: every row of 16 holds its min
+  x = __builtin_fminf(x, dpp_move<0x142, 0xA>(x));  // row_bcast15 into rows 1 and 3
+  x = __builtin_fminf(x, dpp_move<0x143, 0xC>(x));  // row_bcast31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+__device__ __forceinline__ float wave_max_f32(float x) {
+  x = __builtin_fmaxf(x, dpp_move<0xB1, 0xF>(x));
+  x = __builtin_fmaxf(x, dpp_move<0x4E, 0xF>(x));
+  x = __builtin_fmaxf(x, dpp_move<0x141, 0xF>(x));
+  x = __builtin_fmaxf(x, dpp_move<0x140, 0xF>(x));
+  x = __builtin_fmaxf(x, dpp_move<0x142, 0xA>(x));
+  x = __builtin_fmaxf(x, dpp_move<0x143, 0xC>(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+template <template <int> class F, typename... Args>
+int dispatch_dim(int dim, Args&&... args) {
+  switch (dim) {
+    case 1: return F<1>::run(args...);
+    case 2: return F<2>::run(args...);
+    case 3: return F<3>::run(args...);
+    case 4: return F<4>::run(args...);
+    case 5: return F<5>::run(args...);
+    case 6: return F<6>::run(args...);
+    case 7: return F<7>::run(args...);
+    case 8: return F<8>::run(args...);
+    default: return fail(FLOODER_E_ARG, "dim must be in 1..8");
+  }
+}
+
+}  // namespace flooder

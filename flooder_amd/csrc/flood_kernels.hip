@@ -20,25 +20,12 @@
 //
 // Work is pulled from device-side queues (atomic head) so heavy-tailed candidate counts balance.
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
+#include "flood_common.hpp"
 
-#include "../../include/flooder_hip.h"
-
-namespace {
-
-constexpr uint32_t INF_BITS = 0x7f800000u;
-constexpr int SCAN_PARTS = 8;        // each simplex's slab is scanned by 8 independent work units
-constexpr int SCAN_THREADS = 256;
-constexpr int SWEEP_THREADS = 256;   // 4 independent waves per block
-constexpr int KS = 8;                // samples per lane  -> 512 samples per wave tile
-constexpr int CHUNK = FLOODER_SWEEP_CHUNK;
-static_assert(64 * KS == FLOODER_TILE_SAMPLES, "tile size");
+namespace flooder {
 
 thread_local char g_err[256] = "";
-int g_sweep_variant = 0;  // 0 = packed fp32 (v_pk_*), 1 = plain fp32; flooder_set_option("sweep_variant")
+char* err_buf() { return g_err; }
 
 int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -54,37 +41,20 @@ int check_launch(const char* what) {
   return FLOODER_OK;
 }
 
-__host__ __device__ constexpr int padded_dim(int dim) { return dim <= 2 ? 2 : (dim <= 4 ? 4 : 8); }
+}  // namespace flooder
 
-template <int N>
-struct Row {
-  float v[N];
-};
+using namespace flooder;
 
-// One padded row (DP floats) with a single vector load.
-template <int DP>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&out)[DP]) {
-  if constexpr (DP == 2) {
-    float2 t = *reinterpret_cast<const float2*>(p);
-    out[0] = t.x; out[1] = t.y;
-  } else if constexpr (DP == 4) {
-    float4 t = *reinterpret_cast<const float4*>(p);
-    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
-  } else {
-    float4 a = *reinterpret_cast<const float4*>(p);
-    float4 b = *reinterpret_cast<const float4*>(p + 4);
-    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
-  }
-}
+namespace {
 
-__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+constexpr int SCAN_PARTS = 8;        // each simplex's slab is scanned by 8 independent work units
+constexpr int SCAN_THREADS = 256;
+constexpr int SWEEP_THREADS = 256;   // 4 independent waves per block
+constexpr int KS = 8;                // samples per lane  -> 512 samples per wave tile
+constexpr int CHUNK = FLOODER_SWEEP_CHUNK;
+static_assert(64 * KS == FLOODER_TILE_SAMPLES, "tile size");
 
-__device__ __forceinline__ int64_t wave_uniform64(int64_t v) {
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(v & 0xffffffffu));
-  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
+int g_sweep_variant = 0;  // 0 = packed fp32 (v_pk_*), 1 = plain fp32; flooder_set_option("sweep_variant")
 
 // ---------------------------------------------------------------------------------- ball scan
 // Work unit g = simplex * SCAN_PARTS + part.  Blocks stride over the units (uniform cost per point).
@@ -172,23 +142,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void ball_scan_kernel(
 }
 
 // ---------------------------------------------------------------------------------- sweep
-// Wave-uniform candidate rows come in through the scalar cache: the pointer is cast to the
-// constant address space so each padded row is one s_load_dwordx2/x4/x8 into SGPRs, and the VALU
-// reads the coordinates as scalar operands (no LDS staging, no barrier, no VGPR per candidate).
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int DP>
-struct RowVec {
-  typedef float type __attribute__((ext_vector_type(DP)));
-};
-
-template <int DP>
-__device__ __forceinline__ typename RowVec<DP>::type load_cand(const float* p) {
-  typedef typename RowVec<DP>::type vec_t;
-  typedef const __attribute__((address_space(4))) vec_t* cptr_t;
-  return *((cptr_t)(uintptr_t)p);
-}
-
 __device__ __forceinline__ int64_t upper_bound_minus1(const int64_t* __restrict__ prefix, int64_t n,
                                                       int64_t g) {
   // largest s in [0, n) with prefix[s] <= g   (prefix[0] = 0, prefix[n] = total > g)
@@ -261,7 +214,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(
       for (int gi = 0; gi < n_groups; ++gi) {
         typename RowVec<DP>::type c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = load_cand<DP>(cp + u * DP);
+        for (int u = 0; u < 8; ++u) c[u] = load_uniform_row<DP>(cp + u * DP);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
 #pragma unroll
@@ -296,7 +249,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(
       for (int gi = 0; gi < n_groups; ++gi) {
         typename RowVec<DP>::type c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = load_cand<DP>(cp + u * DP);
+        for (int u = 0; u < 8; ++u) c[u] = load_uniform_row<DP>(cp + u * DP);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
 #pragma unroll
@@ -427,21 +380,6 @@ __global__ void fps_last_kernel(const unsigned long long* best, int n_lms, int64
 }
 
 // ---------------------------------------------------------------------------------- dispatch
-template <template <int> class F, typename... Args>
-int dispatch_dim(int dim, Args&&... args) {
-  switch (dim) {
-    case 1: return F<1>::run(args...);
-    case 2: return F<2>::run(args...);
-    case 3: return F<3>::run(args...);
-    case 4: return F<4>::run(args...);
-    case 5: return F<5>::run(args...);
-    case 6: return F<6>::run(args...);
-    case 7: return F<7>::run(args...);
-    case 8: return F<8>::run(args...);
-    default: return fail(FLOODER_E_ARG, "dim must be in 1..8");
-  }
-}
-
 int scan_grid(int64_t n_simplices) {
   int64_t units = n_simplices * SCAN_PARTS;
   int64_t g = units < 256 * 8 ? units : 256 * 8;
@@ -508,7 +446,7 @@ extern "C" {
 
 int flooder_abi_version(void) { return FLOODER_ABI_VERSION; }
 
-const char* flooder_last_error(void) { return g_err; }
+const char* flooder_last_error(void) { return err_buf(); }
 
 int flooder_padded_dim(int dim) { return padded_dim(dim); }
 

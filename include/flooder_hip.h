@@ -38,6 +38,9 @@ extern "C" {
 #define FLOODER_CAND_ALIGN 8   /* each simplex's candidate list is padded to x8     */
 #define FLOODER_SWEEP_CHUNK 2048 /* candidates per sweep work item                   */
 #define FLOODER_TILE_SAMPLES 512 /* samples per sweep work item (64 lanes x 8)       */
+#define FLOODER_BVH_LEAF 16      /* points per leaf of the point hierarchy            */
+#define FLOODER_BVH_FANOUT 64    /* children per inner node (one per lane)            */
+#define FLOODER_BVH_MAX_LEVELS 6 /* 16 * 64^5 points                                  */
 
 int flooder_abi_version(void);
 const char* flooder_last_error(void);
@@ -112,6 +115,39 @@ int flooder_sweep_f32(const float* cand, const int64_t* cand_off, const int32_t*
 int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const int32_t* face_ptr,
                          const int32_t* face_rows, int n_faces, float* out_face, float* out_dist,
                          void* stream);
+
+/*
+ * ---- Hierarchically culled sweep (default device path) ---------------------------------------------
+ * Replaces the reference's pruning chain as a whole - slab selection by searchsorted (core.py:201-208),
+ * compute_mask (triton_kernels.py:161-223), torch.nonzero (core.py:218) and compute_filtration
+ * (triton_kernels.py:48-96): instead of a bounding ball per simplex, an implicit bounding-box tree over
+ * the Morton-sorted cloud is traversed per tile of samples, and only leaves that can still lower a
+ * running minimum are evaluated.  The value computed is the exact minimum over ALL points (what the
+ * reference's CPU branch returns, core.py:197-199), with the same direct-difference arithmetic.
+ */
+
+/* 64-bit Morton codes of the points inside the box [box_lo, box_hi] (HOST arrays of `dim` floats);
+ * floor(63/dim) (max 21) bits per axis.  The caller sorts the cloud by these codes. */
+int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box_lo,
+                       const float* box_hi, int64_t* codes, void* stream);
+
+/* Number of nodes (all levels, each padded to a multiple of 64) of the tree over n_pts points. */
+int64_t flooder_bvh_node_count(int64_t n_pts);
+
+/* Build the tree.  pts_sorted: padded rows (flooder_padded_dim(dim) floats), Morton order, row count
+ * rounded up to a multiple of FLOODER_BVH_LEAF with +inf rows.  nodes: flooder_bvh_node_count(n_pts)
+ * x 2 x padded_dim floats (box lo then hi per node). */
+int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream);
+
+/* Sweep: out_d2[s, r] = bits(min over all points of |p(s,r) - x|^2) with p as in flooder_sweep_f32.
+ * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or three
+ * zeroed uint64 counters {leaves evaluated, leaves tested, inner nodes expanded} (per wave-item). */
+int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                          const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                          int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
+
+/* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
+int flooder_selftest(const float* in64, float* out128, void* stream);
 
 /* Set n uint32 words to `value` (used to initialise d2 buffers to +inf bits). */
 int flooder_fill_u32(uint32_t* buf, int64_t n, uint32_t value, void* stream);

@@ -63,11 +63,30 @@ def test_kernels_match_reference_triton_vectors(name, dev):
     assert_close_filtration(d[fin], ref[fin], z["points"], name)
 
 
+def test_dpp_wave_reductions(dev):
+    lib = _native.load()
+    g = torch.Generator().manual_seed(0)
+    for trial in range(8):
+        x = torch.rand(64, generator=g)
+        if trial == 1:
+            x[17] = float("inf")
+        if trial == 2:
+            x[:] = float("inf")
+        xd = x.to(dev)
+        out = torch.empty(128, device=dev)
+        assert lib.flooder_selftest(_native.ptr(xd), _native.ptr(out), 0) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out[:64].cpu(), torch.full((64,), float(x.min())))
+        assert torch.equal(out[64:].cpu(), torch.full((64,), float(x.max())))
+
+
+@pytest.mark.parametrize("method", ["bvh", "ball"])
 @pytest.mark.parametrize("name", e2e_cases())
-def test_e2e_matches_reference_goldens(name, dev):
+def test_e2e_matches_reference_goldens(name, method, dev):
     z, kw, keys = load_e2e(name)
     torch.manual_seed(int(z["weight_seed"]))
-    fc = fa.flood_complex(torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev), **kw)
+    fc = fa.flood_complex(torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev),
+                          method=method, **kw)
     assert set(keys) == set(fc)
     assert_close_filtration(dict_values(fc, keys), z["filtration_f32"], z["points"], name)
 
@@ -78,11 +97,35 @@ def test_plain_and_packed_variants_are_bit_identical(dev):
     pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
     try:
         assert lib.flooder_set_option(b"sweep_variant", 1) == 0
-        a = fa.flood_complex(pts, lms, **kw)
+        a = fa.flood_complex(pts, lms, method="ball", **kw)
     finally:
         assert lib.flooder_set_option(b"sweep_variant", 0) == 0
-    b = fa.flood_complex(pts, lms, **kw)
+    b = fa.flood_complex(pts, lms, method="ball", **kw)
     assert a == b
+
+
+@pytest.mark.parametrize("name", ["torus3d_grid30", "cheese3d_grid", "eight2d_rand", "gauss6d_maxdim2"])
+def test_culled_sweep_is_bit_identical_to_ball_sweep(name, dev):
+    """Culling must not change a single bit: exact-NN (bvh) == exhaustive in-ball sweep (ball)."""
+    z, kw, keys = load_e2e(name)
+    pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
+    torch.manual_seed(1)
+    a = fa.flood_complex(pts, lms, method="bvh", **kw)
+    torch.manual_seed(1)
+    b = fa.flood_complex(pts, lms, method="ball", **kw)
+    assert a == b
+
+
+def test_landmarks_outside_cloud_match_cpu_path(dev):
+    """Landmarks that are NOT points of the cloud: the culled sweep still returns the exact value of
+    the reference CPU path (the reference's own GPU path is only a bound there)."""
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(20000, 3)).astype(np.float32)
+    lms = rng.normal(size=(60, 3)).astype(np.float32) * 0.8
+    ref = fo.flood_complex_oracle(pts, lms, points_per_edge=9)
+    fc = fa.flood_complex(torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev), points_per_edge=9)
+    keys = sorted(ref)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), pts, "off-cloud landmarks")
 
 
 def test_medium_cloud_against_kdtree_oracle(dev):
@@ -134,9 +177,9 @@ def test_landmarks_clamped_to_point_count(dev):
 def test_workspace_grouping_is_invisible(dev, monkeypatch):
     z, kw, keys = load_e2e("cheese3d_grid")
     pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
-    a = fa.flood_complex(pts, lms, **kw)
+    a = fa.flood_complex(pts, lms, method="ball", **kw)
     monkeypatch.setattr(core, "CAND_WORKSPACE_BYTES", 1)  # floor of 2^20 rows per group
-    b = fa.flood_complex(pts, lms, batch_size=7, **kw)
+    b = fa.flood_complex(pts, lms, batch_size=7, method="ball", **kw)
     assert a == b
 
 
