@@ -69,8 +69,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the CPU baseline sample")
     ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
-    ap.add_argument("--method", default="bvh", choices=["bvh", "ball"],
-                    help="bvh: hierarchically culled sweep (default); ball: the reference's formulation")
+    ap.add_argument("--bvh-ks", type=int, default=None, help="samples per lane of the culled sweep (1,2,4,8)")
+    ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
+                    help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
+                         "ball: the reference's formulation")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -96,6 +98,8 @@ def main():
     if args.variant is not None:
         _native.check(lib.flooder_set_option(b"sweep_variant", args.variant), "set_option")
 
+    if args.bvh_ks is not None:
+        _native.check(lib.flooder_set_option(b"bvh_ks", args.bvh_ks), "set_option")
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
@@ -130,16 +134,21 @@ def main():
                                              _native.current_stream_ptr(dev)), "ball_count")
     P_local = int(cnt0.sum().item())
     del pts_pad0, search0, lo0, hi0, cnt0
-    stats = torch.zeros(3, dtype=torch.int64, device=dev)
+    stats = torch.zeros(9, dtype=torch.int64, device=dev)
 
     def step(timer=None):
         """raw (unsorted-for-this-method) shard in HBM -> per-face filtration values in HBM"""
         core.LAST_STATS.reset()
-        if args.method == "bvh":
+        if args.method == "cell":
             with core._span(timer, "index_total"):
                 index = core.PointIndex(shard_raw, timer)
             stats.zero_()
-            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats)
+            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=stats)
+        elif args.method == "bvh":
+            with core._span(timer, "index_total"):
+                index = core.PointIndex(shard_raw, timer)
+            stats.zero_()
+            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats[:3])
         else:
             with core._span(timer, "index_total"):
                 o = torch.argsort(shard_raw[:, axis])
@@ -183,8 +192,15 @@ def main():
     pair_evals = P_local * R                       # what the reference's formulation evaluates
     if args.method == "bvh":
         st_h = stats.cpu().tolist()
-        ks = 8 if R > 256 else (4 if R > 128 else (2 if R > 64 else 1))
+        ks = args.bvh_ks or (8 if R > 256 else (4 if R > 128 else (2 if R > 64 else 1)))
         done_evals = st_h[0] * 16 * 64 * ks        # leaves evaluated x 16 points x tile samples
+        st_h = {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1], "nodes_expanded": st_h[2]}
+    elif args.method == "cell":
+        st_h = stats.cpu().tolist()
+        done_evals = st_h[3] + st_h[6] * 16 * 64 + st_h[0] * 16 * 64
+        st_h = {"cell_pairs": st_h[3], "points_staged": st_h[4], "tiles_flagged": st_h[5],
+                "tiles_total": S * ((R + 63) // 64), "fallback_leaves_evaluated": st_h[6],
+                "fallback_leaves_tested": st_h[7], "probe_leaves_evaluated": st_h[0]}
     else:
         st_h = None
         done_evals = pair_evals
@@ -208,11 +224,10 @@ def main():
             "samples_per_simplex": R, "candidate_pairs_rank0": P_local, "pair_evals_rank0": pair_evals,
             "ball_tests_rank0": slab_local, "parallelism": f"point-shard x{world}" if world > 1 else "single GPU",
             "method": args.method, "pair_evals_done_rank0": done_evals,
-            "bvh_stats_rank0": None if st_h is None else {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1],
-                                                          "nodes_expanded": st_h[2]},
+            "sweep_stats_rank0": st_h,
         },
         "roofline": {
-            "kernel": "sweep_bvh_kernel" if args.method == "bvh" else "sweep_kernel", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+            "kernel": {"cell": "cell_sweep_kernel", "bvh": "sweep_bvh_kernel", "ball": "sweep_kernel"}[args.method], "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes": alg_bytes, "avg_launch_ms": round(sweep_ms, 4),
             "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + (S,R) minima "

@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
 
-HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip"]
+HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip"]
 HOST_SOURCES = ["persistence.cpp"]
 
 
@@ -38,7 +38,8 @@ def _hipcc() -> str:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp")]
+    deps = srcs + [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp"),
+                   os.path.join(CSRC, "flood_bvh.hpp")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
     cmd = [

@@ -48,9 +48,10 @@ CAND_ALIGN = 8
 SWEEP_CHUNK = 2048
 TILE_SAMPLES = 512
 BVH_LEAF = 16
-# device sweep: "bvh" = hierarchically culled exact nearest neighbour (default); "ball" = the
-# reference's formulation (bounding-ball candidate lists + exhaustive sweep of each list)
-SWEEP_METHOD = "bvh"
+# device sweep: "cell" = per-simplex LDS cell grid + exact tree finish (default in 2D/3D); "bvh" = box-tree
+# culled exact nearest neighbour (default in other dimensions); "ball" = the reference's formulation
+# (bounding-ball candidate lists + exhaustive sweep of each list)
+SWEEP_METHOD = "auto"
 # candidate workspace budget per group of simplices (bytes); bounds HBM use like the reference's
 # ``batch_size`` bounds its mask tensor
 CAND_WORKSPACE_BYTES = 16 << 30
@@ -487,6 +488,79 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     return out_face, out_dist
 
 
+PROBE_POINTS_PER_EDGE = 6   # lattice of the probe sweep that estimates each simplex's search radius
+PROBE_MARGIN = 1.25
+
+
+def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
+                          reduce_hook: Optional[Callable[[torch.Tensor], None]],
+                          want_dist: bool = False, timer: Optional[_KernelTimer] = None,
+                          stats: Optional[torch.Tensor] = None):
+    """Cell sweep (dim 2 / 3): probe sweep -> per-simplex radius -> LDS cell-grid sweep -> exact tree
+    sweep of the unverified tiles -> [reduce_hook] -> face max.  No host synchronisation.
+
+    ``stats`` (optional, 9 zeroed int64): [0:3] probe tree sweep, [3:6] cell sweep {pairs, points staged,
+    tiles flagged}, [6:9] fallback tree sweep {leaves evaluated, leaves tested, nodes expanded}.
+    """
+    lib = _native.load()
+    dev = index.pts.device
+    st = _native.current_stream_ptr(dev)
+    S, k1, _ = verts.shape
+    R = weights.shape[0]
+    verts = verts.to(torch.float32).contiguous()
+    perm = sample_order(weights)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(R)
+    w_perm = weights.to(torch.float32)[torch.as_tensor(perm, device=dev)].contiguous()
+    rows_perm = torch.as_tensor(inv, device=dev)[faces.rows.long()].to(torch.int32).contiguous()
+
+    def sub(a, b):
+        return None if stats is None else stats[a:b]
+
+    # 1. probe: exact nearest-neighbour distance at a coarse lattice of every simplex
+    w_probe, _, _ = generate_grid(PROBE_POINTS_PER_EDGE, k1 - 1, dev, torch.float32)
+    w_probe = w_probe.contiguous()
+    Rp = w_probe.shape[0]
+    d2p = torch.empty((S, Rp), dtype=torch.int32, device=dev)
+    ctl = torch.zeros(4, dtype=torch.int32, device=dev)  # work-queue heads + flag counter
+    with _span(timer, "probe"):
+        _native.check(lib.flooder_sweep_bvh_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_probe), k1, Rp, S, ctl[0:].data_ptr(), _native.ptr(d2p), _native.ptr(sub(0, 3)), st),
+            "flooder_sweep_bvh_f32")
+    rho = (d2p.view(torch.float32).amax(dim=1).sqrt() * PROBE_MARGIN).contiguous()
+
+    # 2. cell sweep
+    tiles64 = (R + 63) // 64
+    d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
+    flag_list = torch.empty(S * tiles64, dtype=torch.int32, device=dev)
+    with _span(timer, "sweep"):
+        _native.check(lib.flooder_sweep_cell_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_perm), k1, R, S, _native.ptr(rho), ctl[1:].data_ptr(), _native.ptr(d2),
+            _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(sub(3, 6)), st), "flooder_sweep_cell_f32")
+    # 3. exact finish of the flagged tiles, seeded with the minima found so far
+    with _span(timer, "fallback"):
+        _native.check(lib.flooder_sweep_bvh_items_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_perm), k1, R, S, _native.ptr(flag_list), ctl[2:].data_ptr(), ctl[3:].data_ptr(),
+            _native.ptr(d2), _native.ptr(sub(6, 9)), st), "flooder_sweep_bvh_items_f32")
+
+    if reduce_hook is not None:
+        with _span(timer, "reduce"):
+            reduce_hook(d2)
+    out_face = torch.empty((S, faces.n_faces), dtype=torch.float32, device=dev)
+    out_dist = torch.empty((S, R), dtype=torch.float32, device=dev) if want_dist else None
+    with _span(timer, "face_max"):
+        _native.check(lib.flooder_face_max_f32(_native.ptr(d2), S, R, _native.ptr(faces.ptr),
+                                               _native.ptr(rows_perm), faces.n_faces,
+                                               _native.ptr(out_face), _native.ptr(out_dist), st),
+                      "flooder_face_max_f32")
+    if out_dist is not None:
+        out_dist = out_dist[:, torch.as_tensor(inv, device=dev)]
+    return out_face, out_dist
+
+
 def _face_max_cpu(dist: torch.Tensor, faces: _FaceTable) -> torch.Tensor:
     ptr = faces.ptr.cpu().numpy()
     rows = faces.rows.cpu().numpy()
@@ -528,15 +602,20 @@ def flood_complex(
     cross-GPU ``all_reduce(MIN)``.  ``sort_axis`` (keyword-only) fixes the coordinate axis used for the
     cloud sort and the simplex order instead of deriving it from ``points`` (ranks holding different
     shards must agree on the simplex order of the reduced buffer).  ``method`` (keyword-only):
-    ``"bvh"`` (default) evaluates the exact nearest neighbour with hierarchical culling; ``"ball"``
-    runs the reference's formulation literally (bounding-ball candidates, exhaustive sweep).  Both give
-    the same values whenever the landmarks are points of the cloud (the reference's precondition for its
-    own GPU path); for other landmarks ``"bvh"`` returns the exact value of the
+    ``"cell"`` (default in 2D/3D: per-simplex cell grid in LDS, exact tree finish) and ``"bvh"`` (default
+    otherwise: box-tree culling) evaluate the exact nearest neighbour; ``"ball"`` runs the reference's
+    formulation literally (bounding-ball candidates, exhaustive sweep).  All give the same values
+    whenever the landmarks are points of the cloud (the reference's precondition for its own GPU path,
+    SURVEY.md section 8 a-2); for other landmarks ``"cell"``/``"bvh"`` return the exact value of the
     reference's CPU path.
     """
     method = SWEEP_METHOD if method is None else method
-    if method not in ("bvh", "ball"):
-        raise ValueError(f"method must be 'bvh' or 'ball', got {method!r}")
+    if method == "auto":
+        method = "cell" if points.shape[1] in (2, 3) else "bvh"
+    if method not in ("cell", "bvh", "ball"):
+        raise ValueError(f"method must be 'cell', 'bvh' or 'ball', got {method!r}")
+    if method == "cell" and points.shape[1] not in (2, 3):
+        raise ValueError("method 'cell' supports ambient dimension 2 and 3 only")
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
     if use_triton and not _has_hip_kernels():
@@ -626,6 +705,8 @@ def flood_complex(
             if method == "ball":
                 face_vals, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, simplex_vertices, centers,
                                                     radii, weights, faces, reduce_hook)
+            elif method == "cell":
+                face_vals, _ = _sweep_dimension_cell(index, simplex_vertices, weights, faces, reduce_hook)
             else:
                 face_vals, _ = _sweep_dimension_bvh(index, simplex_vertices, weights, faces, reduce_hook)
             face_vals = face_vals.cpu().numpy().astype(np.float64)

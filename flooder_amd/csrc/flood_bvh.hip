@@ -21,45 +21,17 @@
 // removes a pair that could change a minimum: results are bit-identical to the exhaustive sweep.
 
 #include "flood_common.hpp"
+#include "flood_bvh.hpp"
 
 using namespace flooder;
 
 namespace {
 
-constexpr int LEAF = FLOODER_BVH_LEAF;        // points per leaf
-constexpr int FAN = FLOODER_BVH_FANOUT;       // children per inner node (= wave size)
-constexpr int MAXL = FLOODER_BVH_MAX_LEVELS;  // levels incl. leaves
 constexpr float SAFE = 0.99999f;
 
-struct Levels {
-  int n_levels;          // level 0 = leaves ... level n_levels-1 = top (<= 64 nodes)
-  int64_t off[MAXL];     // first node of the level in the node array (levels padded to x64)
-  int64_t count[MAXL];   // real nodes of the level
-};
-
-Levels make_levels(int64_t n_pts) {
-  Levels lv;
-  memset(&lv, 0, sizeof(lv));
-  int64_t c = (n_pts + LEAF - 1) / LEAF;
-  if (c < 1) c = 1;
-  int64_t off = 0;
-  int l = 0;
-  for (;;) {
-    lv.count[l] = c;
-    lv.off[l] = off;
-    off += (c + FAN - 1) / FAN * FAN;
-    ++l;
-    if (c <= FAN || l == MAXL) break;
-    c = (c + FAN - 1) / FAN;
-  }
-  lv.n_levels = l;
-  return lv;
-}
-
-int64_t total_nodes(const Levels& lv) {
-  const int t = lv.n_levels - 1;
-  return lv.off[t] + (lv.count[t] + FAN - 1) / FAN * FAN;
-}
+}  // namespace
+namespace flooder { int g_bvh_ks = 0; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace {
 
 // ------------------------------------------------------------------------------------ morton
 struct Box {
@@ -152,22 +124,24 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
+    const int32_t* __restrict__ n_list, int seed) {
   constexpr int DP = padded_dim(DIM);
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tiles = (R + 64 * KSV - 1) / (64 * KSV);
-  const int64_t n_items = n_simplices * tiles;
+  const int64_t n_items = item_list ? (int64_t)n_list[0] : n_simplices * tiles;
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0;
 
   for (;;) {
     int g32 = 0;
     if (lane == 0) g32 = atomicAdd(queue, 1);
-    const int64_t g = (int64_t)wave_uniform(g32);
+    int64_t g = (int64_t)wave_uniform(g32);
     if (g >= n_items) break;
+    if (item_list) g = (int64_t)item_list[g];  // explicit (simplex, tile) work list
     const int64_t s = g / tiles;
     const int tile = (int)(g - s * tiles);
 
@@ -186,7 +160,8 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 #pragma unroll
         for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
       }
-      best[i] = __builtin_inff();
+      // seed: start from the minima already in out_d2 (upper bounds found by an earlier pass)
+      best[i] = seed ? __uint_as_float(out_d2[s * (int64_t)R + r]) : __builtin_inff();
     }
     // ---- bounding box of the tile (wave-uniform)
     float tlo[DIM], thi[DIM];
@@ -202,6 +177,12 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
       thi[k] = wave_max_f32(mx);
     }
     float M = __builtin_inff();  // largest running minimum of the tile (wave-uniform)
+    if (seed) {
+      float bm = best[0];
+#pragma unroll
+      for (int i = 1; i < KSV; ++i) bm = __builtin_fmaxf(bm, best[i]);
+      M = wave_max_f32(bm);
+    }
 
     // lower bound between the tile box and child `lane` of group `grp` at level `lvl`
     auto child_bounds = [&](int lvl, int64_t grp) {
@@ -338,20 +319,23 @@ template <int DIM>
 struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
-                 unsigned long long* stats, hipStream_t st) {
-    const int grid = 256 * 4;  // persistent blocks; 4 independent waves each
-    if (R <= 64)
+                 unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
+                 int force_ks, hipStream_t st) {
+    const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
+    int ks = force_ks ? force_ks : g_bvh_ks;
+    if (ks == 0) ks = R <= 64 ? 1 : (R <= 128 ? 2 : (R <= 256 ? 4 : 8));
+    if (ks == 1)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats);
-    else if (R <= 128)
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+    else if (ks == 2)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats);
-    else if (R <= 256)
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+    else if (ks == 4)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
     else
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
     return check_launch("sweep_bvh");
   }
 };
@@ -406,8 +390,22 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
     return fail(FLOODER_E_ARG, "flooder_sweep_bvh_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
-                                  out_d2, reinterpret_cast<unsigned long long*>(stats),
+                                  out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0,
                                   (hipStream_t)stream);
+}
+
+int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                const float* verts, const float* weights, int k1, int R,
+                                int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
+                                int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !item_list || !n_items ||
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0)
+    return fail(FLOODER_E_ARG, "flooder_sweep_bvh_items_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
+                                  out_d2, reinterpret_cast<unsigned long long*>(stats), item_list, n_items, 1,
+                                  1, (hipStream_t)stream);
 }
 
 int flooder_selftest(const float* in64, float* out128, void* stream) {

@@ -455,6 +455,10 @@ int flooder_set_option(const char* name, int value) {
     g_sweep_variant = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "bvh_ks") == 0 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) {
+    g_bvh_ks = value;
+    return FLOODER_OK;
+  }
   return fail(FLOODER_E_ARG, "flooder_set_option: unknown option or value");
 }
 

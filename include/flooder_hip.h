@@ -146,6 +146,30 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
                           const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                           int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
 
+/* Same sweep restricted to an explicit work list and SEEDED with the minima already in out_d2 (upper
+ * bounds from an earlier pass): item_list[i] = simplex * ceil(R/64) + tile, tiles are 64 consecutive
+ * samples; *n_items (device int32) entries.  Finishes what flooder_sweep_cell_f32 could not verify. */
+int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                const float* verts, const float* weights, int k1, int R,
+                                int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
+                                int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
+
+/*
+ * Cell sweep (dim 2 and 3; the default device path there).  One workgroup per simplex: the points
+ * within c of the simplex (c = max(rho[s], extent/13)) are gathered through the box tree and
+ * counting-sorted into a cell grid in LDS; every sample visits the 3^dim cells around it.  A minimum
+ * <= (0.999 c)^2 is provably the nearest neighbour; tiles of 64 samples containing an unverified
+ * sample, and simplices whose region exceeds the LDS stage, are appended to flag_list
+ * (n_simplices * ceil(R/64) int32, *flag_count zeroed by the caller) for
+ * flooder_sweep_bvh_items_f32.  rho: per-simplex estimate of the largest nearest-neighbour distance
+ * (any positive value is correct; a good one is fast).  queue: one zeroed int32.
+ * stats: NULL or three zeroed uint64 {pairs evaluated, points staged, tiles flagged}.
+ */
+int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                           const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                           const float* rho, int32_t* queue, uint32_t* out_d2, int32_t* flag_list,
+                           int32_t* flag_count, uint64_t* stats, void* stream);
+
 /* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
 int flooder_selftest(const float* in64, float* out128, void* stream);
 

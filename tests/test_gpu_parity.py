@@ -80,7 +80,7 @@ def test_dpp_wave_reductions(dev):
         assert torch.equal(out[64:].cpu(), torch.full((64,), float(x.max())))
 
 
-@pytest.mark.parametrize("method", ["bvh", "ball"])
+@pytest.mark.parametrize("method", ["auto", "bvh", "ball"])
 @pytest.mark.parametrize("name", e2e_cases())
 def test_e2e_matches_reference_goldens(name, method, dev):
     z, kw, keys = load_e2e(name)
@@ -114,6 +114,10 @@ def test_culled_sweep_is_bit_identical_to_ball_sweep(name, dev):
     torch.manual_seed(1)
     b = fa.flood_complex(pts, lms, method="ball", **kw)
     assert a == b
+    if pts.shape[1] in (2, 3):
+        torch.manual_seed(1)
+        c = fa.flood_complex(pts, lms, method="cell", **kw)
+        assert a == c
 
 
 def test_landmarks_outside_cloud_match_cpu_path(dev):
