@@ -197,10 +197,10 @@ def main():
         st_h = {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1], "nodes_expanded": st_h[2]}
     elif args.method == "cell":
         st_h = stats.cpu().tolist()
-        done_evals = st_h[3] + st_h[6] * 16 * 64 + st_h[0] * 16 * 64
-        st_h = {"cell_pairs": st_h[3], "points_staged": st_h[4], "tiles_flagged": st_h[5],
-                "tiles_total": S * ((R + 63) // 64), "fallback_leaves_evaluated": st_h[6],
-                "fallback_leaves_tested": st_h[7], "probe_leaves_evaluated": st_h[0]}
+        done_evals = st_h[0] + st_h[4] * 16 * 64
+        st_h = {"cell_pairs": st_h[0], "points_staged": st_h[1], "tiles_flagged": st_h[2],
+                "restage_rounds": st_h[3], "tiles_total": S * ((R + 63) // 64),
+                "fallback_leaves_evaluated": st_h[4], "fallback_leaves_tested": st_h[5]}
     else:
         st_h = None
         done_evals = pair_evals

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libflooder_hip.so")
@@ -39,7 +39,7 @@ SIGNATURES = {
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),

@@ -488,19 +488,18 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     return out_face, out_dist
 
 
-PROBE_POINTS_PER_EDGE = 6   # lattice of the probe sweep that estimates each simplex's search radius
-PROBE_MARGIN = 1.25
+CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spacing
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                           reduce_hook: Optional[Callable[[torch.Tensor], None]],
                           want_dist: bool = False, timer: Optional[_KernelTimer] = None,
                           stats: Optional[torch.Tensor] = None):
-    """Cell sweep (dim 2 / 3): probe sweep -> per-simplex radius -> LDS cell-grid sweep -> exact tree
-    sweep of the unverified tiles -> [reduce_hook] -> face max.  No host synchronisation.
+    """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree sweep of the unverified
+    tiles -> [reduce_hook] -> face max.  No host synchronisation.
 
-    ``stats`` (optional, 9 zeroed int64): [0:3] probe tree sweep, [3:6] cell sweep {pairs, points staged,
-    tiles flagged}, [6:9] fallback tree sweep {leaves evaluated, leaves tested, nodes expanded}.
+    ``stats`` (optional, 7 zeroed int64): [0:4] cell sweep {pairs, points staged, tiles flagged,
+    re-staging rounds}, [4:7] finishing tree sweep {leaves evaluated, leaves tested, nodes expanded}.
     """
     lib = _native.load()
     dev = index.pts.device
@@ -517,34 +516,23 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     def sub(a, b):
         return None if stats is None else stats[a:b]
 
-    # 1. probe: exact nearest-neighbour distance at a coarse lattice of every simplex
-    w_probe, _, _ = generate_grid(PROBE_POINTS_PER_EDGE, k1 - 1, dev, torch.float32)
-    w_probe = w_probe.contiguous()
-    Rp = w_probe.shape[0]
-    d2p = torch.empty((S, Rp), dtype=torch.int32, device=dev)
     ctl = torch.zeros(4, dtype=torch.int32, device=dev)  # work-queue heads + flag counter
-    with _span(timer, "probe"):
-        _native.check(lib.flooder_sweep_bvh_f32(
-            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-            _native.ptr(w_probe), k1, Rp, S, ctl[0:].data_ptr(), _native.ptr(d2p), _native.ptr(sub(0, 3)), st),
-            "flooder_sweep_bvh_f32")
-    rho = (d2p.view(torch.float32).amax(dim=1).sqrt() * PROBE_MARGIN).contiguous()
 
-    # 2. cell sweep
+    # 1. cell sweep
     tiles64 = (R + 63) // 64
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     flag_list = torch.empty(S * tiles64, dtype=torch.int32, device=dev)
     with _span(timer, "sweep"):
         _native.check(lib.flooder_sweep_cell_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-            _native.ptr(w_perm), k1, R, S, _native.ptr(rho), ctl[1:].data_ptr(), _native.ptr(d2),
-            _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(sub(3, 6)), st), "flooder_sweep_cell_f32")
-    # 3. exact finish of the flagged tiles, seeded with the minima found so far
+            _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl[1:].data_ptr(), _native.ptr(d2),
+            _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(sub(0, 4)), st), "flooder_sweep_cell_f32")
+    # 2. exact finish of the flagged tiles, seeded with the minima found so far
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, _native.ptr(flag_list), ctl[2:].data_ptr(), ctl[3:].data_ptr(),
-            _native.ptr(d2), _native.ptr(sub(6, 9)), st), "flooder_sweep_bvh_items_f32")
+            _native.ptr(d2), _native.ptr(sub(4, 7)), st), "flooder_sweep_bvh_items_f32")
 
     if reduce_hook is not None:
         with _span(timer, "reduce"):

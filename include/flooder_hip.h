@@ -155,19 +155,20 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
                                 int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
 
 /*
- * Cell sweep (dim 2 and 3; the default device path there).  One workgroup per simplex: the points
- * within c of the simplex (c = max(rho[s], extent/13)) are gathered through the box tree and
- * counting-sorted into a cell grid in LDS; every sample visits the 3^dim cells around it.  A minimum
- * <= (0.999 c)^2 is provably the nearest neighbour; tiles of 64 samples containing an unverified
- * sample, and simplices whose region exceeds the LDS stage, are appended to flag_list
- * (n_simplices * ceil(R/64) int32, *flag_count zeroed by the caller) for
- * flooder_sweep_bvh_items_f32.  rho: per-simplex estimate of the largest nearest-neighbour distance
- * (any positive value is correct; a good one is fast).  queue: one zeroed int32.
- * stats: NULL or three zeroed uint64 {pairs evaluated, points staged, tiles flagged}.
+ * Cell sweep (dim 2 and 3; the default device path there).  One wave per chunk of 256 consecutive
+ * samples of a simplex: the cloud's density inside the chunk's bounding box gives a cell size
+ * c = alpha * (volume / points)^(1/dim); the points within c of the chunk are gathered through the box
+ * tree and counting-sorted into a cell grid in LDS; every sample visits the 3^dim cells around it.  A
+ * minimum <= (0.999 c)^2 is provably the nearest neighbour; otherwise c doubles (up to 3 rounds).  Tiles
+ * of 64 samples that stay unverified or do not fit the LDS stage are appended to flag_list
+ * (n_simplices * ceil(R/64) int32; *flag_count zeroed by the caller) for flooder_sweep_bvh_items_f32,
+ * which finishes them exactly.  alpha > 0 only trades speed (1.35 is a good value), never correctness.
+ * queue: one zeroed int32.  stats: NULL or four zeroed uint64 {pairs evaluated, points staged, tiles
+ * flagged, re-staging rounds}.
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                           const float* rho, int32_t* queue, uint32_t* out_d2, int32_t* flag_list,
+                           float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list,
                            int32_t* flag_count, uint64_t* stats, void* stream);
 
 /* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
