@@ -345,6 +345,15 @@ __global__ void selftest_kernel(const float* in, float* out) {
   const float x = in[threadIdx.x];
   out[threadIdx.x] = wave_min_f32(x);
   out[64 + threadIdx.x] = wave_max_f32(x);
+  // inclusive scan by __shfl_up, as used by the cell sweep's counting sort
+  int v = (int)(x * 100.f);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  out[128 + threadIdx.x] = (float)v;
 }
 
 }  // namespace

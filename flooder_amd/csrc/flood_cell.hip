@@ -49,6 +49,14 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   return v;
 }
 
+// LDS hand-off between lanes of ONE wave: make earlier LDS writes/atomics of every lane visible to
+// later LDS reads of every lane (compiler and hardware ordering), without a workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -66,12 +74,14 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   __shared__ float4 s_pts_all[4][CAPW];
   __shared__ int s_cell_all[4][NC + 8];
   __shared__ int s_leaf_all[4][MAXLEAF];
+  __shared__ int s_keep_all[4][CAPW];  // kept candidates of the count pass: (candidate slot << 10) | cell
   __shared__ int s_front_all[4][2][MAXFRONT];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   float4* s_pts = s_pts_all[wv];
   int* s_cell = s_cell_all[wv];      // [i+1]: count -> start -> end of cell i
   int* s_leaf = s_leaf_all[wv];
+  int* s_keep = s_keep_all[wv];
   const int top = lv.n_levels - 1;
   const int chunks = (R + CHUNK - 1) / CHUNK;
   const int tiles64 = (R + 63) >> 6;
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           if (hit) out_list[out_n + lane_rank(m)] = (int)idx;
           out_n += cnt;
         }
+        wave_lds_sync();
       };
       if (top == 0) test_children(0, 0, s_leaf, n_leaf, MAXLEAF);
       else test_children(top, 0, fa, na, MAXFRONT);
@@ -222,13 +233,17 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     float c = ext;
     if (!give_up) {
       int n0 = 0;
-      for (int idx = lane; idx < n_leaves * LEAF; idx += 64) {
-        const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-        float x[DP];
-        load_row<DP>(pts + row * DP, x);
-        bool in = true;
+      // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
+      for (int ib = 0; ib < n_leaves * LEAF; ib += 64) {
+        const int idx = ib + lane;
+        bool in = idx < n_leaves * LEAF;
+        if (in) {
+          const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
+          float x[DP];
+          load_row<DP>(pts + row * DP, x);
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) in = in && (x[k] >= blo[k]) && (x[k] <= bhi[k]);
+          for (int k = 0; k < DIM; ++k) in = in && (x[k] >= blo[k]) && (x[k] <= bhi[k]);
+        }
         n0 += __popcll(__ballot(in));
       }
       if (n0 > 0 && vol > 0.f) {
@@ -283,47 +298,59 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       n_leaves = gather();
       if (n_leaves < 0) { give_up = true; break; }
       for (int i = lane; i < ncells + 2; i += 64) s_cell[i] = 0;
-      // 2a. count per cell
-      for (int idx = lane; idx < n_leaves * LEAF; idx += 64) {
-        const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
+      wave_lds_sync();
+      // 2a. classify every candidate ONCE (keep? which cell?), count per cell, remember the kept ones
+      int n_keep = 0;  // wave-uniform: the loop has a uniform trip count
+      for (int ib = 0; ib < n_leaves * LEAF; ib += 64) {
+        const int idx = ib + lane;
+        bool keep = idx < n_leaves * LEAF;
+        int cid = 0;
+        int64_t row = 0;
         float x[DP];
-        load_row<DP>(pts + row * DP, x);
-        if (keep_point(x)) atomicAdd(&s_cell[cell_of(x) + 1], 1);
+        if (keep) {
+          row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
+          load_row<DP>(pts + row * DP, x);
+          keep = keep_point(x);
+          cid = cell_of(x);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int cnt = __popcll(m);
+        if (keep) {
+          atomicAdd(&s_cell[cid + 1], 1);
+          const int slot = n_keep + lane_rank(m);
+          if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
+        }
+        n_keep += cnt;
       }
-      // 2b. exclusive prefix: s_cell[i+1] = start of cell i
-      const int per = (ncells + 63) / 64;
-      int sum = 0;
-      for (int i = 0; i < per; ++i) {
-        const int ci = lane * per + i;
-        if (ci < ncells) sum += s_cell[ci + 1];
+      if (n_keep > CAPW) { give_up = true; break; }
+      wave_lds_sync();
+      // 2b. exclusive prefix, 64 cells per step: s_cell[i+1] = start of cell i
+      int total = 0;
+      for (int cb = 0; cb < ncells; cb += 64) {
+        const int ci = cb + lane;
+        const int cnt = ci < ncells ? s_cell[ci + 1] : 0;
+        const int incl = wave_incl_scan(cnt, lane);
+        if (ci < ncells) s_cell[ci + 1] = total + incl - cnt;
+        total += wave_uniform(__shfl(incl, 63));
       }
-      const int incl = wave_incl_scan(sum, lane);
-      const int total = wave_uniform(__shfl(incl, 63));
+      wave_lds_sync();
       if (total > CAPW) { give_up = true; break; }
-      int run = incl - sum;
-      for (int i = 0; i < per; ++i) {
-        const int ci = lane * per + i;
-        if (ci < ncells) {
-          const int cnt = s_cell[ci + 1];
-          s_cell[ci + 1] = run;
-          run += cnt;
-        }
-      }
-      // 2c. scatter; afterwards s_cell[i] = begin and s_cell[i+1] = end of cell i
-      for (int idx = lane; idx < n_leaves * LEAF; idx += 64) {
+      // 2c. scatter the kept candidates; afterwards s_cell[i] = begin and s_cell[i+1] = end of cell i
+      for (int k = lane; k < n_keep; k += 64) {
+        const int e = s_keep[k];
+        const int idx = e >> 10, cid = e & 1023;
         const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
         float x[DP];
         load_row<DP>(pts + row * DP, x);
-        if (keep_point(x)) {
-          const int pos = atomicAdd(&s_cell[cell_of(x) + 1], 1);
-          float4 v;
-          v.x = x[0];
-          v.y = x[1];
-          v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
-          v.w = 0.f;
-          s_pts[pos] = v;
-        }
+        const int pos = atomicAdd(&s_cell[cid + 1], 1);
+        float4 v;
+        v.x = x[0];
+        v.y = x[1];
+        v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
+        v.w = 0.f;
+        s_pts[pos] = v;
       }
+      wave_lds_sync();
       n_staged += (unsigned long long)total;
       if (attempt > 0) ++n_retries;
 
