@@ -134,7 +134,7 @@ def main():
                                              _native.current_stream_ptr(dev)), "ball_count")
     P_local = int(cnt0.sum().item())
     del pts_pad0, search0, lo0, hi0, cnt0
-    stats = torch.zeros(9, dtype=torch.int64, device=dev)
+    stats = torch.zeros(12, dtype=torch.int64, device=dev)
 
     def step(timer=None):
         """raw (unsorted-for-this-method) shard in HBM -> per-face filtration values in HBM"""
@@ -197,10 +197,13 @@ def main():
         st_h = {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1], "nodes_expanded": st_h[2]}
     elif args.method == "cell":
         st_h = stats.cpu().tolist()
-        done_evals = st_h[0] + st_h[4] * 16 * 64
+        done_evals = st_h[0] + st_h[9] * 16 * 64
         st_h = {"cell_pairs": st_h[0], "points_staged": st_h[1], "tiles_flagged": st_h[2],
                 "restage_rounds": st_h[3], "tiles_total": S * ((R + 63) // 64),
-                "fallback_leaves_evaluated": st_h[4], "fallback_leaves_tested": st_h[5]}
+                "chunks_total": S * ((R + 255) // 256),
+                "giveup_gather_density": st_h[4], "giveup_gather_stage": st_h[5], "giveup_lds_full": st_h[6],
+                "giveup_doublings": st_h[7], "exhaustive_rounds": st_h[8],
+                "fallback_leaves_evaluated": st_h[9], "fallback_leaves_tested": st_h[10]}
     else:
         st_h = None
         done_evals = pair_evals

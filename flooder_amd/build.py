@@ -44,7 +44,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         return HIP_LIB
     cmd = [
         _hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-        "-DFLOODER_BUILD", "-Wl,-rpath,/opt/rocm/lib",
+        "-DFLOODER_BUILD", "-Wl,-rpath,/opt/rocm/lib", *os.environ.get("FLOODER_HIPCC_FLAGS", "").split(),
         "-o", HIP_LIB + ".tmp",
     ] + srcs
     if verbose:

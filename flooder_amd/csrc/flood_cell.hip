@@ -30,9 +30,10 @@ namespace {
 constexpr int CHUNK = 256;        // samples per wave item
 constexpr int SPL = CHUNK / 64;   // samples per lane
 constexpr int CAPW = 512;         // points staged per wave
-constexpr int MAXLEAF = 128;      // leaves gathered per wave item (2048 points before filtering)
-constexpr int MAXFRONT = 64;      // inner nodes per level of the gather
+constexpr int MAXLEAF = 384;      // leaves gathered per wave item (6144 points before filtering)
+constexpr int MAXFRONT = 128;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;
+constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 
 template <int DIM>
 struct CellCfg {
@@ -61,6 +62,14 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
+#ifdef FLOODER_PHASE_TIMERS
+#define PHASE_T0() unsigned long long _t_prev = __builtin_amdgcn_s_memtime()
+#define PHASE(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); t_phase[i] += _t - _t_prev; _t_prev = _t; } while (0)
+#else
+#define PHASE_T0() do {} while (0)
+#define PHASE(i) do {} while (0)
+#endif
+
 template <int DIM>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
@@ -87,8 +96,13 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   const int tiles64 = (R + 63) >> 6;
   const int64_t n_items = n_simplices * chunks;
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
+#ifdef FLOODER_PHASE_TIMERS
+  unsigned long long t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  unsigned long long g_gather0 = 0, g_gather = 0, g_cap = 0, g_tries = 0, g_brute = 0;
 
   for (;;) {
+    PHASE_T0();
     int g32 = 0;
     if (lane == 0) g32 = atomicAdd(queue, 1);
     const int64_t g = (int64_t)wave_uniform(g32);
@@ -96,6 +110,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const int64_t s = g / chunks;
     const int q = (int)(g - s * chunks);
     const float* vs = verts + s * (int64_t)k1 * DIM;
+    PHASE(0);
 
     // ---- 0. samples and chunk box
     float p[SPL][DIM];
@@ -181,43 +196,58 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
 
+    PHASE(1);
     // ---- gather: leaves of the box tree overlapping [qlo, qhi]; returns their number or -1 (overflow)
     float qlo[DIM], qhi[DIM];
     auto gather = [&]() -> int {
+      constexpr int GB = 4;  // frontier nodes tested per step
       int* fa = s_front_all[wv][0];
       int* fb = s_front_all[wv][1];
       int na = 0, nb = 0, n_leaf = 0;
       bool over = false;
-      auto test_children = [&](int lvl, int64_t grp, int* out_list, int& out_n, int cap) {
-        const int64_t idx = grp * FAN + lane;
-        bool hit = false;
-        if (idx < lv.count[lvl]) {
-          float lo[DP], hi[DP];
-          const float* nb_ = nodes + (lv.off[lvl] + idx) * 2 * DP;
-          load_row<DP>(nb_, lo);
-          load_row<DP>(nb_ + DP, hi);
-          hit = true;
+      // children of up to GB nodes `grp[u]` (valid for u < ng) at level lvl -> append hits to out_list
+      auto test_children = [&](int lvl, const int64_t (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
+        bool hit[GB];
+        float lo[GB][DP], hi[GB][DP];
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) hit = hit && (lo[k] <= qhi[k]) && (hi[k] >= qlo[k]);
+        for (int u = 0; u < GB; ++u) {
+          const int64_t idx = grp[u] * FAN + lane;
+          hit[u] = (u < ng) && (idx < lv.count[lvl]);
+          const float* nb_ = nodes + (lv.off[lvl] + (hit[u] ? idx : 0)) * 2 * DP;
+          load_row<DP>(nb_, lo[u]);
+          load_row<DP>(nb_ + DP, hi[u]);
         }
-        const unsigned long long m = __ballot(hit);
-        const int cnt = __popcll(m);
-        if (out_n + cnt > cap) {
-          over = true;
-        } else {
-          if (hit) out_list[out_n + lane_rank(m)] = (int)idx;
-          out_n += cnt;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          if (u < ng) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) hit[u] = hit[u] && (lo[u][k] <= qhi[k]) && (hi[u][k] >= qlo[k]);
+            const unsigned long long m = __ballot(hit[u]);
+            const int cnt = __popcll(m);
+            if (out_n + cnt > cap) {
+              over = true;
+            } else {
+              if (hit[u]) out_list[out_n + lane_rank(m)] = (int)(grp[u] * FAN + lane);
+              out_n += cnt;
+            }
+          }
         }
         wave_lds_sync();
       };
-      if (top == 0) test_children(0, 0, s_leaf, n_leaf, MAXLEAF);
-      else test_children(top, 0, fa, na, MAXFRONT);
+      {
+        const int64_t g0_[GB] = {0, 0, 0, 0};
+        if (top == 0) test_children(0, g0_, 1, s_leaf, n_leaf, MAXLEAF);
+        else test_children(top, g0_, 1, fa, na, MAXFRONT);
+      }
       for (int lvl = top; lvl >= 1 && !over; --lvl) {
         nb = 0;
-        for (int f = 0; f < na && !over; ++f) {
-          const int node = wave_uniform(fa[f]);
-          if (lvl == 1) test_children(0, node, s_leaf, n_leaf, MAXLEAF);
-          else test_children(lvl - 1, node, fb, nb, MAXFRONT);
+        for (int f = 0; f < na && !over; f += GB) {
+          int64_t grp[GB];
+          const int ng = na - f < GB ? na - f : GB;
+#pragma unroll
+          for (int u = 0; u < GB; ++u) grp[u] = wave_uniform(fa[f + u < na ? f + u : f]);
+          if (lvl == 1) test_children(0, grp, ng, s_leaf, n_leaf, MAXLEAF);
+          else test_children(lvl - 1, grp, ng, fb, nb, MAXFRONT);
         }
         int* t = fa; fa = fb; fb = t;
         na = nb;
@@ -229,22 +259,30 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { qlo[k] = blo[k]; qhi[k] = bhi[k]; }
     int n_leaves = gather();
+    PHASE(2);
     bool give_up = n_leaves < 0;
+    if (give_up) ++g_gather0;
     float c = ext;
     if (!give_up) {
       int n0 = 0;
       // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
-      for (int ib = 0; ib < n_leaves * LEAF; ib += 64) {
-        const int idx = ib + lane;
-        bool in = idx < n_leaves * LEAF;
-        if (in) {
-          const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-          float x[DP];
-          load_row<DP>(pts + row * DP, x);
+      const int n_cand0 = n_leaves * LEAF;
+      for (int ib = 0; ib < n_cand0; ib += 64 * UNR) {
+        float x[UNR][DP];
+        bool in[UNR];
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) in = in && (x[k] >= blo[k]) && (x[k] <= bhi[k]);
+        for (int u = 0; u < UNR; ++u) {  // issue all loads of the step first
+          const int idx = ib + u * 64 + lane;
+          in[u] = idx < n_cand0;
+          const int64_t row = in[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
+          load_row<DP>(pts + row * DP, x[u]);
         }
-        n0 += __popcll(__ballot(in));
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) in[u] = in[u] && (x[u][k] >= blo[k]) && (x[u][k] <= bhi[k]);
+          n0 += __popcll(__ballot(in[u]));
+        }
       }
       if (n0 > 0 && vol > 0.f) {
         const float h = DIM == 3 ? cbrtf(vol / (float)n0) : __builtin_sqrtf(vol / (float)n0);
@@ -252,6 +290,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
     if (!(c > 0.f) || !(c < 3.0e38f)) c = 1.f;
+    PHASE(3);
 
     // ---- 2-4. stage, query, verify; double c while samples stay open
     for (int attempt = 0; attempt < MAX_TRIES && !give_up; ++attempt) {
@@ -296,33 +335,114 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       };
 
       n_leaves = gather();
-      if (n_leaves < 0) { give_up = true; break; }
+      PHASE(4);
+      if (n_leaves < 0) { give_up = true; ++g_gather; break; }
       for (int i = lane; i < ncells + 2; i += 64) s_cell[i] = 0;
       wave_lds_sync();
       // 2a. classify every candidate ONCE (keep? which cell?), count per cell, remember the kept ones
       int n_keep = 0;  // wave-uniform: the loop has a uniform trip count
-      for (int ib = 0; ib < n_leaves * LEAF; ib += 64) {
-        const int idx = ib + lane;
-        bool keep = idx < n_leaves * LEAF;
-        int cid = 0;
-        int64_t row = 0;
-        float x[DP];
-        if (keep) {
-          row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-          load_row<DP>(pts + row * DP, x);
-          keep = keep_point(x);
-          cid = cell_of(x);
+      const int n_cand = n_leaves * LEAF;
+      for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
+        float x[UNR][DP];
+        bool keep[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {  // issue all loads of the step first
+          const int idx = ib + u * 64 + lane;
+          keep[u] = idx < n_cand;
+          const int64_t row = keep[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
+          load_row<DP>(pts + row * DP, x[u]);
         }
-        const unsigned long long m = __ballot(keep);
-        const int cnt = __popcll(m);
-        if (keep) {
-          atomicAdd(&s_cell[cid + 1], 1);
-          const int slot = n_keep + lane_rank(m);
-          if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int idx = ib + u * 64 + lane;
+          keep[u] = keep[u] && keep_point(x[u]);
+          const int cid = cell_of(x[u]);
+          const unsigned long long m = __ballot(keep[u]);
+          if (keep[u]) {
+            atomicAdd(&s_cell[cid + 1], 1);
+            const int slot = n_keep + lane_rank(m);
+            if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
+          }
+          n_keep += __popcll(m);
         }
-        n_keep += cnt;
       }
-      if (n_keep > CAPW) { give_up = true; break; }
+      PHASE(5);
+      const float c_ok = (0.999f * c) * (0.999f * c);
+      if (n_keep > CAPW) {
+        // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
+        // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
+        // runs its open samples against the staged batch with broadcast LDS reads.
+        wave_lds_sync();
+        ++g_brute;
+        int n_st = 0;
+        auto flush = [&]() {
+          wave_lds_sync();
+          for (int j = 0; j < n_st; j += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u < n_st ? j + u : n_st - 1];
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) {
+              float bb = best[i];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                float t0 = p[i][0] - x[u].x;
+                float d2 = t0 * t0;
+                t0 = p[i][1] - x[u].y;
+                d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = p[i][2] - x[u].z;
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                bb = __builtin_fminf(bb, d2);
+              }
+              best[i] = bb;
+            }
+          }
+          n_pairs += (unsigned long long)n_st * SPL;
+          n_st = 0;
+          wave_lds_sync();
+        };
+        for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
+          float x[UNR][DP];
+          bool keep[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int idx = ib + u * 64 + lane;
+            keep[u] = idx < n_cand;
+            const int64_t row = keep[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
+            load_row<DP>(pts + row * DP, x[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            keep[u] = keep[u] && keep_point(x[u]);
+            const unsigned long long m = __ballot(keep[u]);
+            if (n_st + __popcll(m) > CAPW) flush();
+            if (keep[u]) {
+              float4 v;
+              v.x = x[u][0];
+              v.y = x[u][1];
+              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+              v.w = 0.f;
+              s_pts[n_st + lane_rank(m)] = v;
+            }
+            n_st += __popcll(m);
+          }
+        }
+        if (n_st > 0) flush();
+        bool any_open = false;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          open[i] = open[i] && !(best[i] <= c_ok);
+          any_open = any_open || open[i];
+        }
+        if (attempt > 0) ++n_retries;
+        PHASE(9);
+        if (__ballot(any_open) == 0ull) break;
+        if (attempt == MAX_TRIES - 1) ++g_tries;
+        c *= 2.f;
+        continue;
+      }
       wave_lds_sync();
       // 2b. exclusive prefix, 64 cells per step: s_cell[i+1] = start of cell i
       int total = 0;
@@ -335,63 +455,98 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
       wave_lds_sync();
       if (total > CAPW) { give_up = true; break; }
+      PHASE(6);
       // 2c. scatter the kept candidates; afterwards s_cell[i] = begin and s_cell[i+1] = end of cell i
-      for (int k = lane; k < n_keep; k += 64) {
-        const int e = s_keep[k];
-        const int idx = e >> 10, cid = e & 1023;
-        const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-        float x[DP];
-        load_row<DP>(pts + row * DP, x);
-        const int pos = atomicAdd(&s_cell[cid + 1], 1);
-        float4 v;
-        v.x = x[0];
-        v.y = x[1];
-        v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
-        v.w = 0.f;
-        s_pts[pos] = v;
+      for (int kb = 0; kb < n_keep; kb += 64 * UNR) {
+        float x[UNR][DP];
+        int cid[UNR];
+        bool on[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int k = kb + u * 64 + lane;
+          on[u] = k < n_keep;
+          const int e = on[u] ? s_keep[k] : 0;
+          const int idx = e >> 10;
+          cid[u] = e & 1023;
+          const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
+          load_row<DP>(pts + row * DP, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (on[u]) {
+            const int pos = atomicAdd(&s_cell[cid[u] + 1], 1);
+            float4 v;
+            v.x = x[u][0];
+            v.y = x[u][1];
+            v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+            v.w = 0.f;
+            s_pts[pos] = v;
+          }
+        }
       }
       wave_lds_sync();
       n_staged += (unsigned long long)total;
       if (attempt > 0) ++n_retries;
 
+      PHASE(7);
       // 3. query the open samples
-      const float c_ok = (0.999f * c) * (0.999f * c);
       bool any_open = false;
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         if (open[i]) {
           int ck[DIM];
+          float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
-            const int t = (int)((p[i][k] - g0[k]) * inv_c);
+            const float tf = (p[i][k] - g0[k]) * inv_c;
+            const int t = (int)tf;
             ck[k] = t < 1 ? 1 : (t > nc[k] - 2 ? nc[k] - 2 : t);
+            const float f = tf - (float)ck[k];  // position inside the (clamped) cell, in cells
+            const float lo_gap = __builtin_fmaxf(f, 0.f) * c * 0.999f;
+            const float hi_gap = __builtin_fmaxf(1.f - f, 0.f) * c * 0.999f;
+            gap2[k][0] = lo_gap * lo_gap;
+            gap2[k][1] = 0.f;
+            gap2[k][2] = hi_gap * hi_gap;
           }
           float b = best[i];
+          // rows of 3 cells along x, nearest first; a row is skipped when even its slab is no closer
+          // than the running minimum
           constexpr int NROW = DIM == 3 ? 9 : 3;
+          constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+          constexpr int ORD2[3] = {0, -1, 1};
 #pragma unroll
           for (int rw = 0; rw < NROW; ++rw) {
             int base;
+            float lb;
             if constexpr (DIM == 3) {
-              const int dz = rw / 3 - 1, dy = rw % 3 - 1;
+              const int dy = ORD3[rw][0], dz = ORD3[rw][1];
               base = ((ck[2] + dz) * nc[1] + (ck[1] + dy)) * nc[0] + ck[0] - 1;
+              lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
             } else {
-              const int dy = rw - 1;
+              const int dy = ORD2[rw];
               base = (ck[1] + dy) * nc[0] + ck[0] - 1;
+              lb = gap2[1][dy + 1];
             }
+            if (!(lb < b)) continue;
             const int bg = s_cell[base];
             const int en = s_cell[base + 3];
             n_pairs += (unsigned long long)(en - bg);
-            for (int j = bg; j < en; ++j) {
-              const float4 x = s_pts[j];
-              float t0 = p[i][0] - x.x;
-              float d2 = t0 * t0;
-              t0 = p[i][1] - x.y;
-              d2 = __builtin_fmaf(t0, t0, d2);
-              if constexpr (DIM == 3) {
-                t0 = p[i][2] - x.z;
+            for (int j = bg; j < en; j += 4) {  // 4 LDS reads in flight; repeats of the last point are harmless
+              float4 x[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u < en ? j + u : en - 1];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                float t0 = p[i][0] - x[u].x;
+                float d2 = t0 * t0;
+                t0 = p[i][1] - x[u].y;
                 d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = p[i][2] - x[u].z;
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                b = __builtin_fminf(b, d2);
               }
-              b = __builtin_fminf(b, d2);
             }
           }
           best[i] = b;
@@ -399,7 +554,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         }
         any_open = any_open || open[i];
       }
+      PHASE(8);
       if (__ballot(any_open) == 0ull) break;
+      if (attempt == MAX_TRIES - 1) ++g_tries;
       c *= 2.f;
     }
 
@@ -416,8 +573,13 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         ++n_flagged;
       }
     }
+    PHASE(10);
   }
   if (stats) {
+#ifdef FLOODER_PHASE_TIMERS
+    if (lane == 0)
+      for (int i = 0; i < 12; ++i) atomicAdd(&stats[16 + i], t_phase[i]);
+#endif
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_pairs += __shfl_xor(n_pairs, o);
     if (lane == 0) {
@@ -425,6 +587,11 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       atomicAdd(&stats[1], n_staged);
       atomicAdd(&stats[2], n_flagged);
       atomicAdd(&stats[3], n_retries);
+      atomicAdd(&stats[4], g_gather0);
+      atomicAdd(&stats[5], g_gather);
+      atomicAdd(&stats[6], g_cap);
+      atomicAdd(&stats[7], g_tries);
+      atomicAdd(&stats[8], g_brute);
     }
   }
 }

@@ -163,8 +163,9 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
  * of 64 samples that stay unverified or do not fit the LDS stage are appended to flag_list
  * (n_simplices * ceil(R/64) int32; *flag_count zeroed by the caller) for flooder_sweep_bvh_items_f32,
  * which finishes them exactly.  alpha > 0 only trades speed (1.35 is a good value), never correctness.
- * queue: one zeroed int32.  stats: NULL or four zeroed uint64 {pairs evaluated, points staged, tiles
- * flagged, re-staging rounds}.
+ * queue: one zeroed int32.  stats: NULL or nine zeroed uint64 {pairs evaluated, points staged, tiles
+ * flagged, re-staging rounds, chunks given up: tree gather overflow at density / at staging, kept list
+ * full, cell doublings exhausted; rounds evaluated exhaustively because the LDS stage was full}.
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,

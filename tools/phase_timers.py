@@ -1,0 +1,27 @@
+"""Diagnostic: per-phase cycle shares of the cell sweep (library built with -DFLOODER_PHASE_TIMERS)."""
+import sys, torch, numpy as np
+sys.path.insert(0, '.')
+import flooder_amd as fa
+from flooder_amd import _native, core
+lib = _native.load()
+torch.manual_seed(42)
+dev = torch.device('cuda:0')
+pts = torch.randn(1_000_000, 3).to(dev)
+lms = fa.generate_landmarks(pts, 1000, start_idx=0)
+stree, simplices = core._build_complex(lms, 3)
+simp = torch.as_tensor(simplices[3], device=dev)
+verts = lms[simp]
+weights, vi, fi = core.generate_grid(30, 3, dev, torch.float32)
+faces = core._FaceTable(fi, weights.shape[0], dev)
+index = core.PointIndex(pts)
+stats = torch.zeros(32, dtype=torch.int64, device=dev)
+for _ in range(2):
+    stats.zero_()
+    core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
+torch.cuda.synchronize()
+t = stats[16:28].cpu().numpy().astype(float)
+names = ["pop", "samples+box+planes", "gather0", "density", "gather1", "count", "prefix", "scatter", "query", "brute", "output", "-"]
+tot = t.sum()
+for n, v in zip(names, t):
+    print(f"{n:22s} {v/tot*100:6.2f} %   {v/121040/2400:8.2f} us/chunk (at 2.4 GHz... memtime ticks 100MHz? raw {v:.3e})")
+print("stats", stats[:12].tolist())
