@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the CPU baseline sample")
     ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
     ap.add_argument("--bvh-ks", type=int, default=None, help="samples per lane of the culled sweep (1,2,4,8)")
+    ap.add_argument("--bvh-subs", type=int, default=None, help="waves per flagged tile in the exact finish")
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
@@ -100,6 +101,8 @@ def main():
 
     if args.bvh_ks is not None:
         _native.check(lib.flooder_set_option(b"bvh_ks", args.bvh_ks), "set_option")
+    if args.bvh_subs is not None:
+        _native.check(lib.flooder_set_option(b"bvh_subs", args.bvh_subs), "set_option")
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
@@ -134,7 +137,7 @@ def main():
                                              _native.current_stream_ptr(dev)), "ball_count")
     P_local = int(cnt0.sum().item())
     del pts_pad0, search0, lo0, hi0, cnt0
-    stats = torch.zeros(12, dtype=torch.int64, device=dev)
+    stats = torch.zeros(13, dtype=torch.int64, device=dev)
 
     def step(timer=None):
         """raw (unsorted-for-this-method) shard in HBM -> per-face filtration values in HBM"""
@@ -148,7 +151,7 @@ def main():
             with core._span(timer, "index_total"):
                 index = core.PointIndex(shard_raw, timer)
             stats.zero_()
-            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats[:3])
+            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats[:4])
         else:
             with core._span(timer, "index_total"):
                 o = torch.argsort(shard_raw[:, axis])
@@ -203,7 +206,8 @@ def main():
                 "chunks_total": S * ((R + 255) // 256),
                 "giveup_gather_density": st_h[4], "giveup_gather_stage": st_h[5], "giveup_lds_full": st_h[6],
                 "giveup_doublings": st_h[7], "exhaustive_rounds": st_h[8],
-                "fallback_leaves_evaluated": st_h[9], "fallback_leaves_tested": st_h[10]}
+                "fallback_leaves_evaluated": st_h[9], "fallback_leaves_tested": st_h[10],
+                "fallback_nodes_expanded": st_h[11], "fallback_max_tests_one_tile": st_h[12]}
     else:
         st_h = None
         done_evals = pair_evals

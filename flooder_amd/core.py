@@ -498,9 +498,9 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree sweep of the unverified
     tiles -> [reduce_hook] -> face max.  No host synchronisation.
 
-    ``stats`` (optional, 12 zeroed int64): [0:9] cell sweep {pairs, points staged, tiles flagged,
-    re-staging rounds, 4 give-up reasons, exhaustive rounds}, [9:12] finishing tree sweep {leaves
-    evaluated, leaves tested, nodes expanded}.
+    ``stats`` (optional, 13 zeroed int64): [0:9] cell sweep {pairs, points staged, tiles flagged,
+    re-staging rounds, 4 give-up reasons, exhaustive rounds}, [9:13] finishing tree sweep {leaves
+    evaluated, leaves tested, nodes expanded, most tests by one tile}.
     """
     lib = _native.load()
     dev = index.pts.device
@@ -527,13 +527,13 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         _native.check(lib.flooder_sweep_cell_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl[1:].data_ptr(), _native.ptr(d2),
-            _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(stats), st), "flooder_sweep_cell_f32")
+            _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
     # 2. exact finish of the flagged tiles, seeded with the minima found so far
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, _native.ptr(flag_list), ctl[2:].data_ptr(), ctl[3:].data_ptr(),
-            _native.ptr(d2), _native.ptr(sub(9, 12)), st), "flooder_sweep_bvh_items_f32")
+            _native.ptr(d2), _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
 
     if reduce_hook is not None:
         with _span(timer, "reduce"):

@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -125,23 +125,32 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
-    const int32_t* __restrict__ n_list, int seed) {
+    const int32_t* __restrict__ n_list, int seed, int subs) {
+  // subs > 1 (work-list mode, KSV = 1): a tile of 64 samples is split over `subs` waves, each wave
+  // carrying 64/subs distinct samples (replicated across its lanes) - tight boxes for the hard tiles.
   constexpr int DP = padded_dim(DIM);
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tiles = (R + 64 * KSV - 1) / (64 * KSV);
-  const int64_t n_items = item_list ? (int64_t)n_list[0] : n_simplices * tiles;
+  const int64_t n_items = item_list ? (int64_t)n_list[0] * subs : n_simplices * tiles;
+  const int per_sub = 64 / subs;
   const int top = lv.n_levels - 1;
-  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0;
+  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
 
   for (;;) {
     int g32 = 0;
     if (lane == 0) g32 = atomicAdd(queue, 1);
     int64_t g = (int64_t)wave_uniform(g32);
     if (g >= n_items) break;
-    if (item_list) g = (int64_t)item_list[g];  // explicit (simplex, tile) work list
+    int sub = 0;
+    if (item_list) {  // explicit (simplex, tile) work list
+      sub = (int)(g % subs);
+      g = (int64_t)item_list[g / subs];
+    }
+    const int slane = sub * per_sub + (lane & (per_sub - 1));  // sample slot of this lane inside the tile
+    const unsigned long long tests_before = n_leaf_test + n_node_test;
     const int64_t s = g / tiles;
     const int tile = (int)(g - s * tiles);
 
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* vs = verts + s * (int64_t)k1 * DIM;
 #pragma unroll
     for (int i = 0; i < KSV; ++i) {
-      int r = tile * 64 * KSV + i * 64 + lane;
+      int r = tile * 64 * KSV + i * 64 + slane;
       if (r >= R) r = R - 1;  // duplicate of the last sample, never stored
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
@@ -277,11 +286,14 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 
 #pragma unroll
     for (int i = 0; i < KSV; ++i) {
-      const int r = tile * 64 * KSV + i * 64 + lane;
-      if (r < R) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
+      const int r = tile * 64 * KSV + i * 64 + slane;
+      if (r < R && lane < per_sub) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
     }
+    const unsigned long long item_tests = n_leaf_test + n_node_test - tests_before;
+    max_item_tests = item_tests > max_item_tests ? item_tests : max_item_tests;
   }
   if (stats && lane == 0) {
+    atomicMax(&stats[3], max_item_tests);
     atomicAdd(&stats[0], n_leaf_eval);
     atomicAdd(&stats[1], n_leaf_test);
     atomicAdd(&stats[2], n_node_test);
@@ -320,22 +332,22 @@ struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
                  unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
-                 int force_ks, hipStream_t st) {
+                 int force_ks, int subs, hipStream_t st) {
     const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : (R <= 128 ? 2 : (R <= 256 ? 4 : 8));
     if (ks == 1)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
     else if (ks == 2)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
     else if (ks == 4)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
     else
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
     return check_launch("sweep_bvh");
   }
 };
@@ -399,7 +411,7 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
     return fail(FLOODER_E_ARG, "flooder_sweep_bvh_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
-                                  out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0,
+                                  out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0, 1,
                                   (hipStream_t)stream);
 }
 
@@ -414,7 +426,7 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), item_list, n_items, 1,
-                                  1, (hipStream_t)stream);
+                                  1, g_bvh_subs, (hipStream_t)stream);
 }
 
 int flooder_selftest(const float* in64, float* out128, void* stream) {

@@ -30,8 +30,8 @@ namespace {
 constexpr int CHUNK = 256;        // samples per wave item
 constexpr int SPL = CHUNK / 64;   // samples per lane
 constexpr int CAPW = 512;         // points staged per wave
-constexpr int MAXLEAF = 384;      // leaves gathered per wave item (6144 points before filtering)
-constexpr int MAXFRONT = 128;     // inner nodes per level of the gather
+constexpr int MAXLEAF = 1024;     // leaves gathered per wave item (16 K points before filtering)
+constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 

@@ -12,6 +12,7 @@ namespace flooder {
 constexpr uint32_t INF_BITS = 0x7f800000u;
 
 extern int g_bvh_ks;
+extern int g_bvh_subs;
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

@@ -459,6 +459,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_ks = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "bvh_subs") == 0 && value >= 1 && value <= 64 && (value & (value - 1)) == 0) {
+    g_bvh_subs = value;
+    return FLOODER_OK;
+  }
   return fail(FLOODER_E_ARG, "flooder_set_option: unknown option or value");
 }
 

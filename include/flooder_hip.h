@@ -140,8 +140,8 @@ int64_t flooder_bvh_node_count(int64_t n_pts);
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream);
 
 /* Sweep: out_d2[s, r] = bits(min over all points of |p(s,r) - x|^2) with p as in flooder_sweep_f32.
- * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or three
- * zeroed uint64 counters {leaves evaluated, leaves tested, inner nodes expanded} (per wave-item). */
+ * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or four
+ * zeroed uint64 counters {leaves evaluated, leaves tested, inner nodes expanded, most tests by one item}. */
 int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                           const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                           int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
