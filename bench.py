@@ -138,6 +138,7 @@ def main():
     P_local = int(cnt0.sum().item())
     del pts_pad0, search0, lo0, hi0, cnt0
     stats = torch.zeros(13, dtype=torch.int64, device=dev)
+    plan = core.SamplePlan(weights, faces)
 
     def step(timer=None):
         """raw (unsorted-for-this-method) shard in HBM -> per-face filtration values in HBM"""
@@ -146,12 +147,12 @@ def main():
             with core._span(timer, "index_total"):
                 index = core.PointIndex(shard_raw, timer)
             stats.zero_()
-            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=stats)
+            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=stats, plan=plan)
         elif args.method == "bvh":
             with core._span(timer, "index_total"):
                 index = core.PointIndex(shard_raw, timer)
             stats.zero_()
-            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats[:4])
+            out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer, stats=stats[:4], plan=plan)
         else:
             with core._span(timer, "index_total"):
                 o = torch.argsort(shard_raw[:, axis])

@@ -31,7 +31,8 @@ SIGNATURES = {
                                   c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_face_max_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p]),
-    "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_bbox_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_bvh_node_count": (c_int64, [c_int64]),
     "flooder_bvh_build_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

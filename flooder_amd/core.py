@@ -387,6 +387,19 @@ def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int,
     return out_face, out_dist
 
 
+def cloud_box(points: torch.Tensor) -> torch.Tensor:
+    """Bounding box of a ROCm point tensor computed on the device: 16 floats, [0:dim] = min,
+    [8:8+dim] = max (one pass over the cloud; torch's column min/max takes ~1 ms per million points)."""
+    lib = _native.load()
+    pts32 = points.detach().to(torch.float32).contiguous()
+    n, dim = pts32.shape
+    box = torch.empty(16, dtype=torch.float32, device=pts32.device)
+    partial = torch.empty(1024 * 16, dtype=torch.float32, device=pts32.device)
+    _native.check(lib.flooder_bbox_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(box), _native.ptr(partial),
+                                       _native.current_stream_ptr(pts32.device)), "flooder_bbox_f32")
+    return box
+
+
 class PointIndex:
     """Morton-sorted copy of a point set plus its implicit box tree (HBM resident).
 
@@ -403,14 +416,10 @@ class PointIndex:
         n, dim = pts32.shape
         self.n, self.dim = n, dim
         self.dp = lib.flooder_padded_dim(dim)
-        lo = pts32.min(dim=0).values
-        hi = pts32.max(dim=0).values
-        box = torch.stack([lo, hi]).cpu().numpy().astype(np.float32)  # host arrays for the C call
-        self.box_lo, self.box_hi = np.ascontiguousarray(box[0]), np.ascontiguousarray(box[1])
+        self.box = cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
         codes = torch.empty(n, dtype=torch.int64, device=dev)
         with _span(timer, "morton"):
-            _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim,
-                                                 self.box_lo.ctypes.data, self.box_hi.ctypes.data,
+            _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
                                                  _native.ptr(codes), st), "flooder_morton_f32")
         order = torch.argsort(codes)
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
@@ -443,10 +452,26 @@ def sample_order(weights: torch.Tensor) -> np.ndarray:
     return np.argsort(code, kind="stable")
 
 
+class SamplePlan:
+    """Device-resident sample weights in sweep order plus the face table remapped to that order
+    (built once per dimension pass; independent of the simplices)."""
+
+    def __init__(self, weights: torch.Tensor, faces: _FaceTable):
+        dev = weights.device
+        self.R, self.k1 = weights.shape
+        perm = sample_order(weights)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(self.R)
+        self.inv = torch.as_tensor(inv, device=dev)
+        self.w_perm = weights.to(torch.float32)[torch.as_tensor(perm, device=dev)].contiguous()
+        self.rows_perm = self.inv[faces.rows.long()].to(torch.int32).contiguous()
+        self.faces = faces
+
+
 def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                          reduce_hook: Optional[Callable[[torch.Tensor], None]],
                          want_dist: bool = False, timer: Optional[_KernelTimer] = None,
-                         stats: Optional[torch.Tensor] = None):
+                         stats: Optional[torch.Tensor] = None, plan: Optional["SamplePlan"] = None):
     """All simplices of one dimension against an indexed point set -> (S, F) face maxima.
 
     sweep_bvh (plain stores into d2 bits, samples in Morton order of their weights) ->
@@ -459,12 +484,8 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     S, k1, _ = verts.shape
     R = weights.shape[0]
     verts = verts.to(torch.float32).contiguous()
-    perm = sample_order(weights)
-    inv = np.empty_like(perm)
-    inv[perm] = np.arange(R)
-    perm_t = torch.as_tensor(perm, device=dev)
-    w_perm = weights.to(torch.float32)[perm_t].contiguous()
-    rows_perm = torch.as_tensor(inv, device=dev)[faces.rows.long()].to(torch.int32).contiguous()
+    plan = plan if plan is not None else SamplePlan(weights, faces)
+    w_perm, rows_perm = plan.w_perm, plan.rows_perm
 
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     queue = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -484,7 +505,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
                                                _native.ptr(out_face), _native.ptr(out_dist), st),
                       "flooder_face_max_f32")
     if out_dist is not None:
-        out_dist = out_dist[:, torch.as_tensor(inv, device=dev)]  # back to the caller's sample order
+        out_dist = out_dist[:, plan.inv]  # back to the caller's sample order
     return out_face, out_dist
 
 
@@ -494,7 +515,7 @@ CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spac
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                           reduce_hook: Optional[Callable[[torch.Tensor], None]],
                           want_dist: bool = False, timer: Optional[_KernelTimer] = None,
-                          stats: Optional[torch.Tensor] = None):
+                          stats: Optional[torch.Tensor] = None, plan: Optional[SamplePlan] = None):
     """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree sweep of the unverified
     tiles -> [reduce_hook] -> face max.  No host synchronisation.
 
@@ -508,11 +529,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     S, k1, _ = verts.shape
     R = weights.shape[0]
     verts = verts.to(torch.float32).contiguous()
-    perm = sample_order(weights)
-    inv = np.empty_like(perm)
-    inv[perm] = np.arange(R)
-    w_perm = weights.to(torch.float32)[torch.as_tensor(perm, device=dev)].contiguous()
-    rows_perm = torch.as_tensor(inv, device=dev)[faces.rows.long()].to(torch.int32).contiguous()
+    plan = plan if plan is not None else SamplePlan(weights, faces)
+    w_perm, rows_perm = plan.w_perm, plan.rows_perm
 
     def sub(a, b):
         return None if stats is None else stats[a:b]
@@ -546,7 +564,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                                                _native.ptr(out_face), _native.ptr(out_dist), st),
                       "flooder_face_max_f32")
     if out_dist is not None:
-        out_dist = out_dist[:, torch.as_tensor(inv, device=dev)]
+        out_dist = out_dist[:, plan.inv]
     return out_face, out_dist
 
 
@@ -647,10 +665,13 @@ def flood_complex(
     LAST_STATS.n_points = points.shape[0]
 
     # sort the cloud along its widest axis (core.py:140-144)
-    if sort_axis is None:
-        axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
-    else:
+    if sort_axis is not None:
         axis = int(sort_axis)
+    elif on_gpu:
+        box = cloud_box(points).cpu()
+        axis = int(torch.argmax(box[8:8 + dim] - box[:dim]).item())
+    else:
+        axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
     if on_gpu:
         pts32 = points.to(torch.float32)
         order = torch.argsort(pts32[:, axis])

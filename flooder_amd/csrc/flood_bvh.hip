@@ -39,10 +39,68 @@ struct Box {
   float scale[FLOODER_MAX_DIM];
 };
 
+// ------------------------------------------------------------------------------------ bounding box
+// Stage 1: per-block partial (lo[8], hi[8]); stage 2: one block folds the partials into box[0:dim] = lo,
+// box[8:8+dim] = hi.  No atomics, no host round trip.
+template <int DIM>
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restrict__ pts, int64_t n, int ld,
+                                                           float* __restrict__ partial) {
+  float lo[DIM], hi[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const float v = pts[j * ld + k];
+      lo[k] = __builtin_fminf(lo[k], v);
+      hi[k] = __builtin_fmaxf(hi[k], v);
+    }
+  }
+  __shared__ float s_lo[4][DIM], s_hi[4][DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const float a = wave_min_f32(lo[k]);
+    const float b = wave_max_f32(hi[k]);
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][k] = a; s_hi[threadIdx.x >> 6][k] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < DIM) {
+    const int k = threadIdx.x;
+    float a = s_lo[0][k], b = s_hi[0][k];
+    for (int w = 1; w < 4; ++w) { a = __builtin_fminf(a, s_lo[w][k]); b = __builtin_fmaxf(b, s_hi[w][k]); }
+    partial[blockIdx.x * 16 + k] = a;
+    partial[blockIdx.x * 16 + 8 + k] = b;
+  }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void bbox_final_kernel(const float* __restrict__ partial, int n_partial,
+                                                        float* __restrict__ box) {
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    float a = __builtin_inff(), b = -__builtin_inff();
+    for (int i = threadIdx.x; i < n_partial; i += 64) {
+      a = __builtin_fminf(a, partial[i * 16 + k]);
+      b = __builtin_fmaxf(b, partial[i * 16 + 8 + k]);
+    }
+    a = wave_min_f32(a);
+    b = wave_max_f32(b);
+    if (threadIdx.x == 0) { box[k] = a; box[8 + k] = b; }
+  }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
-                                                     Box box, int64_t* __restrict__ codes) {
+                                                     const float* __restrict__ dbox, int64_t* __restrict__ codes) {
   constexpr int BITS = 63 / DIM > 21 ? 21 : 63 / DIM;
+  Box box;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const float ext = dbox[8 + k] - dbox[k];
+    box.lo[k] = dbox[k];
+    box.scale[k] = ext > 0.f ? (float)((1u << BITS) - 1u) / ext : 0.f;
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
     uint32_t q[DIM];
@@ -303,11 +361,23 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 // ------------------------------------------------------------------------------------ host ops
 template <int DIM>
 struct MortonOp {
-  static int run(const float* pts, int64_t n, int ld, const Box& box, int64_t* codes, hipStream_t st) {
+  static int run(const float* pts, int64_t n, int ld, const float* box, int64_t* codes, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes);
     return check_launch("morton");
+  }
+};
+
+template <int DIM>
+struct BboxOp {
+  static int run(const float* pts, int64_t n, int ld, float* box, float* partial, hipStream_t st) {
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > FLOODER_BBOX_BLOCKS) blocks = FLOODER_BBOX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((bbox_partial_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, partial);
+    hipLaunchKernelGGL((bbox_final_kernel<DIM>), dim3(1), dim3(64), 0, st, partial, (int)blocks, box);
+    return check_launch("bbox");
   }
 };
 
@@ -377,22 +447,18 @@ int64_t flooder_bvh_node_count(int64_t n_pts) {
   return total_nodes(lv);
 }
 
-int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box_lo,
-                       const float* box_hi, int64_t* codes, void* stream) {
+int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* box, float* partial,
+                     void* stream) {
+  if (!pts || !box || !partial || n_pts < 1 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
+    return fail(FLOODER_E_ARG, "flooder_bbox_f32: bad argument");
+  return dispatch_dim<BboxOp>(dim, pts, n_pts, ld, box, partial, (hipStream_t)stream);
+}
+
+int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
+                       void* stream) {
   if (n_pts == 0) return FLOODER_OK;
-  if (!pts || !box_lo || !box_hi || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
+  if (!pts || !box || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
     return fail(FLOODER_E_ARG, "flooder_morton_f32: bad argument");
-  Box box;
-  const int bits = 63 / dim > 21 ? 21 : 63 / dim;
-  for (int k = 0; k < FLOODER_MAX_DIM; ++k) {
-    box.lo[k] = 0.f;
-    box.scale[k] = 0.f;
-  }
-  for (int k = 0; k < dim; ++k) {
-    const float ext = box_hi[k] - box_lo[k];
-    box.lo[k] = box_lo[k];
-    box.scale[k] = ext > 0.f ? (float)((1u << bits) - 1u) / ext : 0.f;
-  }
   return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, (hipStream_t)stream);
 }
 

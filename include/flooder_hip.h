@@ -41,6 +41,7 @@ extern "C" {
 #define FLOODER_BVH_LEAF 16      /* points per leaf of the point hierarchy            */
 #define FLOODER_BVH_FANOUT 64    /* children per inner node (one per lane)            */
 #define FLOODER_BVH_MAX_LEVELS 6 /* 16 * 64^5 points                                  */
+#define FLOODER_BBOX_BLOCKS 1024  /* partial results of flooder_bbox_f32               */
 
 int flooder_abi_version(void);
 const char* flooder_last_error(void);
@@ -126,10 +127,15 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
  * reference's CPU branch returns, core.py:197-199), with the same direct-difference arithmetic.
  */
 
-/* 64-bit Morton codes of the points inside the box [box_lo, box_hi] (HOST arrays of `dim` floats);
+/* Bounding box of the cloud, on the device: box[0:dim] = min, box[8:8+dim] = max (box: 16 floats;
+ * partial: FLOODER_BBOX_BLOCKS * 16 floats of scratch).  Replaces points.max(dim=0) - points.min(dim=0)
+ * of core.py:140-142 without a host round trip. */
+int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* box, float* partial, void* stream);
+
+/* 64-bit Morton codes of the points relative to `box` (DEVICE, layout of flooder_bbox_f32);
  * floor(63/dim) (max 21) bits per axis.  The caller sorts the cloud by these codes. */
-int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box_lo,
-                       const float* box_hi, int64_t* codes, void* stream);
+int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
+                       void* stream);
 
 /* Number of nodes (all levels, each padded to a multiple of 64) of the tree over n_pts points. */
 int64_t flooder_bvh_node_count(int64_t n_pts);
