@@ -11,8 +11,9 @@ across ranks] -> per-face maxima), inputs resident in HBM when the timed region 
 Delaunay and the Python dict / SimplexTree hand-off are outside the step.
 
 value = N_points x S_top / t_step / 1e6  [M points x simplices / s], whole job over all ranks.
-With N ranks the cloud is sharded (interleaved rows of the sorted cloud), total work fixed:
-"scaling": "strong".
+With N ranks the simplices are interleaved over the ranks (every rank holds the whole cloud) and the per-face
+values are combined with one RCCL all_reduce(MIN); --shard points shards the cloud instead.  Total work is
+fixed: "scaling": "strong".
 """
 
 from __future__ import annotations
@@ -71,6 +72,9 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
     ap.add_argument("--bvh-ks", type=int, default=None, help="samples per lane of the culled sweep (1,2,4,8)")
     ap.add_argument("--bvh-subs", type=int, default=None, help="waves per flagged tile in the exact finish")
+    ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
+                    help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
+                         "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
@@ -85,11 +89,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # (test rigs may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FLOODER_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import flooder_amd as fa
     from flooder_amd import _native, core
@@ -118,11 +127,21 @@ def main():
     verts, centers, radii, simp = verts[order_s], centers[order_s], radii[order_s], simp[order_s]
     weights, vertex_idxs, face_idxs = core.generate_grid(w["ppe"], d, dev, torch.float32)
     faces = core._FaceTable(face_idxs, weights.shape[0], dev)
-    order_p = torch.argsort(pts_full[:, axis])
-    shard_raw = pts_full[order_p][rank::world].contiguous()  # this rank's interleaved share (raw rows)
+    S_all = verts.shape[0]
+    if world > 1 and args.shard == "points":
+        order_p = torch.argsort(pts_full[:, axis])
+        shard_raw = pts_full[order_p][rank::world].contiguous()  # this rank's interleaved share (raw rows)
+        mine = None
+        hook = min_reduce_hook()
+    else:
+        shard_raw = pts_full.contiguous()                          # whole cloud on every rank
+        mine = torch.arange(rank, S_all, world, device=dev) if world > 1 else None
+        hook = None
+    face_hook = min_reduce_hook() if (world > 1 and mine is not None) else None
+    if mine is not None:
+        verts, centers, radii = verts[mine].contiguous(), centers[mine].contiguous(), radii[mine].contiguous()
     dp = lib.flooder_padded_dim(w["dim"])
     del pts_full
-    hook = min_reduce_hook() if world > 1 else None
     S, R = verts.shape[0], weights.shape[0]
 
     # reference-defined work of this input (untimed): candidate pairs P = sum_s |X n ball_s|
@@ -160,6 +179,12 @@ def main():
                 search = pts_pad[:, axis].contiguous()
             out, _ = core._sweep_dimension_hip(pts_pad, search, axis, w["dim"], verts, centers, radii, weights,
                                                faces, hook, timer=timer)
+        if mine is not None:  # simplex sharding: every rank ends with all (S_all, F) values
+            full = torch.full((S_all, out.shape[1]), float("inf"), dtype=out.dtype, device=dev)
+            full[mine] = out
+            with core._span(timer, "reduce"):
+                face_hook(full)
+            out = full
         return out
 
     def sync_all():
@@ -182,7 +207,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = w["n"] * S / (elapsed / args.steps) / 1e6
+    value = w["n"] * S_all / (elapsed / args.steps) / 1e6
 
     # ------------------------------------------------------------------ per-kernel numbers
     k_ms = timer.totals_ms()
@@ -228,9 +253,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S,
+            "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S_all,
+            "top_simplices_rank0": S,
             "samples_per_simplex": R, "candidate_pairs_rank0": P_local, "pair_evals_rank0": pair_evals,
-            "ball_tests_rank0": slab_local, "parallelism": f"point-shard x{world}" if world > 1 else "single GPU",
+            "ball_tests_rank0": slab_local, "parallelism": (f"{args.shard}-shard x{world}" if world > 1 else "single GPU"),
             "method": args.method, "pair_evals_done_rank0": done_evals,
             "sweep_stats_rank0": st_h,
         },
@@ -251,15 +277,15 @@ def main():
         from oracle import flood_oracle as fo
 
         cb = fo.kdtree_sweep_sample(pts_cpu.numpy(), lms.cpu().numpy(), simp.cpu().numpy(), w["ppe"], d,
-                                    n_sample=min(args.cpu_sample, S), seed=0, workers=1)
+                                    n_sample=min(args.cpu_sample, S_all), seed=0, workers=1)
         got = out.cpu().numpy()[cb["picked"]]
         ref = cb["face_max"]
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6 * float(pts_cpu.abs().max()))
-        cpu_value = w["n"] * cb["n_sample"] / (cb["query_s"] + cb["build_s"] * cb["n_sample"] / S) / 1e6
+        cpu_value = w["n"] * cb["n_sample"] / (cb["query_s"] + cb["build_s"] * cb["n_sample"] / S_all) / 1e6
         result["cpu_baseline"] = {
             "value": round(cpu_value, 4), "unit": "M points×simplices/s", "cores": 1, "kind": "port",
             "sample": f"oracle kd-tree sweep (scipy KDTree.query, workers=1, as reference core.py:197-199) of "
-                      f"{cb['n_sample']} of {S} tetrahedra x {R} samples; tree build {cb['build_s']:.2f}s "
+                      f"{cb['n_sample']} of {S_all} tetrahedra x {R} samples; tree build {cb['build_s']:.2f}s "
                       f"(charged pro rata), query {cb['query_s']:.2f}s; host has {os.cpu_count()} cores",
         }
         result["parity"] = {"checked_simplices": int(cb["n_sample"]), "values": int(got.size),

@@ -593,6 +593,8 @@ def flood_complex(
     reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
     sort_axis: Optional[int] = None,
     method: Optional[str] = None,
+    simplex_shard: Optional[Tuple[int, int]] = None,
+    face_reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -711,22 +713,36 @@ def flood_complex(
         LAST_STATS.top_simplices = num_simplices
         LAST_STATS.samples_per_simplex = weights.shape[0]
 
+        if simplex_shard is not None:
+            sh_rank, sh_world = simplex_shard
+            mine = torch.arange(sh_rank, num_simplices, sh_world, device=device)
+        else:
+            mine = None
+        sv = simplex_vertices if mine is None else simplex_vertices[mine]
         if on_gpu:
             if method == "ball":
-                face_vals, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, simplex_vertices, centers,
-                                                    radii, weights, faces, reduce_hook)
+                face_dev, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, sv,
+                                                   centers if mine is None else centers[mine],
+                                                   radii if mine is None else radii[mine], weights, faces,
+                                                   reduce_hook)
             elif method == "cell":
-                face_vals, _ = _sweep_dimension_cell(index, simplex_vertices, weights, faces, reduce_hook)
+                face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook)
             else:
-                face_vals, _ = _sweep_dimension_bvh(index, simplex_vertices, weights, faces, reduce_hook)
-            face_vals = face_vals.cpu().numpy().astype(np.float64)
+                face_dev, _ = _sweep_dimension_bvh(index, sv, weights, faces, reduce_hook)
         else:
-            samples = weights.unsqueeze(0) @ simplex_vertices
+            samples = weights.unsqueeze(0) @ sv
             dist, _ = kdtree.query(np.asarray(samples))
             dist = torch.as_tensor(dist)
             if reduce_hook is not None:
                 reduce_hook(dist)
-            face_vals = _face_max_cpu(dist, faces).numpy().astype(np.float64)
+            face_dev = _face_max_cpu(dist, faces)
+        if mine is not None:
+            full = torch.full((num_simplices, faces.n_faces), float("inf"), dtype=face_dev.dtype, device=device)
+            full[mine] = face_dev
+            if face_reduce_hook is not None:
+                face_reduce_hook(full)
+            face_dev = full
+        face_vals = face_dev.cpu().numpy().astype(np.float64)
 
         simp_h = d_simplices.cpu().numpy()
         if num_rand is None:

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,16 +35,20 @@ def _worker(rank, world, port, name, out_dir):
         pts = torch.as_tensor(z["points"])
         lms = torch.as_tensor(z["landmarks"])
         torch.manual_seed(int(z["weight_seed"]))
-        fc = flood_complex_sharded(shard_points(pts, rank, world), lms, **kw)
+        if mode == "points":
+            fc = flood_complex_sharded(shard_points(pts, rank, world), lms, mode="points", **kw)
+        else:
+            fc = flood_complex_sharded(pts, lms, mode="simplices", **kw)
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([fc[k] for k in keys]))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["simplices", "points"])
 @pytest.mark.parametrize("name", ["torus3d_grid", "eight2d_rand"])
-def test_two_rank_gloo_matches_unsharded(name, tmp_path):
+def test_two_rank_gloo_matches_unsharded(name, mode, tmp_path):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path), mode), nprocs=2, join=True)
     z, kw, keys = load_e2e(name)
     r0 = np.load(tmp_path / "r0.npy")
     r1 = np.load(tmp_path / "r1.npy")

@@ -212,6 +212,24 @@ def test_shard_min_reduce_equals_unsharded(dev):
     assert out == full
 
 
+def test_simplex_shards_min_reduce_equals_unsharded(dev):
+    """Simplex sharding on one GPU: ranks 0..2 of 3 each sweep every third simplex; the element-wise MIN
+    of their (S, F) face buffers is the unsharded result, bit for bit."""
+    pts = fo.noisy_torus(60_000, seed=11)
+    lms = pts[fo.exact_fps(pts, 150, 0)]
+    tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
+    full = fa.flood_complex(tp, tl, points_per_edge=10)
+    bufs = []
+    for r in range(3):
+        fa.flood_complex(tp, tl, points_per_edge=10, simplex_shard=(r, 3),
+                         face_reduce_hook=lambda buf, c=bufs: c.append(buf.clone()))
+    merged = torch.minimum(torch.minimum(bufs[0], bufs[1]), bufs[2])
+    assert torch.isfinite(merged).all()
+    out = fa.flood_complex(tp, tl, points_per_edge=10, simplex_shard=(0, 3),
+                           face_reduce_hook=lambda buf: buf.copy_(merged))
+    assert out == full
+
+
 def test_full_size_properties_1m_gaussian(dev):
     """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
     vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""
