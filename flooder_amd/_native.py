@@ -38,7 +38,8 @@ SIGNATURES = {
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                            c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                            c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),

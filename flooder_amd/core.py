@@ -535,7 +535,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     def sub(a, b):
         return None if stats is None else stats[a:b]
 
-    ctl = torch.zeros(4, dtype=torch.int32, device=dev)  # work-queue heads + flag counter
+    ctl = torch.zeros(6, dtype=torch.int32, device=dev)  # work-queue heads + flag counters
 
     # 1. cell sweep
     tiles64 = (R + 63) // 64
@@ -546,12 +546,13 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl[1:].data_ptr(), _native.ptr(d2),
             _native.ptr(flag_list), ctl[2:].data_ptr(), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
-    # 2. exact finish of the flagged tiles, seeded with the minima found so far
+    # 2. exact finish of the flagged tiles, seeded with the minima found so far (tiles are split over
+    #    several waves when the list is short)
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, _native.ptr(flag_list), ctl[2:].data_ptr(), ctl[3:].data_ptr(),
-            _native.ptr(d2), _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
+            _native.ptr(d2), 0, None, None, _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
 
     if reduce_hook is not None:
         with _span(timer, "reduce"):

@@ -183,7 +183,11 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
-    const int32_t* __restrict__ n_list, int seed, int subs) {
+    const int32_t* __restrict__ n_list, int seed, int subs_max, int budget,
+    int32_t* __restrict__ list2, int32_t* __restrict__ count2) {
+  // budget > 0 (work-list mode): a wave abandons a tile after `budget` box tests, stores the minima it has
+  // (valid upper bounds) and appends the tile to list2; a second pass finishes those tiles split over
+  // many more waves.  Bounds the tail caused by tiles near the medial axis of the cloud.
   // subs > 1 (work-list mode, KSV = 1): a tile of 64 samples is split over `subs` waves, each wave
   // carrying 64/subs distinct samples (replicated across its lanes) - tight boxes for the hard tiles.
   constexpr int DP = padded_dim(DIM);
@@ -192,8 +196,16 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tiles = (R + 64 * KSV - 1) / (64 * KSV);
+  // few flagged tiles: split each over up to subs_max waves (short tail); many: keep lanes distinct
+  int subs = 1;
+  if (item_list) {
+    subs = subs_max;
+    while (subs > 1 && (int64_t)n_list[0] * subs > 32768) subs >>= 1;
+  }
   const int64_t n_items = item_list ? (int64_t)n_list[0] * subs : n_simplices * tiles;
   const int per_sub = 64 / subs;
+  // budgeted pass over a SHORT list: hand every tile straight to the split pass (the GPU would idle)
+  if (budget > 0 && n_list[0] <= 2048) budget = 1;
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
 
@@ -251,10 +263,13 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
       M = wave_max_f32(bm);
     }
 
-    // lower bound between the tile box and child `lane` of group `grp` at level `lvl`
-    auto child_bounds = [&](int lvl, int64_t grp) {
+    // child `lane` of group `grp` at level `lvl`: its box (registers) and the lower bound to the tile box
+    float c_lo[DIM], c_hi[DIM];
+    auto child_bounds = [&](int lvl, int64_t grp) -> float {
       const int64_t idx = grp * FAN + lane;
       float lb = __builtin_inff();
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) { c_lo[k] = __builtin_inff(); c_hi[k] = -__builtin_inff(); }
       if (idx < lv.count[lvl]) {
         float lo[DP], hi[DP];
         const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
@@ -263,39 +278,70 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         lb = 0.f;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
+          c_lo[k] = lo[k];
+          c_hi[k] = hi[k];
           const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
           lb = __builtin_fmaf(gap, gap, lb);
         }
       }
-      s_lb[wv][lvl][lane] = lb;
-      if (lane == 0) s_grp[wv][lvl] = grp;
+      return lb;
     };
 
+    // Inner levels keep their per-lane bounds in LDS (touched once per node expansion); the leaf level
+    // runs entirely in registers: bound in lb0, the 64 leaf boxes in c_lo/c_hi, read back by readlane.
     int lvl = top;
-    child_bounds(top, 0);
+    float lb0 = child_bounds(top, 0);
+    int64_t grp0 = 0;
     ++n_node_test;
+    if (top > 0) {
+      s_lb[wv][top][lane] = lb0;
+      if (lane == 0) s_grp[wv][top] = 0;
+    }
+    bool abandoned = false;
     for (;;) {
-      const float lbv = s_lb[wv][lvl][lane];
-      const float mn = wave_min_f32(lbv);
-      if (!(mn * SAFE < M)) {  // nothing left at this level can improve any sample of the tile
+      if (budget > 0 && (int)(n_leaf_test + n_node_test - tests_before) >= budget) {
+        abandoned = true;
+        break;
+      }
+      if (lvl > 0) {
+        const float lbv = s_lb[wv][lvl][lane];
+        const float mn = wave_min_f32(lbv);
+        if (!(mn * SAFE < M)) {  // nothing left at this level can improve any sample of the tile
+          if (++lvl > top) break;
+          continue;
+        }
+        const int j = __builtin_ctzll(__ballot(lbv == mn));
+        if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
+        const int64_t c = s_grp[wv][lvl] * FAN + j;
+        --lvl;
+        const float lb = child_bounds(lvl, c);
+        ++n_node_test;
+        if (lvl > 0) {
+          s_lb[wv][lvl][lane] = lb;
+          if (lane == 0) s_grp[wv][lvl] = c;
+        } else {
+          lb0 = lb;
+          grp0 = c;
+        }
+        continue;
+      }
+      // ---- leaf level: nearest unvisited leaf of the current group
+      const float mn = wave_min_f32(lb0);
+      if (!(mn * SAFE < M)) {
         if (++lvl > top) break;
         continue;
       }
-      const unsigned long long eq = __ballot(lbv == mn);
-      const int j = __builtin_ctzll(eq);
-      if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
-      const int64_t c = s_grp[wv][lvl] * FAN + j;
-      if (lvl > 0) {
-        --lvl;
-        child_bounds(lvl, c);
-        ++n_node_test;
-        continue;
-      }
-      // ---- leaf c: can any sample of any lane still improve?
+      const int j = __builtin_ctzll(__ballot(lb0 == mn));
+      if (lane == j) lb0 = __builtin_inff();  // visited
+      const int64_t c = grp0 * FAN + j;
       ++n_leaf_test;
-      const float* lb_ptr = nodes + (lv.off[0] + c) * 2 * DP;
-      const typename RowVec<DP>::type blo = load_uniform_row<DP>(lb_ptr);
-      const typename RowVec<DP>::type bhi = load_uniform_row<DP>(lb_ptr + DP);
+      // can any sample of any lane still improve against leaf c?  (its box comes from lane j)
+      float blo[DIM], bhi[DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        blo[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
+        bhi[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
+      }
       bool need = false;
 #pragma unroll
       for (int i = 0; i < KSV; ++i) {
@@ -346,6 +392,10 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     for (int i = 0; i < KSV; ++i) {
       const int r = tile * 64 * KSV + i * 64 + slane;
       if (r < R && lane < per_sub) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
+    }
+    if (abandoned && sub == 0 && lane == 0) {  // (budgeted passes run with subs = 1)
+      const int pos = atomicAdd(count2, 1);
+      list2[pos] = (int)g;
     }
     const unsigned long long item_tests = n_leaf_test + n_node_test - tests_before;
     max_item_tests = item_tests > max_item_tests ? item_tests : max_item_tests;
@@ -402,22 +452,22 @@ struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
                  unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
-                 int force_ks, int subs, hipStream_t st) {
+                 int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, hipStream_t st) {
     const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : (R <= 128 ? 2 : (R <= 256 ? 4 : 8));
     if (ks == 1)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
     else if (ks == 2)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
     else if (ks == 4)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
     else
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
     return check_launch("sweep_bvh");
   }
 };
@@ -478,21 +528,25 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0, 1,
-                                  (hipStream_t)stream);
+                                  0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                 const float* verts, const float* weights, int k1, int R,
                                 int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
-                                int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream) {
+                                int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
+                                int32_t* count2, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !item_list || !n_items ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0)
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || budget < 0 ||
+      (budget > 0 && (!list2 || !count2)))
     return fail(FLOODER_E_ARG, "flooder_sweep_bvh_items_f32: bad argument");
   const Levels lv = make_levels(n_pts);
+  // a budgeted pass keeps 64 distinct samples per wave; the unbudgeted pass may split tiles
+  const int subs = budget > 0 ? 1 : g_bvh_subs;
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), item_list, n_items, 1,
-                                  1, g_bvh_subs, (hipStream_t)stream);
+                                  1, subs, budget, list2, count2, (hipStream_t)stream);
 }
 
 int flooder_selftest(const float* in64, float* out128, void* stream) {

@@ -154,11 +154,15 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
 
 /* Same sweep restricted to an explicit work list and SEEDED with the minima already in out_d2 (upper
  * bounds from an earlier pass): item_list[i] = simplex * ceil(R/64) + tile, tiles are 64 consecutive
- * samples; *n_items (device int32) entries.  Finishes what flooder_sweep_cell_f32 could not verify. */
+ * samples; *n_items (device int32) entries.  Finishes what flooder_sweep_cell_f32 could not verify.
+ * budget > 0: a wave abandons a tile after that many box tests, stores its current minima and appends the
+ * tile to list2 / *count2 (zeroed by the caller) - call again on list2 with budget 0, where each tile is
+ * split over up to 64 waves (tiles near the medial axis of the cloud have huge candidate sets). */
 int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                 const float* verts, const float* weights, int k1, int R,
                                 int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
-                                int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
+                                int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
+                                int32_t* count2, uint64_t* stats, void* stream);
 
 /*
  * Cell sweep (dim 2 and 3; the default device path there).  One wave per chunk of 256 consecutive
