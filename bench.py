@@ -116,7 +116,12 @@ def main():
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
     pts_full = pts_cpu.to(dev)
+    fa.generate_landmarks(pts_full, 8, start_idx=0)  # warm-up
+    torch.cuda.synchronize()
+    t_fps0 = time.perf_counter()
     lms = fa.generate_landmarks(pts_full, w["n_lms"], start_idx=0)
+    torch.cuda.synchronize()
+    t_fps = time.perf_counter() - t_fps0
     stree, simplices = core._build_complex(lms, w["dim"])
     d = w["dim"]
     simp = torch.as_tensor(simplices[d], device=dev)
@@ -270,6 +275,12 @@ def main():
                      "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flop_per_pair": 10},
         },
         "kernels_ms_per_step": {k: round(v / args.steps, 4) for k, v in k_ms.items()},
+        # landmark selection (generate_landmarks, outside the step): one distance-update + arg-max sweep of
+        # the cloud per landmark; algorithmic bytes = (4*dim + 8) B per point and iteration
+        "fps": {"points": w["n"], "landmarks": w["n_lms"], "ms": round(t_fps * 1e3, 3),
+                "us_per_landmark": round(t_fps / w["n_lms"] * 1e6, 3),
+                "algorithmic_GBs": round((4 * w["dim"] + 8) * w["n"] * w["n_lms"] / t_fps / 1e9, 1),
+                "hbm_peak_GBs": HBM_PEAK_GBS},
     }
 
     # ------------------------------------------------------------------ CPU baseline + parity (rank 0, N=1)

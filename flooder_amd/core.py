@@ -137,8 +137,8 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0) -> torch.T
         pts = points.detach().to(torch.float32).contiguous()
         n = pts.shape[0]
         out_idx = torch.empty(n_lms, dtype=torch.int64, device=pts.device)
-        work_min = torch.empty(n, dtype=torch.float32, device=pts.device)
-        work_best = torch.zeros(n_lms, dtype=torch.int64, device=pts.device)
+        work_min = torch.empty(4 * n, dtype=torch.float32, device=pts.device)
+        work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
         with torch.cuda.device(pts.device):
             st = _native.current_stream_ptr(pts.device)
             _native.check(lib.flooder_fps_f32(_native.ptr(pts), n, dim, dim, n_lms, int(start_idx),

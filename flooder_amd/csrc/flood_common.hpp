@@ -87,6 +87,22 @@ __device__ __forceinline__ float wave_max_f32(float x) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_move_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+  uint32_t t;
+  t = dpp_move_u32<0xB1, 0xF>(x); x = t < x ? t : x;
+  t = dpp_move_u32<0x4E, 0xF>(x); x = t < x ? t : x;
+  t = dpp_move_u32<0x141, 0xF>(x); x = t < x ? t : x;
+  t = dpp_move_u32<0x140, 0xF>(x); x = t < x ? t : x;
+  t = dpp_move_u32<0x142, 0xA>(x); x = t < x ? t : x;
+  t = dpp_move_u32<0x143, 0xC>(x); x = t < x ? t : x;
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 template <template <int> class F, typename... Args>
 int dispatch_dim(int dim, Args&&... args) {
   switch (dim) {

@@ -370,6 +370,95 @@ __global__ __launch_bounds__(256) void fps_step_kernel(const float* __restrict__
   }
 }
 
+// Fast path for dim <= 3: rows (x, y, z, running min d^2) are one 16-byte load, the running minimum one
+// 4-byte store; 4 rows per thread, all loads issued before any use; the block owns a fixed 1024-row
+// slice, so across the launches of one FPS run every XCD keeps re-reading the same ~2.5 MB from its L2.
+template <int DIM>
+__global__ __launch_bounds__(256) void fps_rows_init_kernel(const float* __restrict__ pts, int64_t n, int ld,
+                                                            float4* __restrict__ rows) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    float4 r;
+    r.x = pts[j * ld];
+    r.y = DIM > 1 ? pts[j * ld + (DIM > 1 ? 1 : 0)] : 0.f;
+    r.z = DIM > 2 ? pts[j * ld + (DIM > 2 ? 2 : 0)] : 0.f;
+    r.w = __builtin_inff();
+    rows[j] = r;
+  }
+}
+
+constexpr int FPS_SLOTS = 64;  // arg-max slots per iteration (same-address atomics serialise at ~13 ns each)
+
+// winner of iteration `it`: reduce its FPS_SLOTS slots (every wave does this redundantly, one slot per lane)
+__device__ __forceinline__ uint32_t fps_winner(const unsigned long long* __restrict__ best, int it) {
+  const unsigned long long k = best[(int64_t)it * FPS_SLOTS + (threadIdx.x & 63)];
+  const float m = __uint_as_float((uint32_t)(k >> 32));       // d^2 >= 0 (or 0 for an empty slot)
+  const uint32_t lowinv = (uint32_t)(k & 0xffffffffu);        // 0xffffffff - index (0 for an empty slot)
+  const float wm = wave_max_f32(m);
+  const uint32_t idx = wave_min_u32((m == wm && k != 0ull) ? 0xffffffffu - lowinv : 0xffffffffu);
+  return idx;
+}
+
+__global__ __launch_bounds__(256) void fps_fast_kernel(float4* __restrict__ rows, int64_t n, int it,
+                                                       unsigned long long* __restrict__ best,
+                                                       int64_t* __restrict__ out_idx) {
+  const uint32_t q = fps_winner(best, it - 1);
+  const float4 c = rows[q];
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_idx[it - 1] = (int64_t)q;
+  const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  float4 r[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t j = base + u * 256;
+    r[u] = rows[j < n ? j : n - 1];
+  }
+  float bm = -1.f;
+  uint32_t bi = 0xffffffffu;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t j = base + u * 256;
+    if (j < n) {
+      float t = r[u].x - c.x;
+      float d2 = t * t;
+      t = r[u].y - c.y;
+      d2 = __builtin_fmaf(t, t, d2);
+      t = r[u].z - c.z;
+      d2 = __builtin_fmaf(t, t, d2);
+      const float m = d2 < r[u].w ? d2 : r[u].w;
+      if (m < r[u].w) reinterpret_cast<float*>(rows + j)[3] = m;
+      if (m > bm) { bm = m; bi = (uint32_t)j; }  // ascending j: the first maximum keeps the lowest index
+    }
+  }
+  // wave: largest distance, then lowest index among the lanes that hold it
+  const float wm = wave_max_f32(bm);
+  const uint32_t wi = wave_min_u32(bm == wm ? bi : 0xffffffffu);
+  __shared__ float s_m[4];
+  __shared__ uint32_t s_i[4];
+  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = wm; s_i[threadIdx.x >> 6] = wi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = s_m[0];
+    uint32_t i = s_i[0];
+    for (int w = 1; w < 4; ++w)
+      if (s_m[w] > m || (s_m[w] == m && s_i[w] < i)) { m = s_m[w]; i = s_i[w]; }
+    if (m >= 0.f) {
+      const unsigned long long key =
+          ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(0xffffffffu - i);
+      atomicMax(&best[(int64_t)it * FPS_SLOTS + (blockIdx.x % FPS_SLOTS)], key);
+    }
+  }
+}
+
+__global__ void fps_fast_init_kernel(unsigned long long* best, int64_t start) {
+  // iteration 0 "winner" = the start point: a positive distance so that the slot counts as filled
+  best[0] = ((unsigned long long)__float_as_uint(1.0f) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)start);
+}
+
+__global__ void fps_fast_last_kernel(const unsigned long long* best, int n_lms, int64_t* out_idx) {
+  const uint32_t q = fps_winner(best, n_lms - 1);
+  if (threadIdx.x == 0) out_idx[n_lms - 1] = (int64_t)q;
+}
+
 __global__ void fps_init_kernel(unsigned long long* best, int64_t start) {
   best[0] = (unsigned long long)(0xffffffffu - (uint32_t)start);
 }
@@ -427,16 +516,32 @@ struct SweepOp {
 
 template <int DIM>
 struct FpsOp {
-  static int run(const float* pts, int64_t n, int ld, int n_lms, float* mind,
+  static int run(const float* pts, int64_t n, int ld, int n_lms, int64_t start, float* mind,
                  unsigned long long* best, int64_t* out_idx, hipStream_t st) {
-    int64_t blocks = (n + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    for (int it = 1; it < n_lms; ++it) {
-      hipLaunchKernelGGL((fps_step_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, it,
-                         mind, best, out_idx);
+    if constexpr (DIM <= 3) {
+      // rows = (x, y, z, running min): mind is used as the 4*n float row buffer
+      float4* rows = reinterpret_cast<float4*>(mind);
+      int64_t ib = (n + 255) / 256;
+      if (ib > 4096) ib = 4096;
+      hipLaunchKernelGGL((fps_rows_init_kernel<DIM>), dim3((int)ib), dim3(256), 0, st, pts, n, ld, rows);
+      const int64_t blocks = (n + 1023) / 1024;
+      hipLaunchKernelGGL(fps_fast_init_kernel, dim3(1), dim3(1), 0, st, best, start);
+      for (int it = 1; it < n_lms; ++it)
+        hipLaunchKernelGGL(fps_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, st, rows, n, it, best, out_idx);
+      hipLaunchKernelGGL(fps_fast_last_kernel, dim3(1), dim3(64), 0, st, best, n_lms, out_idx);
+      return check_launch("fps_fast");
+    } else {
+      int64_t blocks = (n + 256 * 4 - 1) / (256 * 4);
+      if (blocks > 2048) blocks = 2048;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(fps_init_kernel, dim3(1), dim3(1), 0, st, best, start);
+      for (int it = 1; it < n_lms; ++it) {
+        hipLaunchKernelGGL((fps_step_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, it,
+                           mind, best, out_idx);
+      }
+      hipLaunchKernelGGL(fps_last_kernel, dim3(1), dim3(1), 0, st, best, n_lms, out_idx);
+      return check_launch("fps_step");
     }
-    return check_launch("fps_step");
   }
 };
 
@@ -537,11 +642,7 @@ int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms,
     return fail(FLOODER_E_ARG, "flooder_fps_f32: bad argument");
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* best = reinterpret_cast<unsigned long long*>(work_best);
-  hipLaunchKernelGGL(fps_init_kernel, dim3(1), dim3(1), 0, st, best, start);
-  int rc = dispatch_dim<FpsOp>(dim, pts, n_pts, ld, n_lms, work_min, best, out_idx, st);
-  if (rc != FLOODER_OK) return rc;
-  hipLaunchKernelGGL(fps_last_kernel, dim3(1), dim3(1), 0, st, best, n_lms, out_idx);
-  return check_launch("fps_last");
+  return dispatch_dim<FpsOp>(dim, pts, n_pts, ld, n_lms, start, work_min, best, out_idx, st);
 }
 
 }  // extern "C"

@@ -192,8 +192,9 @@ int flooder_fill_u32(uint32_t* buf, int64_t n, uint32_t value, void* stream);
  * Farthest-point sampling.  Replaces fpsample.bucket_fps_kdline_sampling as called by
  * generate_landmarks (flooder/core.py:337-343): exact FPS order starting at `start`.
  *   out_idx: n_lms int64 (selection order, out_idx[0] = start);
- *   work_min: n_pts float32 scratch (running squared distance to the selected set);
- *   work_best: n_lms uint64 scratch, zeroed by the caller.
+ *   work_min: 4 * n_pts float32 scratch, 16-byte aligned (rows x, y, z, running squared distance to the
+ *             selected set for dim <= 3; the first n_pts floats otherwise);
+ *   work_best: 64 * n_lms uint64 scratch, zeroed by the caller (64 arg-max slots per iteration).
  */
 int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms, int64_t start,
                     int64_t* out_idx, float* work_min, uint64_t* work_best, void* stream);
