@@ -1,0 +1,149 @@
+"""Persistent homology (Z/2) of a ``flooder_amd.SimplexTree``.
+
+Stand-in for ``gudhi.SimplexTree.compute_persistence`` / ``persistence_intervals_in_dimension`` (gudhi is a
+third-party C++ library; the reference calls it at ``flooder/cli.py:473-476`` and
+``tests/test_flooder.py:55-71``).  The boundary-matrix reduction runs in host C++
+(``csrc/persistence.cpp`` -> ``libflooder_host.so``); a pure-Python reduction of the same algorithm is kept
+for cross-checking (``persistence_pairs_python``).
+
+Conventions follow gudhi: simplices are ordered by (filtration value, dimension, vertices); intervals of
+length <= ``min_persistence`` are dropped (``min_persistence=-1`` keeps everything); homology in the top
+dimension of the complex is only reported with ``persistence_dim_max=True``; unpaired simplices give
+intervals ``(birth, inf)``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+_HOST_LIB = None
+
+
+def _host_lib():
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        from . import build
+
+        path = build.HOST_LIB
+        if not os.path.exists(path):
+            build.build_host()
+        lib = ctypes.CDLL(path)
+        lib.flooder_persistence_z2.restype = ctypes.c_int
+        lib.flooder_persistence_z2.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]
+        _HOST_LIB = lib
+    return _HOST_LIB
+
+
+def filtration_order(st):
+    """Simplices of the tree in filtration order with their boundaries.
+
+    Returns (dims int32 (n,), filt float64 (n,), bptr int64 (n+1,), bidx int64, rows) where ``rows[d]`` is the
+    dimension-d simplex table and the boundary of simplex j (position in filtration order) is
+    ``bidx[bptr[j]:bptr[j+1]]`` (positions in filtration order)."""
+    st._flush()
+    dims_present = sorted(d for d, r in st._rows.items() if r.shape[0])
+    if not dims_present:
+        z = np.zeros(0, dtype=np.int64)
+        return np.zeros(0, np.int32), np.zeros(0), np.zeros(1, np.int64), z, {}
+    top = dims_present[-1]
+    counts = [st._rows[d].shape[0] if d in st._rows else 0 for d in range(top + 1)]
+    offs = np.concatenate([[0], np.cumsum(counts)])  # global id = offs[d] + row index
+    n = int(offs[-1])
+    dims = np.concatenate([np.full(c, d, dtype=np.int32) for d, c in enumerate(counts)])
+    filt = np.concatenate([st._vals[d] if d in st._vals else np.zeros(0) for d in range(top + 1)])
+    filt_key = np.where(np.isnan(filt), np.inf, filt)
+    # (filtration, dimension, lexicographic row order == table order)
+    order = np.lexsort((np.arange(n), dims, filt_key))
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    # boundaries in global ids
+    bcount = np.where(dims > 0, dims + 1, 0).astype(np.int64)
+    bptr_g = np.concatenate([[0], np.cumsum(bcount)])
+    bidx_g = np.empty(int(bptr_g[-1]), dtype=np.int64)
+    for d in range(1, top + 1):
+        rows = st._rows.get(d)
+        if rows is None or rows.shape[0] == 0:
+            continue
+        base = bptr_g[offs[d]]
+        faces = np.empty((rows.shape[0], d + 1), dtype=np.int64)
+        for j in range(d + 1):
+            idx = st._locate(d - 1, np.delete(rows, j, axis=1))
+            if (idx < 0).any():
+                raise ValueError("complex is not closed under taking faces")
+            faces[:, j] = offs[d - 1] + idx
+        bidx_g[base:base + faces.size] = faces.reshape(-1)
+    # permute to filtration order
+    bcount_o = bcount[order]
+    bptr = np.concatenate([[0], np.cumsum(bcount_o)]).astype(np.int64)
+    bidx = np.empty_like(bidx_g)
+    # gather boundaries of the simplices in filtration order
+    starts = bptr_g[order]
+    take = np.concatenate([np.arange(s, s + c) for s, c in zip(starts.tolist(), bcount_o.tolist())]) if n else np.zeros(0, np.int64)
+    bidx = pos[bidx_g[take.astype(np.int64)]] if take.size else np.zeros(0, np.int64)
+    return dims[order].astype(np.int32), filt[order], bptr, bidx.astype(np.int64), order
+
+
+def reduce_pairs(dims: np.ndarray, bptr: np.ndarray, bidx: np.ndarray) -> np.ndarray:
+    lib = _host_lib()
+    n = dims.shape[0]
+    pair = np.empty(n, dtype=np.int64)
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    bptr = np.ascontiguousarray(bptr, dtype=np.int64)
+    bidx = np.ascontiguousarray(bidx, dtype=np.int64)
+    rc = lib.flooder_persistence_z2(n, dims.ctypes.data, bptr.ctypes.data, bidx.ctypes.data, pair.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("flooder_persistence_z2 failed")
+    return pair
+
+
+def reduce_pairs_python(dims: np.ndarray, bptr: np.ndarray, bidx: np.ndarray) -> np.ndarray:
+    """Plain left-to-right column reduction with Python sets (reference for the C++ reduction)."""
+    n = dims.shape[0]
+    pair = np.full(n, -1, dtype=np.int64)
+    low_to_col: Dict[int, int] = {}
+    cols: Dict[int, set] = {}
+    for j in range(n):
+        c = set(bidx[bptr[j]:bptr[j + 1]].tolist())
+        while c:
+            low = max(c)
+            k = low_to_col.get(low)
+            if k is None:
+                break
+            c ^= cols[k]
+        if c:
+            low = max(c)
+            low_to_col[low] = j
+            cols[j] = c
+            pair[low] = j
+            pair[j] = low
+    return pair
+
+
+def intervals_from_pairs(dims, filt, pair, min_persistence=0.0, persistence_dim_max=False) -> Dict[int, np.ndarray]:
+    top = int(dims.max()) if dims.size else -1
+    out: Dict[int, List[Tuple[float, float]]] = {}
+    for j in range(dims.shape[0]):
+        p = pair[j]
+        d = int(dims[j])
+        if p == -1:
+            b, e = float(filt[j]), float("inf")
+        elif p > j:
+            b, e = float(filt[j]), float(filt[p])
+        else:
+            continue
+        if d == top and not persistence_dim_max:
+            continue
+        if e - b > min_persistence:
+            out.setdefault(d, []).append((b, e))
+    return {d: np.array(v, dtype=np.float64).reshape(-1, 2) for d, v in out.items()}
+
+
+def persistence_pairs(st, min_persistence: float = 0.0, persistence_dim_max: bool = False) -> Dict[int, np.ndarray]:
+    dims, filt, bptr, bidx, _ = filtration_order(st)
+    pair = reduce_pairs(dims, bptr, bidx)
+    return intervals_from_pairs(dims, filt, pair, min_persistence, persistence_dim_max)

@@ -230,6 +230,34 @@ def test_simplex_shards_min_reduce_equals_unsharded(dev):
     assert out == full
 
 
+def test_persistence_intervals_match_oracle(dev):
+    """Persistence intervals of the GPU result vs of the oracle's filtration values (same Z/2 reduction):
+    every bar longer than 1e-4 agrees within the filtration tolerance."""
+    from flooder_amd.simplex_tree import SimplexTree
+    pts = fo.noisy_torus(100_000, seed=21)
+    lms = pts[fo.exact_fps(pts, 400, 0)]
+    ref = fo.flood_complex_oracle(pts, lms, points_per_edge=8)
+    st = fa.flood_complex(torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev), points_per_edge=8,
+                          return_simplex_tree=True)
+    by_len = {}
+    for k, v in ref.items():
+        by_len.setdefault(len(k), []).append((k, v))
+    rt = SimplexTree.from_arrays([np.array([k for k, _ in by_len[L]]) for L in sorted(by_len)])
+    for L in sorted(by_len):
+        rt.assign_filtration_bulk(np.array([k for k, _ in by_len[L]]), np.array([v for _, v in by_len[L]]))
+    st.compute_persistence()
+    rt.compute_persistence()
+    for d in range(3):
+        a = st.persistence_intervals_in_dimension(d)
+        b = rt.persistence_intervals_in_dimension(d)
+        a = a[(a[:, 1] - a[:, 0]) > 1e-4]
+        b = b[(b[:, 1] - b[:, 0]) > 1e-4]
+        assert a.shape == b.shape, (d, a.shape, b.shape)
+        assert np.allclose(a, b, rtol=1e-5, atol=2e-6)
+    h1 = st.persistence_intervals_in_dimension(1)
+    assert ((h1[:, 1] - h1[:, 0]) > 0.4).sum() == 2  # the torus' two loops
+
+
 def test_full_size_properties_1m_gaussian(dev):
     """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
     vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""
