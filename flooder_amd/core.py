@@ -770,4 +770,6 @@ def flood_complex(
         torch.cuda.empty_cache()
     if return_simplex_tree:
         return stree
+    if isinstance(stree, SimplexTree):
+        return stree.to_dict()
     return dict((tuple(simplex), filtr) for (simplex, filtr) in stree.get_simplices())

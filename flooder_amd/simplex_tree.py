@@ -50,6 +50,16 @@ def _lex_sort_rows(rows: np.ndarray) -> np.ndarray:
 def _unique_rows(rows: np.ndarray) -> np.ndarray:
     if rows.shape[0] == 0:
         return rows
+    base = int(rows.max()) + 1
+    k = rows.shape[1]
+    if base ** k < 2 ** 62:  # pack each row into one int64 key: a 1-D sort instead of a lexsort
+        mult = base ** np.arange(k - 1, -1, -1, dtype=np.int64)
+        keys = np.unique(rows @ mult)
+        out = np.empty((keys.shape[0], k), dtype=np.int64)
+        for j in range(k - 1, -1, -1):
+            out[:, j] = keys % base
+            keys = keys // base
+        return out
     rows = rows[_lex_sort_rows(rows)]
     keep = np.ones(rows.shape[0], dtype=bool)
     keep[1:] = np.any(rows[1:] != rows[:-1], axis=1)
@@ -278,6 +288,17 @@ class SimplexTree:
         lens_l = lens[order].tolist()
         for row, v, k in zip(rows_l, vals_l, lens_l):
             yield row[:k], v
+
+    def to_dict(self) -> Dict[Tuple[int, ...], float]:
+        """``{simplex tuple: filtration}`` of the whole complex (what ``dict(stree.get_simplices())`` gives,
+        reference core.py:285-288) without a Python-level generator per simplex."""
+        self._flush()
+        out: Dict[Tuple[int, ...], float] = {}
+        for d in sorted(self._rows):
+            rows = self._rows[d]
+            if rows.shape[0]:
+                out.update(zip(map(tuple, rows.tolist()), self._vals[d].tolist()))
+        return out
 
     def get_filtration(self) -> Iterator[Tuple[List[int], float]]:
         """Simplices sorted by (filtration, dimension, lexicographic), gudhi's filtration order."""
