@@ -255,6 +255,15 @@ def main():
         done_evals = pair_evals
     valu_tflops = 10.0 * done_evals / (sweep_ms * 1e-3) / 1e12  # 3d+1 flop per evaluated pair, d = 3
 
+    # measured HBM traffic of the dominant kernel (rocprofv3 PMC passes, tools/collect_profiles.sh ->
+    # profiles/traffic.json; FETCH_SIZE doubled for 16 B/lane loads as MI355X_MICROARCH.md prescribes)
+    traffic = None
+    try:
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}:{args.method}", {}).get("bytes_per_launch")
+    except Exception:
+        traffic = None
     result = {
         "metric": "M points×simplices/s (coverage sweep)",
         "value": round(value, 3),
@@ -280,7 +289,7 @@ def main():
         },
         "roofline": {
             "kernel": {"cell": "cell_sweep_kernel", "bvh": "sweep_bvh_kernel", "ball": "sweep_kernel"}[args.method], "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes": alg_bytes, "avg_launch_ms": round(sweep_ms, 4),
             "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + (S,R) minima "
                     "(SURVEY.md 8d); the kernel itself is fp32-VALU/latency-bound, see valu",
