@@ -633,6 +633,8 @@ def flood_complex(
             "use_triton=True requested, but the HIP kernels are not available in this environment "
             "(build them with `python -m flooder_amd.build`)."
         )
+    if points.dim() != 2 or points.shape[0] == 0:
+        raise RuntimeError(f"points must be a non-empty (N, d) tensor, got shape {tuple(points.shape)}")
     if max_dimension is None:
         max_dimension = points.shape[1]
     if isinstance(landmarks, Integral):

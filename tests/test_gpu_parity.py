@@ -258,6 +258,58 @@ def test_persistence_intervals_match_oracle(dev):
     assert ((h1[:, 1] - h1[:, 0]) > 0.4).sum() == 2  # the torus' two loops
 
 
+def test_edge_cases_gpu(dev):
+    torch.manual_seed(0)
+    # 1-D ambient space
+    x = torch.rand(5000, 1)
+    lms = x[fo.exact_fps(x.numpy(), 20, 0)]
+    fc = fa.flood_complex(x.to(dev), lms.to(dev), points_per_edge=9)
+    ref = fo.flood_complex_oracle(x.numpy(), lms.numpy(), points_per_edge=9)
+    keys = sorted(ref)
+    assert set(fc) == set(keys)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), x.numpy(), "1d")
+    # tiny cloud, fewer points than one leaf; single simplex
+    pts = torch.rand(7, 3)
+    fc = fa.flood_complex(pts.to(dev), pts[:4].clone().to(dev), points_per_edge=4)
+    ref = fo.flood_complex_oracle(pts.numpy(), pts[:4].numpy(), points_per_edge=4)
+    keys = sorted(ref)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), pts.numpy(), "tiny")
+    # duplicated points and a large coordinate offset
+    p = torch.rand(4000, 3) * 0.01 + 500.0
+    p[2000:] = p[:2000]
+    lm = p[fo.exact_fps(p.numpy(), 30, 0)]
+    fc = fa.flood_complex(p.to(dev), lm.to(dev), points_per_edge=5)
+    ref = fo.flood_complex_oracle(p.numpy(), lm.numpy(), points_per_edge=5)
+    keys = sorted(ref)
+    assert_close_filtration(dict_values(fc, keys), dict_values(ref, keys), p.numpy(), "offset+duplicates")
+    with pytest.raises(RuntimeError):
+        fa.flood_complex(torch.zeros((0, 3), device=dev), 4)
+
+
+def test_fuzz_methods_agree(dev):
+    """Random small configurations: cell == bvh == ball bit for bit, and all within tolerance of the oracle."""
+    rng = np.random.default_rng(123)
+    for case in range(12):
+        dim = int(rng.choice([2, 3, 3]))
+        n = int(rng.choice([80, 700, 6000]))
+        pts = rng.normal(size=(n, dim)).astype(np.float32)
+        if case % 3 == 0:
+            pts = (rng.normal(size=(n, dim)) * 0.03 + rng.normal(size=(6, dim))[rng.integers(0, 6, n)]).astype(np.float32)
+        n_l = int(min(n, rng.choice([dim + 2, 25, 90])))
+        lms = pts[fo.exact_fps(pts, n_l, 0)]
+        kw = dict(points_per_edge=int(rng.choice([2, 4, 9]))) if case % 4 else dict(points_per_edge=None, num_rand=150)
+        tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
+        res = {}
+        for m in ("cell", "bvh", "ball"):
+            torch.manual_seed(case)
+            res[m] = fa.flood_complex(tp, tl, method=m, **kw)
+        torch.manual_seed(case)
+        ref = fo.flood_complex_oracle(pts, lms, **kw)
+        assert res["cell"] == res["ball"] and res["bvh"] == res["ball"], f"case {case}"
+        keys = sorted(ref)
+        assert_close_filtration(dict_values(res["cell"], keys), dict_values(ref, keys), pts, f"case {case}")
+
+
 def test_full_size_properties_1m_gaussian(dev):
     """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
     vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""

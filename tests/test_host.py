@@ -140,3 +140,28 @@ def test_rocm_tensor_without_library_fails_loudly(monkeypatch):
         _native.load()
     with pytest.raises(ImportError):
         fa.flood_complex(torch.rand(10, 2), torch.rand(4, 2), use_triton=True)
+
+
+def test_edge_cases_cpu():
+    # empty cloud: a clean error
+    with pytest.raises(RuntimeError):
+        fa.flood_complex(torch.zeros((0, 3)), 5)
+    # 1-D ambient space: the "Delaunay complex" is the chain of sorted landmarks
+    torch.manual_seed(0)
+    x = torch.rand(200, 1)
+    fc = fa.flood_complex(x, 12, points_per_edge=9)
+    ref = fo_complex(x.numpy(), 12, points_per_edge=9)
+    assert set(fc) == set(ref)
+    assert max(abs(fc[k] - ref[k]) for k in ref) < 1e-6
+    assert sum(len(k) == 2 for k in fc) == 11
+    # a single simplex (landmarks == dim + 1 points)
+    pts = torch.rand(50, 2)
+    fc = fa.flood_complex(pts, pts[:3].clone(), points_per_edge=5)
+    assert set(fc) == {(0,), (1,), (2,), (0, 1), (0, 2), (1, 2), (0, 1, 2)}
+    assert fc[(0,)] == 0.0 and fc[(0, 1, 2)] >= max(fc[(0, 1)], fc[(0, 2)], fc[(1, 2)])
+
+
+def fo_complex(pts, n_lms, **kw):
+    from oracle import flood_oracle as fo
+    lms = pts[fo.exact_fps(pts, n_lms, 0)]
+    return fo.flood_complex_oracle(pts, lms, **kw)
