@@ -237,7 +237,7 @@ def main():
     pair_evals = P_local * R                       # what the reference's formulation evaluates
     if args.method == "bvh":
         st_h = stats.cpu().tolist()
-        ks = args.bvh_ks or (8 if R > 256 else (4 if R > 128 else (2 if R > 64 else 1)))
+        ks = args.bvh_ks or (2 if R > 64 else 1)
         done_evals = st_h[0] * 16 * 64 * ks        # leaves evaluated x 16 points x tile samples
         st_h = {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1], "nodes_expanded": st_h[2]}
     elif args.method == "cell":

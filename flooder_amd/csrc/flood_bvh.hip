@@ -322,6 +322,31 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         } else {
           lb0 = lb;
           grp0 = c;
+          // ---- transposed refine: all 64 leaf boxes of the group (one per lane) against every sample of
+          // the tile (broadcast one lane's samples at a time).  A leaf that no sample can still improve on
+          // is dropped here, in 1/64 of a per-leaf test each, before the nearest-first loop pops it.
+          const bool cand = lb * SAFE < M;
+          // worth it when the per-leaf tests it replaces cost more than one pass over the tile's samples
+          constexpr int PER_LEAF = KSV * 4 * DIM + 40, PER_GROUP = 64 * KSV * (4 * DIM + 3);
+          if (KSV <= 2 && __popcll(__ballot(cand)) * PER_LEAF > PER_GROUP) {
+            bool need = false;
+#pragma unroll 2
+            for (int src = 0; src < 64; ++src) {
+#pragma unroll
+              for (int i = 0; i < KSV; ++i) {
+                float lbp = 0.f;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                  const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[i][k]), src));
+                  const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
+                  lbp = __builtin_fmaf(gap, gap, lbp);
+                }
+                const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best[i]), src));
+                need = need || (lbp * SAFE < bi);
+              }
+            }
+            if (!(cand && need)) lb0 = __builtin_inff();
+          }
         }
         continue;
       }
@@ -455,7 +480,7 @@ struct SweepBvhOp {
                  int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, hipStream_t st) {
     const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
-    if (ks == 0) ks = R <= 64 ? 1 : (R <= 128 ? 2 : (R <= 256 ? 4 : 8));
+    if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
     if (ks == 1)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
                          weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
