@@ -209,6 +209,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # create the communicator outside the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, device=dev), op=dist.ReduceOp.MIN)
     for _ in range(max(args.warmup, 0)):
         out = step()
     sync_all()

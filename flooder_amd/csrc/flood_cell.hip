@@ -33,6 +33,8 @@ constexpr int CAPW = 512;         // points staged per wave
 constexpr int MAXLEAF = 1024;     // leaves gathered per wave item (16 K points before filtering)
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;
+constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively at most (sparse chunk box)
+constexpr int EXH_MAX_DENSE = 64 * CAPW;  // ... when the chunk box itself is full of points
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 
 template <int DIM>
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     bool give_up = n_leaves < 0;
     if (give_up) ++g_gather0;
     float c = ext;
+    int n0 = 0;  // points of the cloud inside the chunk box
     if (!give_up) {
-      int n0 = 0;
       // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
       const int n_cand0 = n_leaves * LEAF;
       for (int ib = 0; ib < n_cand0; ib += 64 * UNR) {
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
       PHASE(5);
       const float c_ok = (0.999f * c) * (0.999f * c);
+      // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
+      // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
+      if (n_keep > (n0 * 8 >= n_keep ? EXH_MAX_DENSE : EXH_MAX)) { give_up = true; ++g_cap; break; }
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
