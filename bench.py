@@ -164,7 +164,7 @@ def main():
                                              _native.current_stream_ptr(dev)), "ball_count")
     P_local = int(cnt0.sum().item())
     del pts_pad0, search0, lo0, hi0, cnt0
-    stats = torch.zeros(13, dtype=torch.int64, device=dev)
+    stats = torch.zeros(16, dtype=torch.int64, device=dev)
     plan = core.SamplePlan(weights, faces)
 
     def build_index():
@@ -251,7 +251,8 @@ def main():
                 "giveup_gather_density": st_h[4], "giveup_gather_stage": st_h[5], "giveup_lds_full": st_h[6],
                 "giveup_doublings": st_h[7], "exhaustive_rounds": st_h[8],
                 "fallback_leaves_evaluated": st_h[9], "fallback_leaves_tested": st_h[10],
-                "fallback_nodes_expanded": st_h[11], "fallback_max_tests_one_tile": st_h[12]}
+                "fallback_nodes_expanded": st_h[11], "fallback_max_tests_one_tile": st_h[12],
+                "fine_rows_swept": st_h[13], "fine_rows_total": st_h[14]}
     else:
         st_h = None
         done_evals = pair_evals

@@ -39,10 +39,13 @@ SIGNATURES = {
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                            c_void_p, c_void_p, c_void_p]),
+                                            c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                       c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p]),
+                                       c_int64, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_prune_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
+                                       c_int, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
     "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
     const int32_t* __restrict__ n_list, int seed, int subs_max, int budget,
-    int32_t* __restrict__ list2, int32_t* __restrict__ count2) {
+    int32_t* __restrict__ list2, int32_t* __restrict__ count2, RowSel sel) {
   // budget > 0 (work-list mode): a wave abandons a tile after `budget` box tests, stores the minima it has
   // (valid upper bounds) and appends the tile to list2; a second pass finishes those tiles split over
   // many more waves.  Bounds the tail caused by tiles near the medial axis of the cloud.
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   __shared__ int64_t s_grp[4][MAXL];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int tiles = (R + 64 * KSV - 1) / (64 * KSV);
+  const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
+  const int tiles = (n_slots + 64 * KSV - 1) / (64 * KSV);
   // few flagged tiles: split each over up to subs_max waves (short tail); many: keep lanes distinct
   int subs = 1;
   if (item_list) {
@@ -223,15 +224,20 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const unsigned long long tests_before = n_leaf_test + n_node_test;
     const int64_t s = g / tiles;
     const int tile = (int)(g - s * tiles);
+    const int n_live = sel.list ? sel.cnt[s] : R;
+    if (tile * 64 * KSV >= n_live) continue;
 
     // ---- this lane's KSV samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188)
     float p[KSV][DIM];
     float best[KSV];
+    int row[KSV];
     const float* vs = verts + s * (int64_t)k1 * DIM;
 #pragma unroll
     for (int i = 0; i < KSV; ++i) {
-      int r = tile * 64 * KSV + i * 64 + slane;
-      if (r >= R) r = R - 1;  // duplicate of the last sample, never stored
+      int slot = tile * 64 * KSV + i * 64 + slane;
+      if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
+      const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
+      row[i] = r;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
       for (int j = 0; j < k1; ++j) {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
       }
       // seed: start from the minima already in out_d2 (upper bounds found by an earlier pass)
-      best[i] = seed ? __uint_as_float(out_d2[s * (int64_t)R + r]) : __builtin_inff();
+      best[i] = seed ? __uint_as_float(out_d2[s * (int64_t)sel.ld_out + r]) : __builtin_inff();
     }
     // ---- bounding box of the tile (wave-uniform)
     float tlo[DIM], thi[DIM];
@@ -415,8 +421,8 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 
 #pragma unroll
     for (int i = 0; i < KSV; ++i) {
-      const int r = tile * 64 * KSV + i * 64 + slane;
-      if (r < R && lane < per_sub) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
+      if (tile * 64 * KSV + i * 64 + slane < n_live && lane < per_sub)
+        out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
     }
     if (abandoned && sub == 0 && lane == 0) {  // (budgeted passes run with subs = 1)
       const int pos = atomicAdd(count2, 1);
@@ -477,22 +483,23 @@ struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
                  unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
-                 int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, hipStream_t st) {
+                 int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, RowSel sel,
+                 hipStream_t st) {
     const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
     if (ks == 1)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
     else if (ks == 2)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
     else if (ks == 4)
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
     else
       hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2);
+                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
     return check_launch("sweep_bvh");
   }
 };
@@ -553,25 +560,27 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0, 1,
-                                  0, nullptr, nullptr, (hipStream_t)stream);
+                                  0, nullptr, nullptr, RowSel{nullptr, nullptr, 0, R}, (hipStream_t)stream);
 }
 
 int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                 const float* verts, const float* weights, int k1, int R,
                                 int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
-                                int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
+                                int32_t* queue, uint32_t* out_d2, int ld_out, const int32_t* row_list,
+                                const int32_t* row_cnt, int list_stride, int budget, int32_t* list2,
                                 int32_t* count2, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !item_list || !n_items ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || budget < 0 ||
-      (budget > 0 && (!list2 || !count2)))
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || budget < 0 || ld_out < 1 ||
+      (budget > 0 && (!list2 || !count2)) || (row_list && (!row_cnt || list_stride < 1)))
     return fail(FLOODER_E_ARG, "flooder_sweep_bvh_items_f32: bad argument");
+  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
   const Levels lv = make_levels(n_pts);
   // a budgeted pass keeps 64 distinct samples per wave; the unbudgeted pass may split tiles
   const int subs = budget > 0 ? 1 : g_bvh_subs;
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), item_list, n_items, 1,
-                                  1, subs, budget, list2, count2, (hipStream_t)stream);
+                                  1, subs, budget, list2, count2, sel, (hipStream_t)stream);
 }
 
 int flooder_selftest(const float* in64, float* out128, void* stream) {

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, RowSel sel) {
   constexpr int DP = padded_dim(DIM);
   constexpr int G = CellCfg<DIM>::G;
   constexpr int NC = CellCfg<DIM>::NC;
@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   int* s_leaf = s_leaf_all[wv];
   int* s_keep = s_keep_all[wv];
   const int top = lv.n_levels - 1;
-  const int chunks = (R + CHUNK - 1) / CHUNK;
-  const int tiles64 = (R + 63) >> 6;
+  const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
+  const int chunks = (n_slots + CHUNK - 1) / CHUNK;
+  const int tiles64 = (n_slots + 63) >> 6;
   const int64_t n_items = n_simplices * chunks;
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
 #ifdef FLOODER_PHASE_TIMERS
@@ -112,18 +113,23 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const int64_t s = g / chunks;
     const int q = (int)(g - s * chunks);
     const float* vs = verts + s * (int64_t)k1 * DIM;
+    const int n_live = sel.list ? sel.cnt[s] : R;  // live slots of this simplex (wave-uniform)
+    if (q * CHUNK >= n_live) continue;
     PHASE(0);
 
     // ---- 0. samples and chunk box
     float p[SPL][DIM];
     float best[SPL];
     bool open[SPL];  // still unverified
+    int row[SPL];    // row of the weight table / column of the output
     float blo[DIM], bhi[DIM];
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
-      int r = q * CHUNK + i * 64 + lane;
-      open[i] = r < R;
-      if (r >= R) r = R - 1;
+      int slot = q * CHUNK + i * 64 + lane;
+      open[i] = slot < n_live;
+      if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
+      const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
+      row[i] = r;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
       for (int j = 0; j < k1; ++j) {
@@ -568,8 +574,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     // ---- results; tiles of 64 samples that are still open go to the exact tree sweep
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
-      const int r = q * CHUNK + i * 64 + lane;
-      if (r < R) out_d2[s * (int64_t)R + r] = __float_as_uint(best[i]);
+      if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
       if (__ballot(open[i]) != 0ull) {
         if (lane == 0) {
           const int pos = atomicAdd(flag_count, 1);
@@ -606,11 +611,11 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 hipStream_t st) {
+                 RowSel sel, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       const int grid = 256 * 3;  // persistent blocks of 4 independent waves (LDS: 3 blocks per CU)
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, queue, out, flag_list, flag_count, stats);
+                         weights, k1, R, ns, alpha, queue, out, flag_list, flag_count, stats, sel);
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
@@ -624,18 +629,21 @@ extern "C" {
 
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                           float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list,
-                           int32_t* flag_count, uint64_t* stats, void* stream) {
+                           float alpha, int32_t* queue, uint32_t* out_d2, int ld_out,
+                           const int32_t* row_list, const int32_t* row_cnt, int list_stride,
+                           int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f) || ld_out < 1 ||
+      (row_list && (!row_cnt || list_stride < 1)))
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: bad argument");
+  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
   if (dim != 2 && dim != 3) return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
-  if (n_simplices * (int64_t)((R + 63) / 64) > 0x7fffffffLL)
+  if (n_simplices * (int64_t)(((row_list ? list_stride : R) + 63) / 64) > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: too many (simplex, tile) pairs");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
-                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats),
+                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel,
                               (hipStream_t)stream);
 }
 
