@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
+    ap.add_argument("--alpha", type=float, default=None, help="cell size of the cell sweep in units of the local spacing")
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
@@ -115,6 +116,8 @@ def main():
         _native.check(lib.flooder_set_option(b"bvh_ks", args.bvh_ks), "set_option")
     if args.bvh_subs is not None:
         _native.check(lib.flooder_set_option(b"bvh_subs", args.bvh_subs), "set_option")
+    if args.alpha is not None:
+        core.CELL_ALPHA = args.alpha
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
