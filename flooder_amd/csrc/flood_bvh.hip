@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 2; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -485,7 +485,7 @@ struct SweepBvhOp {
                  unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
                  int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, RowSel sel,
                  hipStream_t st) {
-    const int grid = 256 * 8;  // persistent blocks; 4 independent waves each
+    const int grid = g_bvh_grid;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
     if (ks == 1)

@@ -613,7 +613,7 @@ struct CellOp {
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
                  RowSel sel, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
-      const int grid = 256 * 3;  // persistent blocks of 4 independent waves (LDS: 3 blocks per CU)
+      const int grid = g_cell_grid;  // persistent blocks of 4 independent waves
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
                          weights, k1, R, ns, alpha, queue, out, flag_list, flag_count, stats, sel);
       return check_launch("cell_sweep");

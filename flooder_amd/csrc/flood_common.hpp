@@ -13,6 +13,8 @@ constexpr uint32_t INF_BITS = 0x7f800000u;
 
 extern int g_bvh_ks;
 extern int g_bvh_subs;
+extern int g_bvh_grid;
+extern int g_cell_grid;
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

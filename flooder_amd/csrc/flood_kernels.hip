@@ -564,6 +564,14 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_ks = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_grid") == 0 && value >= 1 && value <= 65536) {
+    g_cell_grid = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "bvh_grid") == 0 && value >= 1 && value <= 65536) {
+    g_bvh_grid = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "bvh_subs") == 0 && value >= 1 && value <= 64 && (value & (value - 1)) == 0) {
     g_bvh_subs = value;
     return FLOODER_OK;

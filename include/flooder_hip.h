@@ -49,8 +49,12 @@ const char* flooder_last_error(void);
 /* Name of the GPU architecture of `device` copied into buf (e.g. "gfx950:sramecc+:xnack-"). */
 int flooder_device_arch(int device, char* buf, int buflen);
 
-/* Tuning switches (process-wide).  "sweep_variant": 0 = packed-fp32 inner loop (default),
- * 1 = plain fp32 inner loop; both give bit-identical results. */
+/* Tuning switches (process-wide); none of them changes a result bit.
+ *   "sweep_variant": 0 = packed-fp32 inner loop (default), 1 = plain fp32 inner loop (ball sweep);
+ *   "bvh_ks": samples per lane of the tree sweep (0 = auto: 1 for R <= 64, else 2);
+ *   "bvh_subs": sub-tiles a tree-sweep item may be split into (default 16);
+ *   "bvh_grid": persistent workgroups of the tree sweep (default 1024 = 4 per CU);
+ *   "cell_grid": persistent workgroups of the cell sweep (default 512 = the 2 per CU that fit LDS). */
 int flooder_set_option(const char* name, int value);
 
 /* Row stride (floats) of a padded point / candidate row for ambient dimension `dim`:
