@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
+    ap.add_argument("--emulate-shard", default=None, metavar="r/W",
+                    help="diagnostic (N=1 only): time rank r's share of a W-rank simplex-sharded step, no collective")
     ap.add_argument("--alpha", type=float, default=None, help="cell size of the cell sweep in units of the local spacing")
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
@@ -155,6 +157,10 @@ def main():
         mine = torch.arange(rank, S_all, world, device=dev) if world > 1 else None
         hook = None
     face_hook = min_reduce_hook() if (world > 1 and mine is not None) else None
+    if args.emulate_shard and world == 1:
+        er, ew = (int(v) for v in args.emulate_shard.split("/"))
+        mine = torch.arange(er, S_all, ew, device=dev)
+        face_hook = lambda t: t  # noqa: E731  (the 360 KB all_reduce is not emulated)
     if mine is not None:
         verts, centers, radii = verts[mine].contiguous(), centers[mine].contiguous(), radii[mine].contiguous()
     dp = lib.flooder_padded_dim(w["dim"])
@@ -308,6 +314,7 @@ def main():
             "valu": {"achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flop_per_pair": 10},
         },
+        "emulated_shard": args.emulate_shard,
         "kernels_ms_per_step": {k: round(v / args.steps, 4) for k, v in k_ms.items()},
         # landmark selection (generate_landmarks, outside the step): one distance-update + arg-max sweep of
         # the cloud per landmark; algorithmic bytes = (4*dim + 8) B per point and iteration

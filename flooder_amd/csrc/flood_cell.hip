@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 
   for (;;) {
     PHASE_T0();
+#ifdef FLOODER_PHASE_TIMERS
+    const unsigned long long t_chunk0 = __builtin_amdgcn_s_memtime();
+#endif
     int g32 = 0;
     if (lane == 0) g32 = atomicAdd(queue, 1);
     const int64_t g = (int64_t)wave_uniform(g32);
@@ -584,6 +587,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
     PHASE(10);
+#ifdef FLOODER_PHASE_TIMERS
+    if (stats && lane == 0) stats[64 + g] = __builtin_amdgcn_s_memtime() - t_chunk0;  // diagnostic build only
+#endif
   }
   if (stats) {
 #ifdef FLOODER_PHASE_TIMERS
