@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/ab.sh <workload> "<flags A>" "<flags B>" ...  - one bench line per flag set
+wl=$1; shift
+for f in "$@"; do
+  timeout 300 python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline $f 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['config']['sweep_stats_rank0'] or {}
+print('$wl [$f]', d['ms_per_step'], d['kernels_ms_per_step'], 'index', d['ms_index_build'], {k:s.get(k) for k in ('restage_rounds','tiles_flagged','exhaustive_rounds','cell_pairs','points_staged')})"
+done
