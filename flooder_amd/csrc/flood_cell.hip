@@ -34,7 +34,6 @@ constexpr int MAXLEAF = 1024;     // leaves gathered per wave item (16 K points 
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;
 constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively at most (sparse chunk box)
-constexpr int EXH_MAX_DENSE = 64 * CAPW;  // ... when the chunk box itself is full of points
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 
 template <int DIM>
@@ -76,7 +75,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    int64_t n_simplices, float alpha, int exh_dense, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, RowSel sel) {
   constexpr int DP = padded_dim(DIM);
@@ -107,7 +106,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   for (;;) {
     PHASE_T0();
 #ifdef FLOODER_PHASE_TIMERS
-    const unsigned long long t_chunk0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_chunk0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+    unsigned long long t_phase0[12];
+    for (int i = 0; i < 12; ++i) t_phase0[i] = t_phase[i];
 #endif
     int g32 = 0;
     if (lane == 0) g32 = atomicAdd(queue, 1);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         wave_lds_sync();
       };
       {
-        const int64_t g0_[GB] = {0, 0, 0, 0};
+        const int64_t g0_[GB] = {};
         if (top == 0) test_children(0, g0_, 1, s_leaf, n_leaf, MAXLEAF);
         else test_children(top, g0_, 1, fa, na, MAXFRONT);
       }
@@ -304,6 +305,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     PHASE(3);
 
     // ---- 2-4. stage, query, verify; double c while samples stay open
+#ifdef FLOODER_PHASE_TIMERS
+    unsigned long long d_info = 0, d_tb = 0, d_flush = 0, d_wait = 0;  // diagnostics of the last attempt
+#endif
     for (int attempt = 0; attempt < MAX_TRIES && !give_up; ++attempt) {
       c = __builtin_fmaxf(c, ext / (float)(G - 3));
       const float inv_c = 1.f / c;
@@ -378,10 +382,15 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         }
       }
       PHASE(5);
+#ifdef FLOODER_PHASE_TIMERS
+      d_info = (unsigned long long)n_cand | ((unsigned long long)n_keep << 20) | ((unsigned long long)(attempt + 1) << 40) |
+               ((unsigned long long)(n_keep > CAPW) << 44);
+      d_tb = 0;
+#endif
       const float c_ok = (0.999f * c) * (0.999f * c);
       // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
-      if (n_keep > (n0 * 8 >= n_keep ? EXH_MAX_DENSE : EXH_MAX)) { give_up = true; ++g_cap; break; }
+      if (n_keep > (n0 * 8 >= n_keep ? exh_dense : EXH_MAX)) { give_up = true; ++g_cap; break; }
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
@@ -390,6 +399,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         ++g_brute;
         int n_st = 0;
         auto flush = [&]() {
+#ifdef FLOODER_PHASE_TIMERS
+          const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+#endif
           wave_lds_sync();
           for (int j = 0; j < n_st; j += 4) {
             float4 x[4];
@@ -416,6 +428,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           n_pairs += (unsigned long long)n_st * SPL;
           n_st = 0;
           wave_lds_sync();
+#ifdef FLOODER_PHASE_TIMERS
+          d_flush += __builtin_amdgcn_s_memtime() - tf0;
+#endif
         };
         for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
           float x[UNR][DP];
@@ -427,11 +442,19 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
             const int64_t row = keep[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
             load_row<DP>(pts + row * DP, x[u]);
           }
+#ifdef FLOODER_PHASE_TIMERS
+          {
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            d_wait += __builtin_amdgcn_s_memtime() - ta;
+          }
+#endif
+          if (n_st + 64 * UNR > CAPW) flush();  // (one call site: room for a whole step is checked up front)
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
             keep[u] = keep[u] && keep_point(x[u]);
             const unsigned long long m = __ballot(keep[u]);
-            if (n_st + __popcll(m) > CAPW) flush();
             if (keep[u]) {
               float4 v;
               v.x = x[u][0];
@@ -588,7 +611,14 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     }
     PHASE(10);
 #ifdef FLOODER_PHASE_TIMERS
-    if (stats && lane == 0) stats[64 + g] = __builtin_amdgcn_s_memtime() - t_chunk0;  // diagnostic build only
+    if (stats && lane == 0) {  // diagnostic build only: sixteen values per chunk
+      stats[64 + 16 * g] = t_chunk0;
+      stats[64 + 16 * g + 1] = __builtin_amdgcn_s_memrealtime();
+      stats[64 + 16 * g + 2] = d_info;
+      stats[64 + 16 * g + 3] = d_wait;   // cycles waiting for the streamed rows in the exhaustive mode
+      stats[64 + 16 * g + 4] = d_flush;  // cycles inside flush() of the exhaustive mode
+      for (int i = 0; i < 11; ++i) stats[64 + 16 * g + 5 + i] = t_phase[i] - t_phase0[i];  // core-clock cycles per phase
+    }
 #endif
   }
   if (stats) {
@@ -621,7 +651,7 @@ struct CellOp {
     if constexpr (DIM == 2 || DIM == 3) {
       const int grid = g_cell_grid;  // persistent blocks of 4 independent waves
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, queue, out, flag_list, flag_count, stats, sel);
+                         weights, k1, R, ns, alpha, g_cell_exh_dense, queue, out, flag_list, flag_count, stats, sel);
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");

@@ -564,6 +564,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_ks = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_exh_dense") == 0 && value >= 512) {
+    g_cell_exh_dense = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_grid") == 0 && value >= 1 && value <= 65536) {
     g_cell_grid = value;
     return FLOODER_OK;

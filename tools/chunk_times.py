@@ -1,8 +1,10 @@
-"""Diagnostic: per-chunk duration of the cell sweep (library built with -DFLOODER_PHASE_TIMERS): where is the tail?"""
+"""Diagnostic: per-chunk start/end cycle stamps of the cell sweep (library built with -DFLOODER_PHASE_TIMERS):
+where is the tail?   usage: python tools/chunk_times.py [W]   (W: keep every W-th simplex, as one rank of W would)"""
 import sys, torch, numpy as np
 sys.path.insert(0, '.')
 import flooder_amd as fa
 from flooder_amd import _native, core
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = _native.load()
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
@@ -11,35 +13,34 @@ lms = fa.generate_landmarks(pts, 1000, start_idx=0)
 stree, simplices = core._build_complex(lms, 3)
 simp = torch.as_tensor(simplices[3], device=dev)
 verts = lms[simp]
+order = torch.argsort(verts.mean(1)[:, 0])
+verts = verts[order][0::W].contiguous()
 weights, vi, fi = core.generate_grid(30, 3, dev, torch.float32)
 faces = core._FaceTable(fi, weights.shape[0], dev)
 index = core.PointIndex(pts)
 S, R = verts.shape[0], weights.shape[0]
 chunks = (R + 255) // 256
-stats = torch.zeros(64 + S * chunks, dtype=torch.int64, device=dev)
-for _ in range(2):
+stats = torch.zeros(64 + 16 * S * chunks, dtype=torch.int64, device=dev)
+for _ in range(3):
     stats.zero_()
     core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
 torch.cuda.synchronize()
-t = stats[64:].cpu().numpy().astype(float)
-print("chunks", t.size, "sum/2048 waves (cycles)", t.sum() / 2048, "max", t.max(), "mean", t.mean(), "median", np.median(t))
-for q in (50, 90, 99, 99.9, 99.99):
-    print("pct", q, np.percentile(t, q))
-order = np.argsort(-t)[:30]
-vol = torch.linalg.det((verts[:, 1:] - verts[:, :1])).abs().cpu().numpy() / 6
-cen = verts.mean(1).norm(dim=1).cpu().numpy()
-for g in order:
+t = stats[64:].cpu().numpy().reshape(-1, 16)
+ok = t[:, 1] > 0
+t0, t1 = t[ok, 0].min(), t[ok, 1].max()
+dur = ((t[:, 1] - t[:, 0]) * ok).astype(np.float64)
+print(f"W={W} chunks {ok.sum()}  span {t1 - t0:.0f} ticks(10ns)  sum/2048 {dur.sum() / 2048:.0f}  max {dur.max():.0f} mean {dur[ok].mean():.0f}")
+first_start = np.sort(t[ok, 0] - t0)
+print("chunk starts (ticks(10ns) after the first): 1st..5th", first_start[:5], " 2048th", first_start[min(2047, len(first_start) - 1)])
+late = np.argsort(-t[:, 1])[:12]
+for g in late:
     s, q = divmod(int(g), chunks)
-    print(f"chunk {g} simplex {s} q {q} cycles {t[g]:.0f} vol {vol[s]:.4f} |centre| {cen[s]:.2f}")
-# greedy list schedule in queue order on 2048 waves -> makespan vs ideal
-import heapq
-h = [0.0] * 2048
-heapq.heapify(h)
-for v in t:
-    heapq.heappush(h, heapq.heappop(h) + v)
-print("list-schedule makespan (cycles)", max(h), "ideal", t.sum() / 2048)
-h = [0.0] * 2048
-heapq.heapify(h)
-for v in np.sort(t)[::-1]:
-    heapq.heappush(h, heapq.heappop(h) + v)
-print("LPT makespan (cycles)", max(h))
+    info = int(t[g, 2])
+    print(f"  ends at {t[g, 1] - t0:9.0f}  started {t[g, 0] - t0:9.0f}  dur {dur[g]:8.0f}  simplex {s} q {q}  n_cand {info & 0xfffff} "
+          f"n_keep {(info >> 20) & 0xfffff} attempts {(info >> 40) & 15} exhaustive {(info >> 44) & 1}  kcycles waiting for streamed rows (exhaustive) {t[g, 3] // 1000} in flush {t[g, 4] // 1000}")
+    names = ["pop", "samples", "gather0", "density", "gather1", "count", "prefix", "scatter", "query", "brute", "output"]
+    print("      kcycles: " + " ".join(f"{n}={int(v) // 1000}" for n, v in zip(names, t[g, 5:16])))
+# occupancy profile: how many waves are busy over time
+edges = np.linspace(t0, t1, 21)
+busy = [(np.minimum(t[ok, 1], b) - np.maximum(t[ok, 0], a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
+print("busy waves per 5% time slice:", np.round(busy).astype(int).tolist())

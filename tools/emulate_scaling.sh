@@ -2,8 +2,8 @@
 # Diagnostic: per-rank step time of a W-rank simplex-sharded run, measured on ONE GPU (no collective).
 # usage: tools/emulate_scaling.sh [workload]
 wl=${1:-cfg2}
-for spec in 0/1 0/2 0/4 0/8 3/8 7/8; do
-  timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --emulate-shard $spec 2>/dev/null | python -c "
+for spec in ${SPECS:-0/1 0/2 0/4 0/8 3/8 7/8}; do
+  timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --emulate-shard $spec $EXTRA 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$spec', d['ms_per_step'], d['kernels_ms_per_step'])"
 done

@@ -14,7 +14,7 @@ verts = lms[simp]
 weights, vi, fi = core.generate_grid(30, 3, dev, torch.float32)
 faces = core._FaceTable(fi, weights.shape[0], dev)
 index = core.PointIndex(pts)
-stats = torch.zeros(64 + verts.shape[0] * ((weights.shape[0] + 255) // 256), dtype=torch.int64, device=dev)  # [64:] per-chunk cycles
+stats = torch.zeros(64 + 16 * verts.shape[0] * ((weights.shape[0] + 255) // 256), dtype=torch.int64, device=dev)  # [64:] per-chunk cycles
 for _ in range(2):
     stats.zero_()
     core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
