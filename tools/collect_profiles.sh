@@ -10,8 +10,8 @@ R=$PWD
 TAG=${1:-cfg2}
 OUT=$R/gpurun_out/prof_final_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $TAG --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/err_trace.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/err_fetch.txt
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/err_write.txt
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sq.json 2> $OUT/err_sq.txt
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $TAG --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/err_trace.txt
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/err_fetch.txt
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/err_write.txt
+timeout 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 bench.py --workload $TAG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sq.json 2> $OUT/err_sq.txt
 ls $OUT/*/runc/ | head -20
