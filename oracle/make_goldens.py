@@ -216,7 +216,35 @@ def main():
         )
         print(f"kernel {name}: candidates per ball {mask[:, :m].sum(1).tolist()}, "
               f"inf rows {int(torch.isinf(dist).all(1).sum())}")
+    make_generator_vectors()
+
+
+def make_generator_vectors():
+    """Section 4 on its own: ``python oracle/make_goldens.py generators``."""
+    _install_shims()
+    import torch
+
+    os.makedirs(OUT, exist_ok=True)
+    # ---- 4. synthetic generators: the reference's clouds for fixed seeds (CPU draws)
+    from flooder import synthetic_data_generators as sg
+
+    gen = {}
+    gen["fig8_plain"] = sg.generate_figure_eight_points_2d(300, seed=5).numpy()
+    gen["fig8_gauss"] = sg.generate_figure_eight_points_2d(200, r_bounds=(0.1, 0.25), noise_std=0.01, seed=6).numpy()
+    gen["fig8_uniform"] = sg.generate_figure_eight_points_2d(200, noise_std=0.02, noise_kind="uniform", seed=7).numpy()
+    p, c, r = sg.generate_swiss_cheese_points(500, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 6, (0.1, 0.2), seed=11)
+    gen["cheese3_points"], gen["cheese3_centres"], gen["cheese3_radii"] = p.numpy(), c.numpy(), r.numpy()
+    p, c, r = sg.generate_swiss_cheese_points(400, (0.0, -1.0), (2.0, 1.0), 3, (0.15, 0.3), seed=12)
+    gen["cheese2_points"], gen["cheese2_centres"], gen["cheese2_radii"] = p.numpy(), c.numpy(), r.numpy()
+    gen["annulus"] = sg.generate_annulus_points_2d(300, torch.tensor([0.5, -0.25]), 1.5, 0.4, seed=13).numpy()
+    gen["torus"] = sg.generate_noisy_torus_points_3d(400, R=3.0, r=1.0, noise_std=0.02, seed=14).numpy()
+    np.savez_compressed(os.path.join(OUT, "generators.npz"), **gen)
+    print("generators:", {k: v.shape for k, v in gen.items()})
+
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["generators"]:
+        make_generator_vectors()
+    else:
+        main()
