@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     PHASE_T0();
 #ifdef FLOODER_PHASE_TIMERS
     const unsigned long long t_chunk0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+    unsigned long long d_steps = 0;  // child-box tests of the tree gathers of this chunk
     unsigned long long t_phase0[12];
     for (int i = 0; i < 12; ++i) t_phase0[i] = t_phase[i];
 #endif
@@ -219,6 +220,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       bool over = false;
       // children of up to GB nodes `grp[u]` (valid for u < ng) at level lvl -> append hits to out_list
       auto test_children = [&](int lvl, const int64_t (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
+#ifdef FLOODER_PHASE_TIMERS
+        ++d_steps;
+#endif
         bool hit[GB];
         float lo[GB][DP], hi[GB][DP];
 #pragma unroll
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       stats[64 + 16 * g] = t_chunk0;
       stats[64 + 16 * g + 1] = __builtin_amdgcn_s_memrealtime();
       stats[64 + 16 * g + 2] = d_info;
-      stats[64 + 16 * g + 3] = d_wait;   // cycles waiting for the streamed rows in the exhaustive mode
+      stats[64 + 16 * g + 3] = d_wait | (d_steps << 40);   // cycles waiting for the streamed rows in the exhaustive mode
       stats[64 + 16 * g + 4] = d_flush;  // cycles inside flush() of the exhaustive mode
       for (int i = 0; i < 11; ++i) stats[64 + 16 * g + 5 + i] = t_phase[i] - t_phase0[i];  // core-clock cycles per phase
     }

@@ -295,10 +295,55 @@ __global__ __launch_bounds__(256) void face_max_kernel(const uint32_t* __restric
     for (int r = threadIdx.x; r < R; r += blockDim.x)
       out_dist[s * (int64_t)R + r] = __builtin_sqrtf(__uint_as_float(row[r]));
   }
+  // Faces with many rows (the simplex itself: all R rows) are reduced by the whole block - a face that lists
+  // every row is scanned directly, coalesced, without its index list; the many small faces (triangles, edges,
+  // vertices) go one per wave, round robin, with no block barrier.
+  constexpr int BIG = 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   for (int f = 0; f < n_faces; ++f) {
     const int b = face_ptr[f], e = face_ptr[f + 1];
+    if (e - b < BIG) continue;  // (block-uniform)
     uint32_t m = 0u;
-    for (int q = b + threadIdx.x; q < e; q += blockDim.x) {
+    if (e - b == R && (R & 3) == 0) {  // rows are 16 B aligned: four values per load
+      const uint4* row4 = reinterpret_cast<const uint4*>(row);
+      for (int r = threadIdx.x; r < (R >> 2); r += blockDim.x) {
+        const uint4 v = row4[r];
+        const uint32_t a = v.x > v.y ? v.x : v.y, c = v.z > v.w ? v.z : v.w;
+        const uint32_t t = a > c ? a : c;
+        m = t > m ? t : m;
+      }
+    } else if (e - b == R) {
+      for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const uint32_t v = row[r];
+        m = v > m ? v : m;
+      }
+    } else {
+      for (int q = b + threadIdx.x; q < e; q += blockDim.x) {
+        const uint32_t v = row[face_rows[q]];
+        m = v > m ? v : m;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(m, o);
+      m = t > m ? t : m;
+    }
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t a = red[0];
+      for (int w = 1; w < n_waves; ++w) a = red[w] > a ? red[w] : a;
+      out_face[s * (int64_t)n_faces + f] = __builtin_sqrtf(__uint_as_float(a));
+    }
+    __syncthreads();
+  }
+  int turn = 0;
+  for (int f = 0; f < n_faces; ++f) {
+    const int b = face_ptr[f], e = face_ptr[f + 1];
+    if (e - b >= BIG) continue;
+    if ((turn++ % n_waves) != wave) continue;
+    uint32_t m = 0u;
+    for (int q = b + lane; q < e; q += 64) {
       const uint32_t v = row[face_rows[q]];
       m = v > m ? v : m;
     }
@@ -307,14 +352,7 @@ __global__ __launch_bounds__(256) void face_max_kernel(const uint32_t* __restric
       const uint32_t t = __shfl_xor(m, o);
       m = t > m ? t : m;
     }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t a = red[0];
-      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) a = red[w] > a ? red[w] : a;
-      out_face[s * (int64_t)n_faces + f] = __builtin_sqrtf(__uint_as_float(a));
-    }
-    __syncthreads();
+    if (lane == 0) out_face[s * (int64_t)n_faces + f] = __builtin_sqrtf(__uint_as_float(m));
   }
 }
 

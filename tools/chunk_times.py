@@ -37,7 +37,7 @@ for g in late:
     s, q = divmod(int(g), chunks)
     info = int(t[g, 2])
     print(f"  ends at {t[g, 1] - t0:9.0f}  started {t[g, 0] - t0:9.0f}  dur {dur[g]:8.0f}  simplex {s} q {q}  n_cand {info & 0xfffff} "
-          f"n_keep {(info >> 20) & 0xfffff} attempts {(info >> 40) & 15} exhaustive {(info >> 44) & 1}  kcycles waiting for streamed rows (exhaustive) {t[g, 3] // 1000} in flush {t[g, 4] // 1000}")
+          f"n_keep {(info >> 20) & 0xfffff} attempts {(info >> 40) & 15} exhaustive {(info >> 44) & 1}  gather steps {t[g, 3] >> 40} kcycles waiting for streamed rows (exhaustive) {(t[g, 3] & ((1 << 40) - 1)) // 1000} in flush {t[g, 4] // 1000}")
     names = ["pop", "samples", "gather0", "density", "gather1", "count", "prefix", "scatter", "query", "brute", "output"]
     print("      kcycles: " + " ".join(f"{n}={int(v) // 1000}" for n, v in zip(names, t[g, 5:16])))
 # occupancy profile: how many waves are busy over time
