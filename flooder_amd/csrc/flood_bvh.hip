@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 2; int g_cell_exh_dense = 64 * 512; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 2; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 4; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bvh_inner_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ sweep
-template <int DIM, int KSV>
+template <int DIM, int KSV, int LB>
 __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   constexpr int DP = padded_dim(DIM);
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
+  // LB > 1 (work-list mode): the LB nearest candidate leaves of a group are fetched together - lane l loads
+  // point l % 16 of leaf slot l / 16 - and staged here, one memory round trip instead of LB dependent ones
+  __shared__ float s_stage[LB > 1 ? 4 : 1][LB > 1 ? LB * LEAF : 1][DP];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
@@ -356,6 +359,114 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         }
         continue;
       }
+      if constexpr (LB > 1) {
+        // ---- leaf level, batched: the (up to) LB nearest unvisited leaves of the current group
+        static_assert(LB * LEAF == 64, "one staged point per lane");
+        int js[LB];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          js[u] = -1;
+          const float mn = wave_min_f32(lb0);
+          if (mn * SAFE < M) {  // (wave-uniform; once it fails it fails for the rest of the batch)
+            const int j = __builtin_ctzll(__ballot(lb0 == mn));
+            if (lane == j) lb0 = __builtin_inff();  // visited
+            js[u] = j;
+            any = true;
+            ++n_leaf_test;
+          }
+        }
+        if (!any) {
+          if (++lvl > top) break;
+          continue;
+        }
+        // which of them can still improve a sample of some lane?  (their boxes come from lanes js[u])
+        bool use[LB];
+        bool any_use = false;
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          use[u] = false;
+          if (js[u] >= 0) {
+            bool need = false;
+            float blo[DIM], bhi[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              blo[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), js[u]));
+              bhi[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), js[u]));
+            }
+#pragma unroll
+            for (int i = 0; i < KSV; ++i) {
+              float lbp = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[i][k], p[i][k] - bhi[k]), 0.f);
+                lbp = __builtin_fmaf(gap, gap, lbp);
+              }
+              need |= (lbp * SAFE < best[i]);
+            }
+            use[u] = __ballot(need) != 0ull;
+            any_use = any_use || use[u];
+          }
+        }
+        if (!any_use) continue;
+        {
+          const int slot = lane / LEAF;
+          int jl = js[0];
+          bool on = use[0];
+#pragma unroll
+          for (int u = 1; u < LB; ++u) {
+            jl = slot == u ? js[u] : jl;
+            on = slot == u ? use[u] : on;
+          }
+          float x[DP];
+#pragma unroll
+          for (int k = 0; k < DP; ++k) x[k] = __builtin_inff();
+          if (on) load_row<DP>(pts + ((grp0 * FAN + jl) * (int64_t)LEAF + (lane % LEAF)) * DP, x);
+#pragma unroll
+          for (int k = 0; k < DP; ++k) s_stage[wv][lane][k] = x[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          if (!use[u]) continue;  // (wave-uniform)
+          ++n_leaf_eval;
+#pragma unroll
+          for (int h = 0; h < LEAF; h += 2) {
+            float ca[DP], cb[DP];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+              ca[k] = s_stage[wv][u * LEAF + h][k];
+              cb[k] = s_stage[wv][u * LEAF + h + 1][k];
+            }
+#pragma unroll
+            for (int i = 0; i < KSV; ++i) {
+              float da, db;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float ta = p[i][k] - ca[k];
+                const float tb = p[i][k] - cb[k];
+                if (k == 0) {
+                  da = ta * ta;
+                  db = tb * tb;
+                } else {
+                  da = __builtin_fmaf(ta, ta, da);
+                  db = __builtin_fmaf(tb, tb, db);
+                }
+              }
+              best[i] = __builtin_fminf(best[i], __builtin_fminf(da, db));
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        float bmx = best[0];
+#pragma unroll
+        for (int i = 1; i < KSV; ++i) bmx = __builtin_fmaxf(bmx, best[i]);
+        M = wave_max_f32(bmx);
+        continue;
+      }
       // ---- leaf level: nearest unvisited leaf of the current group
       const float mn = wave_min_f32(lb0);
       if (!(mn * SAFE < M)) {
@@ -488,18 +599,16 @@ struct SweepBvhOp {
     const int grid = g_bvh_grid;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
-    if (ks == 1)
-      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 1>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
-    else if (ks == 2)
-      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 2>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
-    else if (ks == 4)
-      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 4>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
-    else
-      hipLaunchKernelGGL((sweep_bvh_kernel<DIM, 8>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel);
+    const bool batch = item_list != nullptr && ks == 1 && g_bvh_leaf_batch > 1;
+#define FLOODER_LAUNCH_BVH(KS_, LB_)                                                                              \
+  hipLaunchKernelGGL((sweep_bvh_kernel<DIM, KS_, LB_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, \
+                     k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel)
+    if (batch) FLOODER_LAUNCH_BVH(1, 4);
+    else if (ks == 1) FLOODER_LAUNCH_BVH(1, 1);
+    else if (ks == 2) FLOODER_LAUNCH_BVH(2, 1);
+    else if (ks == 4) FLOODER_LAUNCH_BVH(4, 1);
+    else FLOODER_LAUNCH_BVH(8, 1);
+#undef FLOODER_LAUNCH_BVH
     return check_launch("sweep_bvh");
   }
 };

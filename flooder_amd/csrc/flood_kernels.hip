@@ -602,6 +602,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_ks = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "bvh_leaf_batch") == 0 && (value == 1 || value == 4)) {
+    g_bvh_leaf_batch = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_exh_dense") == 0 && value >= 512) {
     g_cell_exh_dense = value;
     return FLOODER_OK;
