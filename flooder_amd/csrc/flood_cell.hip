@@ -137,10 +137,20 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       row[i] = r;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
-      for (int j = 0; j < k1; ++j) {
-        const float w = weights[(int64_t)r * k1 + j];
+      if (k1 == 4) {  // tetrahedra: the weight row is one 16 B load (same fma order as the general loop)
+        const float4 w4 = *reinterpret_cast<const float4*>(weights + (int64_t)r * 4);
+        const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(wj[j], vs[j * DIM + k], p[i][k]);
+        }
+      } else {
+        for (int j = 0; j < k1; ++j) {
+          const float w = weights[(int64_t)r * k1 + j];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
+        }
       }
       best[i] = __builtin_inff();
     }
@@ -555,22 +565,29 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           constexpr int NROW = DIM == 3 ? 9 : 3;
           constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
           constexpr int ORD2[3] = {0, -1, 1};
+          // bounds of all rows first: independent LDS reads, one latency instead of one per row
+          int row_bg[NROW], row_en[NROW];
+          float row_lb[NROW];
 #pragma unroll
           for (int rw = 0; rw < NROW; ++rw) {
             int base;
-            float lb;
             if constexpr (DIM == 3) {
               const int dy = ORD3[rw][0], dz = ORD3[rw][1];
               base = ((ck[2] + dz) * nc[1] + (ck[1] + dy)) * nc[0] + ck[0] - 1;
-              lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
+              row_lb[rw] = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
             } else {
               const int dy = ORD2[rw];
               base = (ck[1] + dy) * nc[0] + ck[0] - 1;
-              lb = gap2[1][dy + 1];
+              row_lb[rw] = gap2[1][dy + 1];
             }
-            if (!(lb < b)) continue;
-            const int bg = s_cell[base];
-            const int en = s_cell[base + 3];
+            row_bg[rw] = s_cell[base];
+            row_en[rw] = s_cell[base + 3];
+          }
+#pragma unroll
+          for (int rw = 0; rw < NROW; ++rw) {
+            if (!(row_lb[rw] < b)) continue;
+            const int bg = row_bg[rw];
+            const int en = row_en[rw];
             n_pairs += (unsigned long long)(en - bg);
             for (int j = bg; j < en; j += 4) {  // 4 LDS reads in flight; repeats of the last point are harmless
               float4 x[4];
