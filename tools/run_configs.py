@@ -44,3 +44,5 @@ if "cfg4s" in which: run("cfg4-small 200k gaussian 6D", torch.randn(200_000, 6),
 if "fig8" in which:
     t = torch.rand(2_000_000) * 2 * torch.pi
     run("2M figure-eight 2D", torch.stack((torch.sin(t), torch.sin(t) * torch.cos(t)), 1) + 0.01 * torch.randn(2_000_000, 2), 1000)
+if "cfg4" in which:  # BASELINE cfg 4: 2M-point 6D Gaussian, 2k landmarks; max_dimension=2, ppe 8
+    run("cfg4 2M gaussian 6D", torch.randn(2_000_000, 6), 2000, max_dimension=2, points_per_edge=8)
