@@ -29,8 +29,8 @@ namespace {
 
 constexpr int CHUNK = 256;        // samples per wave item
 constexpr int SPL = CHUNK / 64;   // samples per lane
-constexpr int CAPW = 512;         // points staged per wave
-constexpr int MAXLEAF = 1024;     // leaves gathered per wave item (16 K points before filtering)
+constexpr int CAPW = 480;         // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
+constexpr int MAXLEAF = 896;      // leaves gathered per wave item (14 K points before filtering)
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;
 constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively at most (sparse chunk box)
@@ -81,17 +81,30 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   constexpr int DP = padded_dim(DIM);
   constexpr int G = CellCfg<DIM>::G;
   constexpr int NC = CellCfg<DIM>::NC;
+  // LDS per wave: 7.5 KB point stage + 2 KB cell table (16-bit entries, two per word) + 3.5 KB leaf list = 13 KB,
+  // 52 KB per block, so THREE blocks (12 waves) fit a CU's 160 KB; the issue rate of a CU grows with the waves
+  // it holds and this kernel is short of them.  Two lists live inside the point stage while it holds no points:
+  // the gather's frontier (first 1.5 KB, gather phase only) and the kept-candidate list of the classification
+  // pass (last quarter; read completely into registers before the first point is scattered).
   __shared__ float4 s_pts_all[4][CAPW];
-  __shared__ int s_cell_all[4][NC + 8];
+  __shared__ uint32_t s_cell_all[4][(NC + 8) / 2];
   __shared__ int s_leaf_all[4][MAXLEAF];
-  __shared__ int s_keep_all[4][CAPW];  // kept candidates of the count pass: (candidate slot << 10) | cell
-  __shared__ int s_front_all[4][2][MAXFRONT];
+  static_assert(2 * MAXFRONT * sizeof(int) + CAPW * sizeof(int) <= CAPW * sizeof(float4), "aliases fit the stage");
+  static_assert(CAPW % 4 == 0 && CAPW <= 512, "kept-list alias and the 10-bit cell field");
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   float4* s_pts = s_pts_all[wv];
-  int* s_cell = s_cell_all[wv];      // [i+1]: count -> start -> end of cell i
+  uint32_t* s_cell32 = s_cell_all[wv];
+  const uint16_t* s_cell = reinterpret_cast<const uint16_t*>(s_cell32);  // [i+1]: count -> start -> end of cell i
+  uint16_t* s_cell_w = reinterpret_cast<uint16_t*>(s_cell32);
   int* s_leaf = s_leaf_all[wv];
-  int* s_keep = s_keep_all[wv];
+  int* s_keep = reinterpret_cast<int*>(s_pts + (CAPW - CAPW / 4));  // (candidate slot << 10) | cell
+  int* s_front = reinterpret_cast<int*>(s_pts);
+  // entry i of the 16-bit cell table: word i >> 1, half i & 1 (counts stay below 2^16: no carry into the neighbour)
+  auto cell_add = [&](int i) -> int {
+    const int sh = (i & 1) * 16;
+    return (int)((atomicAdd(&s_cell32[i >> 1], 1u << sh) >> sh) & 0xffffu);
+  };
   const int top = lv.n_levels - 1;
   const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
   const int chunks = (n_slots + CHUNK - 1) / CHUNK;
@@ -224,8 +237,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     float qlo[DIM], qhi[DIM];
     auto gather = [&]() -> int {
       constexpr int GB = 4;  // frontier nodes tested per step
-      int* fa = s_front_all[wv][0];
-      int* fb = s_front_all[wv][1];
+      int* fa = s_front;
+      int* fb = s_front + MAXFRONT;
       int na = 0, nb = 0, n_leaf = 0;
       bool over = false;
       // children of up to GB nodes `grp[u]` (valid for u < ng) at level lvl -> append hits to out_list
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       n_leaves = gather();
       PHASE(4);
       if (n_leaves < 0) { give_up = true; ++g_gather; break; }
-      for (int i = lane; i < ncells + 2; i += 64) s_cell[i] = 0;
+      for (int i = lane; i < (ncells + 3) / 2; i += 64) s_cell32[i] = 0u;
       wave_lds_sync();
       // 2a. classify every candidate ONCE (keep? which cell?), count per cell, remember the kept ones
       int n_keep = 0;  // wave-uniform: the loop has a uniform trip count
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           const int cid = cell_of(x[u]);
           const unsigned long long m = __ballot(keep[u]);
           if (keep[u]) {
-            atomicAdd(&s_cell[cid + 1], 1);
+            cell_add(cid + 1);
             const int slot = n_keep + lane_rank(m);
             if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
           }
@@ -501,37 +514,43 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         const int ci = cb + lane;
         const int cnt = ci < ncells ? s_cell[ci + 1] : 0;
         const int incl = wave_incl_scan(cnt, lane);
-        if (ci < ncells) s_cell[ci + 1] = total + incl - cnt;
+        if (ci < ncells) s_cell_w[ci + 1] = (uint16_t)(total + incl - cnt);
         total += wave_uniform(__shfl(incl, 63));
       }
       wave_lds_sync();
       if (total > CAPW) { give_up = true; break; }
       PHASE(6);
       // 2c. scatter the kept candidates; afterwards s_cell[i] = begin and s_cell[i+1] = end of cell i
-      for (int kb = 0; kb < n_keep; kb += 64 * UNR) {
-        float x[UNR][DP];
-        int cid[UNR];
-        bool on[UNR];
+      {
+        constexpr int KPL = (CAPW + 63) / 64;  // kept entries per lane (n_keep <= CAPW here)
+        int ent[KPL];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int k = kb + u * 64 + lane;
-          on[u] = k < n_keep;
-          const int e = on[u] ? s_keep[k] : 0;
-          const int idx = e >> 10;
-          cid[u] = e & 1023;
-          const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-          load_row<DP>(pts + row * DP, x[u]);
+        for (int u = 0; u < KPL; ++u) {
+          const int k = u * 64 + lane;
+          ent[u] = k < n_keep ? s_keep[k] : -1;
         }
+        wave_lds_sync();  // the kept list (inside the point stage) is in registers now: the stage may be written
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          if (on[u]) {
-            const int pos = atomicAdd(&s_cell[cid[u] + 1], 1);
-            float4 v;
-            v.x = x[u][0];
-            v.y = x[u][1];
-            v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-            v.w = 0.f;
-            s_pts[pos] = v;
+        for (int h = 0; h < KPL; h += UNR) {
+          if (h * 64 >= n_keep) break;  // (wave-uniform)
+          float x[UNR][DP];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int idx = ent[h + u] < 0 ? 0 : ent[h + u] >> 10;
+            const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
+            load_row<DP>(pts + row * DP, x[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            if (ent[h + u] >= 0) {
+              const int pos = cell_add((ent[h + u] & 1023) + 1);
+              float4 v;
+              v.x = x[u][0];
+              v.y = x[u][1];
+              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+              v.w = 0.f;
+              s_pts[pos] = v;
+            }
           }
         }
       }

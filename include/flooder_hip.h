@@ -54,7 +54,7 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "bvh_ks": samples per lane of the tree sweep (0 = auto: 1 for R <= 64, else 2);
  *   "bvh_subs": sub-tiles a tree-sweep item may be split into (default 16);
  *   "bvh_grid": persistent workgroups of the tree sweep (default 1024 = 4 per CU);
- *   "cell_grid": persistent workgroups of the cell sweep (default 512 = the 2 per CU that fit LDS);
+ *   "cell_grid": persistent workgroups of the cell sweep (default 768 = the 3 per CU that fit LDS);
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
