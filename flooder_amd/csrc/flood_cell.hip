@@ -689,7 +689,13 @@ struct CellOp {
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
                  RowSel sel, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
-      const int grid = g_cell_grid;  // persistent blocks of 4 independent waves
+      // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
+      // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
+      // measured on 1/4 and 1/8 shares of cfg 2
+      const int64_t n_chunks = ns * (((sel.list ? sel.stride : R) + CHUNK - 1) / CHUNK);
+      int64_t want = n_chunks / 48;
+      want = want < 384 ? 384 : want;
+      const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
                          weights, k1, R, ns, alpha, g_cell_exh_dense, queue, out, flag_list, flag_count, stats, sel);
       return check_launch("cell_sweep");
