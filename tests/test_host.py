@@ -165,3 +165,38 @@ def fo_complex(pts, n_lms, **kw):
     from oracle import flood_oracle as fo
     lms = pts[fo.exact_fps(pts, n_lms, 0)]
     return fo.flood_complex_oracle(pts, lms, **kw)
+
+
+def test_sample_order_gives_compact_chunks():
+    """core.sample_order: a permutation whose aligned runs of 256 / 64 rows are compact patches of the simplex
+    (the cell sweep's chunks and the tree sweep's tiles): far tighter than the grid's own order or a Morton curve."""
+    import torch
+    from flooder_amd import core
+
+    w, _, _ = core.generate_grid(30, 3, torch.device("cpu"), torch.float32)
+    order = core.sample_order(w)
+    R = w.shape[0]
+    assert sorted(order.tolist()) == list(range(R))
+    corners = np.eye(4) - 0.25
+    X = w.numpy().astype(np.float64) @ corners          # regular-simplex coordinates (hyperplane in R^4)
+
+    def box_volumes(perm, chunk):
+        out = []
+        for a in range(0, R, chunk):
+            P = X[perm[a:a + chunk]]
+            e = np.sort(P.max(0) - P.min(0))[1:]        # the three in-plane extents dominate; drop the smallest
+            out.append(float(np.prod(e + 0.03)))
+        return np.array(out)
+
+    ident = np.arange(R)
+    for chunk in (256, 64):
+        v_new, v_id = box_volumes(order, chunk), box_volumes(ident, chunk)
+        assert v_new.sum() < 0.8 * v_id.sum()
+        assert v_new.max() <= v_id.max()
+    # small tables are left alone; edges and triangles get valid permutations too
+    for ppe, d in ((30, 1), (5, 2), (30, 2), (8, 3)):
+        w, _, _ = core.generate_grid(ppe, d, torch.device("cpu"), torch.float32)
+        o = core.sample_order(w)
+        assert sorted(o.tolist()) == list(range(w.shape[0]))
+        if w.shape[0] <= 64:
+            assert o.tolist() == list(range(w.shape[0]))
