@@ -44,6 +44,9 @@ WORKLOADS = {
                  gen="gauss", n=1_000_000, dim=3, n_lms=1000, ppe=30),
     "cfg3": dict(desc="1M-point 3D noisy torus, 1k landmarks, points_per_edge 30 (BASELINE.json configs[2])",
                  gen="torus", n=1_000_000, dim=3, n_lms=1000, ppe=30),
+    "cfg5": dict(desc="16M-point 3D swiss cheese (6 voids), 4k landmarks, points_per_edge 30 (BASELINE.json configs[4], "
+                      "cloud resident in HBM)",
+                 gen="cheese", n=16_000_000, dim=3, n_lms=4000, ppe=30),
     "small": dict(desc="100k-point 3D Gaussian, 300 landmarks, points_per_edge 12 (debug)",
                   gen="gauss", n=100_000, dim=3, n_lms=300, ppe=12),
 }
@@ -61,6 +64,9 @@ def make_points(w):
         z = torch.sin(phi)
         p = torch.stack((x, y, z), dim=1)
         return p + torch.randn_like(p) * 0.02
+    if w["gen"] == "cheese":
+        from flooder_amd.synthetic import generate_swiss_cheese_points
+        return generate_swiss_cheese_points(w["n"], k=6, seed=42)[0]
     raise ValueError(w["gen"])
 
 
