@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the CPU baseline sample")
     ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
     ap.add_argument("--bvh-ks", type=int, default=None, help="samples per lane of the culled sweep (1,2,4,8)")
+    ap.add_argument("--bvh-refine-pct", type=int, default=None,
+                    help="tree sweep: cost-model threshold of the transposed refine in percent (100 = model, 1000000 = off)")
     ap.add_argument("--bvh-leaf-batch", type=int, default=None, help="exact finish: leaves fetched per step (1 or 4)")
     ap.add_argument("--cell-exh-dense", type=int, default=None,
                     help="cell sweep: most kept points a dense chunk evaluates exhaustively before it goes to the tree sweep")
@@ -127,6 +129,8 @@ def main():
 
     if args.bvh_ks is not None:
         _native.check(lib.flooder_set_option(b"bvh_ks", args.bvh_ks), "set_option")
+    if args.bvh_refine_pct is not None:
+        _native.check(lib.flooder_set_option(b"bvh_refine_pct", args.bvh_refine_pct), "set_option")
     if args.bvh_leaf_batch is not None:
         _native.check(lib.flooder_set_option(b"bvh_leaf_batch", args.bvh_leaf_batch), "set_option")
     if args.cell_exh_dense is not None:

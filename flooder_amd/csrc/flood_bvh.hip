@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
-    const int32_t* __restrict__ n_list, int seed, int subs_max, int budget,
+    const int32_t* __restrict__ n_list, int seed, int subs_max, int budget, int refine_pct,
     int32_t* __restrict__ list2, int32_t* __restrict__ count2, RowSel sel) {
   // budget > 0 (work-list mode): a wave abandons a tile after `budget` box tests, stores the minima it has
   // (valid upper bounds) and appends the tile to list2; a second pass finishes those tiles split over
@@ -214,6 +214,12 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   if (budget > 0 && n_list[0] <= 2048) budget = 1;
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
+#ifdef FLOODER_PHASE_TIMERS
+  unsigned long long tb_setup = 0, tb_node = 0, tb_skip = 0, tb_eval = 0, tb_prev = __builtin_amdgcn_s_memtime();
+#define BVH_PHASE(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tb_prev; tb_prev = t_; } while (0)
+#else
+#define BVH_PHASE(acc) do {} while (0)
+#endif
 
   // A list with no more items than waves is dealt out statically, one item per wave: 4096 waves popping an
   // almost empty queue serialise on its one address (~12 ns per atomic - 0.1 ms before any work is done).
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
       if (lane == 0) s_grp[wv][top] = 0;
     }
     bool abandoned = false;
+    BVH_PHASE(tb_setup);
     for (;;) {
       if (budget > 0 && (int)(n_leaf_test + n_node_test - tests_before) >= budget) {
         abandoned = true;
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
           const bool cand = lb * SAFE < M;
           // worth it when the per-leaf tests it replaces cost more than one pass over the tile's samples
           constexpr int PER_LEAF = KSV * 4 * DIM + 40, PER_GROUP = 64 * KSV * (4 * DIM + 3);
-          if (KSV <= 2 && __popcll(__ballot(cand)) * PER_LEAF > PER_GROUP) {
+          if (KSV <= 2 && __popcll(__ballot(cand)) * PER_LEAF * 100 > PER_GROUP * refine_pct) {
             bool need = false;
 #pragma unroll 2
             for (int src = 0; src < 64; ++src) {
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
             if (!(cand && need)) lb0 = __builtin_inff();
           }
         }
+        BVH_PHASE(tb_node);
         continue;
       }
       if constexpr (LB > 1) {
@@ -509,7 +517,11 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         }
         need |= (lbp * SAFE < best[i]);
       }
-      if (__ballot(need) == 0ull) continue;
+      if (__ballot(need) == 0ull) {
+        BVH_PHASE(tb_skip);
+        continue;
+      }
+      BVH_PHASE(tb_skip);
       ++n_leaf_eval;
       const float* cp = pts + c * (int64_t)LEAF * DP;
 #pragma unroll
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 #pragma unroll
       for (int i = 1; i < KSV; ++i) bm = __builtin_fmaxf(bm, best[i]);
       M = wave_max_f32(bm);
+      BVH_PHASE(tb_eval);
     }
 
 #pragma unroll
@@ -562,6 +575,12 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     atomicAdd(&stats[0], n_leaf_eval);
     atomicAdd(&stats[1], n_leaf_test);
     atomicAdd(&stats[2], n_node_test);
+#ifdef FLOODER_PHASE_TIMERS
+    atomicAdd(&stats[40], tb_setup);  // diagnostic build only (tools/bvh_phase.py passes a large buffer)
+    atomicAdd(&stats[41], tb_node);
+    atomicAdd(&stats[42], tb_skip);
+    atomicAdd(&stats[43], tb_eval);
+#endif
   }
 }
 
@@ -614,10 +633,13 @@ struct SweepBvhOp {
     const int grid = g_bvh_grid;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
+    // the transposed refine pays at its cost model's threshold when finishing flagged tiles and at 3x the
+    // threshold in the full sweep (cfg 3 finish 12.5 ms vs 17.0 without it; cfg 2 full tree sweep 6.4 vs 8.6 ms)
+    const int refine_pct = item_list ? g_bvh_refine_pct : 3 * g_bvh_refine_pct;
     const bool batch = item_list != nullptr && ks == 1 && g_bvh_leaf_batch > 1;
 #define FLOODER_LAUNCH_BVH(KS_, LB_)                                                                              \
   hipLaunchKernelGGL((sweep_bvh_kernel<DIM, KS_, LB_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, \
-                     k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, list2, count2, sel)
+                     k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, refine_pct, list2, count2, sel)
     if (batch) FLOODER_LAUNCH_BVH(1, 4);
     else if (ks == 1) FLOODER_LAUNCH_BVH(1, 1);
     else if (ks == 2) FLOODER_LAUNCH_BVH(2, 1);

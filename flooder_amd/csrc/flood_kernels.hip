@@ -602,6 +602,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_ks = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "bvh_refine_pct") == 0 && value >= 1) {
+    g_bvh_refine_pct = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "bvh_leaf_batch") == 0 && (value == 1 || value == 4)) {
     g_bvh_leaf_batch = value;
     return FLOODER_OK;

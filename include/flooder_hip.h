@@ -55,6 +55,9 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "bvh_subs": sub-tiles a tree-sweep item may be split into (default 16);
  *   "bvh_grid": persistent workgroups of the tree sweep (default 1024 = 4 per CU);
  *   "cell_grid": persistent workgroups of the cell sweep (default 768 = the 3 per CU that fit LDS);
+ *   "bvh_refine_pct": threshold of the tree sweep's transposed refine in percent of its cost model (100;
+ *                     the full sweep uses three times the value), "bvh_leaf_batch": leaves fetched per step
+ *                     by the work-list tree sweep (1, or 4 through LDS);
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
