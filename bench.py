@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--bvh-refine-pct", type=int, default=None,
                     help="tree sweep: cost-model threshold of the transposed refine in percent (100 = model, 1000000 = off)")
     ap.add_argument("--bvh-leaf-batch", type=int, default=None, help="exact finish: leaves fetched per step (1 or 4)")
+    ap.add_argument("--cell-exh-sparse", type=int, default=None,
+                    help="cell sweep: most kept points a chunk with an (almost) empty box evaluates exhaustively")
     ap.add_argument("--cell-exh-dense", type=int, default=None,
                     help="cell sweep: most kept points a dense chunk evaluates exhaustively before it goes to the tree sweep")
     ap.add_argument("--cell-grid", type=int, default=None, help="persistent blocks of the cell sweep")
@@ -133,6 +135,8 @@ def main():
         _native.check(lib.flooder_set_option(b"bvh_refine_pct", args.bvh_refine_pct), "set_option")
     if args.bvh_leaf_batch is not None:
         _native.check(lib.flooder_set_option(b"bvh_leaf_batch", args.bvh_leaf_batch), "set_option")
+    if args.cell_exh_sparse is not None:
+        _native.check(lib.flooder_set_option(b"cell_exh_sparse", args.cell_exh_sparse), "set_option")
     if args.cell_exh_dense is not None:
         _native.check(lib.flooder_set_option(b"cell_exh_dense", args.cell_exh_dense), "set_option")
     if args.cell_grid is not None:

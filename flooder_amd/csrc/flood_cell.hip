@@ -75,7 +75,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int exh_dense, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, RowSel sel) {
   constexpr int DP = padded_dim(DIM);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       const float c_ok = (0.999f * c) * (0.999f * c);
       // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
-      if (n_keep > (n0 * 8 >= n_keep ? exh_dense : EXH_MAX)) { give_up = true; ++g_cap; break; }
+      if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) { give_up = true; ++g_cap; break; }
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
@@ -697,7 +697,7 @@ struct CellOp {
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, g_cell_exh_dense, queue, out, flag_list, flag_count, stats, sel);
+                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, queue, out, flag_list, flag_count, stats, sel);
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");

@@ -18,6 +18,7 @@ extern int g_cell_grid;
 extern int g_cell_exh_dense;
 extern int g_bvh_leaf_batch;
 extern int g_bvh_refine_pct;
+extern int g_cell_exh_sparse;
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

@@ -610,6 +610,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_leaf_batch = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_exh_sparse") == 0 && value >= 480) {
+    g_cell_exh_sparse = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_exh_dense") == 0 && value >= 512) {
     g_cell_exh_dense = value;
     return FLOODER_OK;
