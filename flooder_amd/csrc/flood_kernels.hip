@@ -440,9 +440,7 @@ __device__ __forceinline__ uint32_t fps_winner(const unsigned long long* __restr
 __global__ __launch_bounds__(256) void fps_fast_kernel(float4* __restrict__ rows, int64_t n, int it,
                                                        unsigned long long* __restrict__ best,
                                                        int64_t* __restrict__ out_idx) {
-  const uint32_t q = fps_winner(best, it - 1);
-  const float4 c = rows[q];
-  if (blockIdx.x == 0 && threadIdx.x == 0) out_idx[it - 1] = (int64_t)q;
+  // this thread's rows first: the loads are in flight while the previous winner is reduced and fetched
   const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   float4 r[4];
 #pragma unroll
@@ -450,6 +448,9 @@ __global__ __launch_bounds__(256) void fps_fast_kernel(float4* __restrict__ rows
     const int64_t j = base + u * 256;
     r[u] = rows[j < n ? j : n - 1];
   }
+  const uint32_t q = fps_winner(best, it - 1);
+  const float4 c = rows[q];
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_idx[it - 1] = (int64_t)q;
   float bm = -1.f;
   uint32_t bi = 0xffffffffu;
 #pragma unroll
