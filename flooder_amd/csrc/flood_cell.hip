@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   // it holds and this kernel is short of them.  Two lists live inside the point stage while it holds no points:
   // the gather's frontier (first 1.5 KB, gather phase only) and the kept-candidate list of the classification
   // pass (last quarter; read completely into registers before the first point is scattered).
-  __shared__ float4 s_pts_all[4][CAPW];
+  __shared__ float4 s_pts_all[4][CAPW + 4];  // (+4: the unrolled readers run up to three entries past a list's end)
   __shared__ uint32_t s_cell_all[4][(NC + 8) / 2];
   __shared__ int s_leaf_all[4][MAXLEAF];
   static_assert(2 * MAXFRONT * sizeof(int) + CAPW * sizeof(int) <= CAPW * sizeof(float4), "aliases fit the stage");
@@ -429,11 +429,12 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #ifdef FLOODER_PHASE_TIMERS
           const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
 #endif
+          if (lane < 4) s_pts[n_st + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
           wave_lds_sync();
           for (int j = 0; j < n_st; j += 4) {
             float4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u < n_st ? j + u : n_st - 1];
+            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
 #pragma unroll
             for (int i = 0; i < SPL; ++i) {
               float bb = best[i];
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
               best[i] = bb;
             }
           }
-          n_pairs += (unsigned long long)n_st * SPL;
+          if (stats) n_pairs += (unsigned long long)n_st * SPL;
           n_st = 0;
           wave_lds_sync();
 #ifdef FLOODER_PHASE_TIMERS
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           }
         }
       }
+      if (lane < 4) s_pts[total + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
       wave_lds_sync();
       n_staged += (unsigned long long)total;
       if (attempt > 0) ++n_retries;
@@ -607,11 +609,13 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
             if (!(row_lb[rw] < b)) continue;
             const int bg = row_bg[rw];
             const int en = row_en[rw];
-            n_pairs += (unsigned long long)(en - bg);
-            for (int j = bg; j < en; j += 4) {  // 4 LDS reads in flight; repeats of the last point are harmless
+            if (stats) n_pairs += (unsigned long long)(en - bg);
+            // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
+            // the list - a minimum over more real points is still a valid upper bound, and exact once verified
+            for (int j = bg; j < en; j += 4) {
               float4 x[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u < en ? j + u : en - 1];
+              for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 float t0 = p[i][0] - x[u].x;
