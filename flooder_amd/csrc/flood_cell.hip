@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         for (int k = DIM - 1; k >= 0; --k) {
           int ck = (int)((x[k] - g0[k]) * inv_c);
           ck = ck < 0 ? 0 : (ck >= nc[k] ? nc[k] - 1 : ck);
-          id = id * nc[k] + ck;
+          id = __mul24(id, nc[k]) + ck;
         }
         return id;
       };
@@ -589,16 +589,20 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           // bounds of all rows first: independent LDS reads, one latency instead of one per row
           int row_bg[NROW], row_en[NROW];
           float row_lb[NROW];
+          // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
+          const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
+          int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
+          if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
 #pragma unroll
           for (int rw = 0; rw < NROW; ++rw) {
             int base;
             if constexpr (DIM == 3) {
               const int dy = ORD3[rw][0], dz = ORD3[rw][1];
-              base = ((ck[2] + dz) * nc[1] + (ck[1] + dy)) * nc[0] + ck[0] - 1;
+              base = base0 + dy * stride_y + dz * stride_z;
               row_lb[rw] = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
             } else {
               const int dy = ORD2[rw];
-              base = (ck[1] + dy) * nc[0] + ck[0] - 1;
+              base = base0 + dy * stride_y;
               row_lb[rw] = gap2[1][dy + 1];
             }
             row_bg[rw] = s_cell[base];
