@@ -744,7 +744,8 @@ def flood_complex(
     """
     method = SWEEP_METHOD if method is None else method
     if method == "auto":
-        method = "cell" if points.shape[1] in (2, 3) else "bvh"
+        # (the cell sweep addresses the cloud with 32-bit byte offsets: 16 B rows, below 2^28 points)
+        method = "cell" if points.shape[1] in (2, 3) and points.shape[0] < (1 << 28) - 64 else "bvh"
     if method not in ("cell", "bvh", "ball"):
         raise ValueError(f"method must be 'cell', 'bvh' or 'ball', got {method!r}")
     if method == "cell" and points.shape[1] not in (2, 3):

@@ -59,6 +59,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Row at a 32-bit BYTE offset from a wave-uniform base (the sweep's arrays stay below 4 GiB: checked at the entry
+// point): one VGPR of address arithmetic per load instead of a 64-bit multiply-add.
+template <int DP>
+__device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint32_t byte_off, float (&out)[DP]) {
+  load_row<DP>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)byte_off), out);
+}
+
 __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -252,9 +259,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         for (int u = 0; u < GB; ++u) {
           const int64_t idx = grp[u] * FAN + lane;
           hit[u] = (u < ng) && (idx < lv.count[lvl]);
-          const float* nb_ = nodes + (lv.off[lvl] + (hit[u] ? idx : 0)) * 2 * DP;
-          load_row<DP>(nb_, lo[u]);
-          load_row<DP>(nb_ + DP, hi[u]);
+          const uint32_t nb_ = (uint32_t)(lv.off[lvl] + (hit[u] ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+          load_row_at<DP>(nodes, nb_, lo[u]);
+          load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi[u]);
         }
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
@@ -313,8 +320,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         for (int u = 0; u < UNR; ++u) {  // issue all loads of the step first
           const int idx = ib + u * 64 + lane;
           in[u] = idx < n_cand0;
-          const int64_t row = in[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
-          load_row<DP>(pts + row * DP, x[u]);
+          const uint32_t row = in[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+          load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         for (int u = 0; u < UNR; ++u) {  // issue all loads of the step first
           const int idx = ib + u * 64 + lane;
           keep[u] = idx < n_cand;
-          const int64_t row = keep[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
-          load_row<DP>(pts + row * DP, x[u]);
+          const uint32_t row = keep[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+          load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           for (int u = 0; u < UNR; ++u) {
             const int idx = ib + u * 64 + lane;
             keep[u] = idx < n_cand;
-            const int64_t row = keep[u] ? (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF) : 0;
-            load_row<DP>(pts + row * DP, x[u]);
+            const uint32_t row = keep[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+            load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
           }
 #ifdef FLOODER_PHASE_TIMERS
           {
@@ -538,8 +545,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
             const int idx = ent[h + u] < 0 ? 0 : ent[h + u] >> 10;
-            const int64_t row = (int64_t)s_leaf[idx / LEAF] * LEAF + (idx % LEAF);
-            load_row<DP>(pts + row * DP, x[u]);
+            const uint32_t row = (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF);
+            load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
           }
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
@@ -732,6 +739,10 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
   if (n_simplices * (int64_t)(((row_list ? list_stride : R) + 63) / 64) > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: too many (simplex, tile) pairs");
   const Levels lv = make_levels(n_pts);
+  // the kernel addresses rows and node boxes with 32-bit byte offsets
+  if ((n_pts + FLOODER_BVH_LEAF) * (int64_t)(padded_dim(dim) * sizeof(float)) >= (1LL << 32) ||
+      total_nodes(lv) * (int64_t)(2 * padded_dim(dim) * sizeof(float)) >= (1LL << 32))
+    return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel,
                               (hipStream_t)stream);
