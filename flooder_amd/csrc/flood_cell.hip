@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       int na = 0, nb = 0, n_leaf = 0;
       bool over = false;
       // children of up to GB nodes `grp[u]` (valid for u < ng) at level lvl -> append hits to out_list
-      auto test_children = [&](int lvl, const int64_t (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
+      auto test_children = [&](int lvl, const int (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
+        const int lvl_count = (int)lv.count[lvl], lvl_off = (int)lv.off[lvl];  // (node indices fit 32 bits here)
 #ifdef FLOODER_PHASE_TIMERS
         ++d_steps;
 #endif
@@ -257,9 +258,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         float lo[GB][DP], hi[GB][DP];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-          const int64_t idx = grp[u] * FAN + lane;
-          hit[u] = (u < ng) && (idx < lv.count[lvl]);
-          const uint32_t nb_ = (uint32_t)(lv.off[lvl] + (hit[u] ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+          const int idx = grp[u] * FAN + lane;
+          hit[u] = (u < ng) && (idx < lvl_count);
+          const uint32_t nb_ = (uint32_t)(lvl_off + (hit[u] ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
           load_row_at<DP>(nodes, nb_, lo[u]);
           load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi[u]);
         }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
             if (out_n + cnt > cap) {
               over = true;
             } else {
-              if (hit[u]) out_list[out_n + lane_rank(m)] = (int)(grp[u] * FAN + lane);
+              if (hit[u]) out_list[out_n + lane_rank(m)] = grp[u] * FAN + lane;
               out_n += cnt;
             }
           }
@@ -281,14 +282,14 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         wave_lds_sync();
       };
       {
-        const int64_t g0_[GB] = {};
+        const int g0_[GB] = {};
         if (top == 0) test_children(0, g0_, 1, s_leaf, n_leaf, MAXLEAF);
         else test_children(top, g0_, 1, fa, na, MAXFRONT);
       }
       for (int lvl = top; lvl >= 1 && !over; --lvl) {
         nb = 0;
         for (int f = 0; f < na && !over; f += GB) {
-          int64_t grp[GB];
+          int grp[GB];
           const int ng = na - f < GB ? na - f : GB;
 #pragma unroll
           for (int u = 0; u < GB; ++u) grp[u] = wave_uniform(fa[f + u < na ? f + u : f]);
