@@ -594,9 +594,6 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           constexpr int NROW = DIM == 3 ? 9 : 3;
           constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
           constexpr int ORD2[3] = {0, -1, 1};
-          // bounds of all rows first: independent LDS reads, one latency instead of one per row
-          int row_bg[NROW], row_en[NROW];
-          float row_lb[NROW];
           // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
           const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
           int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
@@ -604,23 +601,22 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #pragma unroll
           for (int rw = 0; rw < NROW; ++rw) {
             int base;
+            float lb;
             if constexpr (DIM == 3) {
               const int dy = ORD3[rw][0], dz = ORD3[rw][1];
               base = base0 + dy * stride_y + dz * stride_z;
-              row_lb[rw] = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
+              lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
             } else {
               const int dy = ORD2[rw];
               base = base0 + dy * stride_y;
-              row_lb[rw] = gap2[1][dy + 1];
+              lb = gap2[1][dy + 1];
             }
-            row_bg[rw] = s_cell[base];
-            row_en[rw] = s_cell[base + 3];
-          }
-#pragma unroll
-          for (int rw = 0; rw < NROW; ++rw) {
-            if (!(row_lb[rw] < b)) continue;
-            const int bg = row_bg[rw];
-            const int en = row_en[rw];
+            if (!(lb < b)) continue;
+            // the row's outer cells are dropped too when their slab is no closer than the running minimum
+            const int first = (lb + gap2[0][0] < b) ? 0 : 1;
+            const int last = (lb + gap2[0][2] < b) ? 3 : 2;
+            const int bg = s_cell[base + first];
+            const int en = s_cell[base + last];
             if (stats) n_pairs += (unsigned long long)(en - bg);
             // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
             // the list - a minimum over more real points is still a valid upper bound, and exact once verified
