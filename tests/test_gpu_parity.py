@@ -359,3 +359,33 @@ def test_full_size_properties_1m_gaussian(dev):
     dist, _ = tree.query(samples)
     ref = dist.max(axis=1)
     assert_close_filtration(vals[pick], ref, P, "1M gaussian tetrahedra sample")
+
+
+@pytest.mark.parametrize("cloud", ["torus", "cheese"])
+def test_full_size_far_field_clouds_match_oracle_sample(dev, cloud):
+    """BASELINE cfg 3 (1 M noisy torus) and a 2 M-point slice of cfg 5 (swiss cheese): samples inside the tube /
+    the voids lie far from every point, so most of their tiles take the exact tree finish.  A random sample of
+    tetrahedra is checked against the kd-tree oracle, tetrahedra crossing the empty regions included."""
+    from scipy.spatial import KDTree
+    if cloud == "torus":
+        pts = fa.generate_noisy_torus_points_3d(1_000_000, seed=42)
+        n_lms = 1000
+    else:
+        pts = fa.generate_swiss_cheese_points(2_000_000, k=6, seed=42)[0]
+        n_lms = 1500
+    tp = pts.to(dev)
+    lms = fa.generate_landmarks(tp, n_lms, start_idx=0)
+    st = fa.flood_complex(tp, lms, return_simplex_tree=True)
+    tets = st.simplices_of_dimension(3)
+    vals = st.filtrations_of_dimension(3)
+    assert np.isfinite(vals).all()
+    P, L = pts.numpy(), lms.cpu().numpy()
+    tree = KDTree(P)
+    w, _, _ = fo.generate_grid(30, 3)
+    rng = np.random.default_rng(1)
+    big = np.argsort(-vals)[:15]                      # the farthest-reaching tetrahedra: tube interior / voids
+    pick = np.unique(np.concatenate([big, rng.choice(len(tets), size=25, replace=False)]))
+    samples = np.matmul(w[None], L[tets[pick]])
+    dist, _ = tree.query(samples)
+    assert_close_filtration(vals[pick], dist.max(axis=1), P, f"{cloud} tetrahedra sample")
+    assert float(vals[big].min()) > 5 * float(np.median(vals))    # the sample really contains far-field tetrahedra
