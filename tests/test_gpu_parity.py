@@ -389,3 +389,33 @@ def test_full_size_far_field_clouds_match_oracle_sample(dev, cloud):
     dist, _ = tree.query(samples)
     assert_close_filtration(vals[pick], dist.max(axis=1), P, f"{cloud} tetrahedra sample")
     assert float(vals[big].min()) > 5 * float(np.median(vals))    # the sample really contains far-field tetrahedra
+
+
+def test_degenerate_density_clouds_gpu(dev):
+    """Clouds that stress the cell sweep's capacity paths: a planar cloud in 3D (zero-volume chunk boxes), and two
+    tight clusters joined by a sparse bridge (chunks that overflow the LDS stage next to chunks with an empty box)."""
+    from scipy.spatial import KDTree
+    rng = np.random.default_rng(5)
+    # planar cloud embedded in 3D, landmarks lifted slightly off the plane so that the triangulation is 3D
+    xy = rng.random((60_000, 2)).astype(np.float32)
+    plane = np.concatenate([xy, np.zeros((xy.shape[0], 1), np.float32)], axis=1)
+    lift = plane[fo.exact_fps(plane, 60, 0)].copy()
+    lift[:, 2] = (rng.random(60) * 0.05).astype(np.float32)
+    # clusters + bridge
+    a = rng.normal(0.0, 0.01, (150_000, 3))
+    b = rng.normal(0.0, 0.01, (150_000, 3)) + np.array([1.0, 0.2, -0.3])
+    bridge = np.linspace(0, 1, 400)[:, None] * np.array([1.0, 0.2, -0.3]) + rng.normal(0, 0.002, (400, 3))
+    clusters = np.concatenate([a, b, bridge]).astype(np.float32)
+    for name, P, L in (("planar", plane, lift), ("clusters", clusters, clusters[fo.exact_fps(clusters, 120, 0)])):
+        st = fa.flood_complex(torch.from_numpy(P).to(dev), torch.from_numpy(L).to(dev), return_simplex_tree=True)
+        tets = st.simplices_of_dimension(3)
+        vals = st.filtrations_of_dimension(3)
+        assert np.isfinite(vals).all()
+        w, _, _ = fo.generate_grid(30, 3)
+        pick = rng.choice(len(tets), size=min(40, len(tets)), replace=False)
+        dist, _ = KDTree(P).query(np.matmul(w[None], L[tets[pick]].astype(np.float64)).astype(np.float32))
+        # tree values are monotonised: a tetrahedron's value is at least its own sweep value
+        own = dist.max(axis=1)
+        assert (vals[pick] >= own * (1 - 1e-5) - 1e-6).all(), name
+        # and equals it whenever no face exceeds it (always true here: faces are subsets of the samples)
+        assert_close_filtration(vals[pick], own, P, f"{name} tetrahedra sample")
