@@ -83,8 +83,14 @@ def filtration_order(st):
     bidx = np.empty_like(bidx_g)
     # gather boundaries of the simplices in filtration order
     starts = bptr_g[order]
-    take = np.concatenate([np.arange(s, s + c) for s, c in zip(starts.tolist(), bcount_o.tolist())]) if n else np.zeros(0, np.int64)
-    bidx = pos[bidx_g[take.astype(np.int64)]] if take.size else np.zeros(0, np.int64)
+    total = int(bptr[-1])
+    if total:
+        # entry e of the permuted boundary list belongs to simplex j = owner[e] and is its (e - bptr[j])-th face
+        owner = np.repeat(np.arange(n, dtype=np.int64), bcount_o)
+        take = starts[owner] + (np.arange(total, dtype=np.int64) - bptr[:-1][owner])
+        bidx = pos[bidx_g[take]]
+    else:
+        bidx = np.zeros(0, np.int64)
     return dims[order].astype(np.int32), filt[order], bptr, bidx.astype(np.int64), order
 
 
@@ -125,22 +131,26 @@ def reduce_pairs_python(dims: np.ndarray, bptr: np.ndarray, bidx: np.ndarray) ->
 
 
 def intervals_from_pairs(dims, filt, pair, min_persistence=0.0, persistence_dim_max=False) -> Dict[int, np.ndarray]:
-    top = int(dims.max()) if dims.size else -1
-    out: Dict[int, List[Tuple[float, float]]] = {}
-    for j in range(dims.shape[0]):
-        p = pair[j]
-        d = int(dims[j])
-        if p == -1:
-            b, e = float(filt[j]), float("inf")
-        elif p > j:
-            b, e = float(filt[j]), float(filt[p])
-        else:
-            continue
-        if d == top and not persistence_dim_max:
-            continue
-        if e - b > min_persistence:
-            out.setdefault(d, []).append((b, e))
-    return {d: np.array(v, dtype=np.float64).reshape(-1, 2) for d, v in out.items()}
+    """(birth, death) rows per dimension, in filtration order of the birth simplex: unpaired simplices give
+    essential classes (death = inf), a pair (j, p > j) gives [filt[j], filt[p]); the top dimension is left out
+    unless ``persistence_dim_max``; only intervals longer than ``min_persistence`` are kept."""
+    dims = np.asarray(dims)
+    if dims.size == 0:
+        return {}
+    filt = np.asarray(filt, dtype=np.float64)
+    pair = np.asarray(pair)
+    idx = np.arange(dims.shape[0])
+    births = (pair == -1) | (pair > idx)
+    death = np.where(pair == -1, np.inf, filt[np.where(pair >= 0, pair, 0)])
+    keep = births & (death - filt > min_persistence)
+    top = int(dims.max())
+    if not persistence_dim_max:
+        keep &= dims != top
+    out: Dict[int, np.ndarray] = {}
+    for d in np.unique(dims[keep]).tolist():
+        sel = keep & (dims == d)
+        out[int(d)] = np.stack((filt[sel], death[sel]), axis=1)
+    return out
 
 
 def persistence_pairs(st, min_persistence: float = 0.0, persistence_dim_max: bool = False) -> Dict[int, np.ndarray]:
