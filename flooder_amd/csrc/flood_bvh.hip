@@ -358,10 +358,11 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
           const bool cand = lb * SAFE < M;
           // worth it when the per-leaf tests it replaces cost more than one pass over the tile's samples
           constexpr int PER_LEAF = KSV * 4 * DIM + 40, PER_GROUP = 64 * KSV * (4 * DIM + 3);
-          if (KSV <= 2 && __popcll(__ballot(cand)) * PER_LEAF * 100 > PER_GROUP * refine_pct) {
+          if (KSV <= 2 && (int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 * 64 > (int64_t)PER_GROUP * refine_pct * per_sub) {
             bool need = false;
+            // (a split tile holds only per_sub distinct samples, in lanes 0 .. per_sub - 1)
 #pragma unroll 2
-            for (int src = 0; src < 64; ++src) {
+            for (int src = 0; src < per_sub; ++src) {
 #pragma unroll
               for (int i = 0; i < KSV; ++i) {
                 float lbp = 0.f;
