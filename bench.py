@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--bvh-refine-pct", type=int, default=None,
                     help="tree sweep: cost-model threshold of the transposed refine in percent (100 = model, 1000000 = off)")
     ap.add_argument("--bvh-leaf-batch", type=int, default=None, help="exact finish: leaves fetched per step (1 or 4)")
+    ap.add_argument("--curve", type=int, default=None, help="order of the cloud in the index: 0 Morton, 1 Hilbert (default)")
     ap.add_argument("--cell-exh-sparse", type=int, default=None,
                     help="cell sweep: most kept points a chunk with an (almost) empty box evaluates exhaustively")
     ap.add_argument("--cell-exh-dense", type=int, default=None,
@@ -135,6 +136,8 @@ def main():
         _native.check(lib.flooder_set_option(b"bvh_refine_pct", args.bvh_refine_pct), "set_option")
     if args.bvh_leaf_batch is not None:
         _native.check(lib.flooder_set_option(b"bvh_leaf_batch", args.bvh_leaf_batch), "set_option")
+    if args.curve is not None:
+        _native.check(lib.flooder_set_option(b"curve", args.curve), "set_option")
     if args.cell_exh_sparse is not None:
         _native.check(lib.flooder_set_option(b"cell_exh_sparse", args.cell_exh_sparse), "set_option")
     if args.cell_exh_dense is not None:

@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_curve = 1; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(64) void bbox_final_kernel(const float* __restrict_
 
 template <int DIM>
 __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
-                                                     const float* __restrict__ dbox, int64_t* __restrict__ codes) {
+                                                     const float* __restrict__ dbox, int64_t* __restrict__ codes,
+                                                     int curve) {
+  // curve 0: Morton (Z-order) codes; 1: Hilbert codes (Skilling's axes-to-transpose transform, then the same
+  // bit interleave) - consecutive codes are neighbours in space, so 16 consecutive points make tighter leaves
   constexpr int BITS = 63 / DIM > 21 ? 21 : 63 / DIM;
   Box box;
 #pragma unroll
@@ -113,10 +116,37 @@ __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ p
       q[k] = (uint32_t)t;
     }
     uint64_t code = 0;
+    if (curve == 1 && DIM > 1) {
+      constexpr uint32_t MTOP = 1u << (BITS - 1);
+      for (uint32_t Q = MTOP; Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
 #pragma unroll
-    for (int b = 0; b < BITS; ++b)
+        for (int k = 0; k < DIM; ++k) {
+          if (q[k] & Q) {
+            q[0] ^= P;
+          } else {
+            const uint32_t t = (q[0] ^ q[k]) & P;
+            q[0] ^= t;
+            q[k] ^= t;
+          }
+        }
+      }
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) code |= (uint64_t)((q[k] >> b) & 1u) << (b * DIM + k);
+      for (int k = 1; k < DIM; ++k) q[k] ^= q[k - 1];
+      uint32_t t = 0u;
+      for (uint32_t Q = MTOP; Q > 1u; Q >>= 1)
+        if (q[DIM - 1] & Q) t ^= Q - 1u;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) q[k] ^= t;
+      for (int b = BITS - 1; b >= 0; --b)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) code = (code << 1) | (uint64_t)((q[k] >> b) & 1u);
+    } else {
+#pragma unroll
+      for (int b = 0; b < BITS; ++b)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) code |= (uint64_t)((q[k] >> b) & 1u) << (b * DIM + k);
+    }
     codes[j] = (int64_t)code;
   }
 }
@@ -591,7 +621,7 @@ struct MortonOp {
   static int run(const float* pts, int64_t n, int ld, const float* box, int64_t* codes, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes);
+    hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes, g_curve);
     return check_launch("morton");
   }
 };

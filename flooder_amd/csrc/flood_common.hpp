@@ -19,6 +19,7 @@ extern int g_cell_exh_dense;
 extern int g_bvh_leaf_batch;
 extern int g_bvh_refine_pct;
 extern int g_cell_exh_sparse;
+extern int g_curve;
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

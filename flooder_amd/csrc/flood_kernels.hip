@@ -611,6 +611,10 @@ int flooder_set_option(const char* name, int value) {
     g_bvh_leaf_batch = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "curve") == 0 && (value == 0 || value == 1)) {
+    g_curve = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_exh_sparse") == 0 && value >= 480) {
     g_cell_exh_sparse = value;
     return FLOODER_OK;

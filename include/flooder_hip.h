@@ -58,6 +58,7 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "bvh_refine_pct": threshold of the tree sweep's transposed refine in percent of its cost model (100;
  *                     the full sweep uses three times the value), "bvh_leaf_batch": leaves fetched per step
  *                     by the work-list tree sweep (1, or 4 through LDS);
+ *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
@@ -141,8 +142,10 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
  * of core.py:140-142 without a host round trip. */
 int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* box, float* partial, void* stream);
 
-/* 64-bit Morton codes of the points relative to `box` (DEVICE, layout of flooder_bbox_f32);
- * floor(63/dim) (max 21) bits per axis.  The caller sorts the cloud by these codes. */
+/* 64-bit space-filling-curve codes of the points relative to `box` (DEVICE, layout of flooder_bbox_f32);
+ * floor(63/dim) (max 21) bits per axis.  The caller sorts the cloud by these codes.  Hilbert codes by
+ * default (option "curve" = 1; 0 = Morton / Z-order): consecutive points are neighbours in space, so the
+ * 16-point leaves of the box tree are tight - the tree sweep of cfg 2 takes 3.3 ms instead of 6.5 ms. */
 int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
                        void* stream);
 
