@@ -401,9 +401,10 @@ def cloud_box(points: torch.Tensor) -> torch.Tensor:
 
 
 class PointIndex:
-    """Morton-sorted copy of a point set plus its implicit box tree (HBM resident).
+    """Copy of a point set sorted along a space-filling curve (Hilbert by default) plus its implicit box tree
+    (HBM resident).
 
-    ``pts``   (n_pad, DP) f32: rows in Morton order, padded with +inf rows to a multiple of 16
+    ``pts``   (n_pad, DP) f32: rows in curve order, padded with +inf rows to a multiple of 16
     ``nodes`` (n_nodes, 2*DP) f32: box (lo, hi) of every node, leaves first (16 points each), then
               one level per factor 64, every level padded to a multiple of 64 nodes
     """
@@ -491,7 +492,7 @@ def _sample_order_bisect(w: np.ndarray) -> np.ndarray:
 # cost then dominates, and the step gets slower (6.4 ms vs 3.7 ms; profiles/r1_prune_experiment.json).
 PRUNE_DEFAULT = False
 PRUNE_MIN_ROWS = 1024     # sample tables smaller than this are swept whole
-PRUNE_STRIDE = 8          # every 8th sample (in Morton order of the weights) is swept first ("coarse" rows)
+PRUNE_STRIDE = 8          # every 8th sample (in the sample order of the weights) is swept first ("coarse" rows)
 PRUNE_FACE_STRIDE = 3     # ... and every 3rd sample of each lower-dimensional face, and every vertex
 PRUNE_KNN = 6
 PRUNE_MAX_COARSE = 1536
@@ -570,7 +571,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
                          stats: Optional[torch.Tensor] = None, plan: Optional["SamplePlan"] = None):
     """All simplices of one dimension against an indexed point set -> (S, F) face maxima.
 
-    sweep_bvh (plain stores into d2 bits, samples in Morton order of their weights) ->
+    sweep_bvh (plain stores into d2 bits, samples in the order given by sample_order) ->
     [reduce_hook: cross-shard MIN] -> face max (face rows remapped to the permuted sample order).
     No host synchronisation.
     """
