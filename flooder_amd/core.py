@@ -13,7 +13,9 @@ library raises ``ImportError``.  CPU tensors take the reference's CPU branch (sc
 
 Data layout in HBM (per call, ambient dimension ``dim``, padded row ``DP = 2 | 4 | 8`` floats):
 
-* ``pts``      (N, DP) f32   cloud sorted along its widest axis, rows padded (one 16 B load in 3D)
+* ``pts``      (N, DP) f32   cloud in Hilbert-curve order (``PointIndex``; ``method="ball"``: sorted along
+                               the widest axis as the reference does), rows padded (one 16 B load in 3D)
+* ``nodes``    (n_nodes, 2*DP) f32  implicit box tree over ``pts`` (16-point leaves, fan-out 64)
 * ``verts``    (S, d+1, dim) f32, ``centers`` (S, dim), ``radii`` (S,)  per dimension-d pass
 * ``weights``  (R, d+1) f32  barycentric sample weights (grid or Dirichlet)
 * ``cand``     (P_pad, DP) f32  per-simplex candidate lists (points inside the bounding ball),
@@ -307,6 +309,9 @@ def _sweep_dimension_hip(pts_pad: torch.Tensor, search: torch.Tensor, axis: int,
     R = weights.shape[0]
     dp = pts_pad.shape[1]
     n = pts_pad.shape[0]
+    if S == 0:  # (a simplex shard may be empty)
+        return (torch.empty((0, faces.n_faces), dtype=torch.float32, device=dev),
+                torch.empty((0, R), dtype=torch.float32, device=dev) if want_dist else None)
 
     verts = verts.to(torch.float32).contiguous()
     centers = centers.to(torch.float32).contiguous()
@@ -743,14 +748,6 @@ def flood_complex(
     SURVEY.md section 8 a-2); for other landmarks ``"cell"``/``"bvh"`` return the exact value of the
     reference's CPU path.
     """
-    method = SWEEP_METHOD if method is None else method
-    if method == "auto":
-        # (the cell sweep addresses the cloud with 32-bit byte offsets: 16 B rows, below 2^28 points)
-        method = "cell" if points.shape[1] in (2, 3) and points.shape[0] < (1 << 28) - 64 else "bvh"
-    if method not in ("cell", "bvh", "ball"):
-        raise ValueError(f"method must be 'cell', 'bvh' or 'ball', got {method!r}")
-    if method == "cell" and points.shape[1] not in (2, 3):
-        raise ValueError("method 'cell' supports ambient dimension 2 and 3 only")
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
     if use_triton and not _has_hip_kernels():
@@ -760,6 +757,14 @@ def flood_complex(
         )
     if points.dim() != 2 or points.shape[0] == 0:
         raise RuntimeError(f"points must be a non-empty (N, d) tensor, got shape {tuple(points.shape)}")
+    method = SWEEP_METHOD if method is None else method
+    if method == "auto":
+        # (the cell sweep addresses the cloud with 32-bit byte offsets: 16 B rows, below 2^28 points)
+        method = "cell" if points.shape[1] in (2, 3) and points.shape[0] < (1 << 28) - 64 else "bvh"
+    if method not in ("cell", "bvh", "ball"):
+        raise ValueError(f"method must be 'cell', 'bvh' or 'ball', got {method!r}")
+    if method == "cell" and points.shape[1] not in (2, 3):
+        raise ValueError("method 'cell' supports ambient dimension 2 and 3 only")
     if max_dimension is None:
         max_dimension = points.shape[1]
     if isinstance(landmarks, Integral):
@@ -804,11 +809,10 @@ def flood_complex(
         axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
     if on_gpu:
         pts32 = points.to(torch.float32)
-        order = torch.argsort(pts32[:, axis])
         dp = _native.load().flooder_padded_dim(dim)
         lm32 = landmarks.to(torch.float32)
-        if method == "ball":
-            pts_pad = _pad_rows(pts32[order], dp)
+        if method == "ball":  # the reference's formulation: cloud sorted along the widest axis (core.py:140-144)
+            pts_pad = _pad_rows(pts32[torch.argsort(pts32[:, axis])], dp)
             search = pts_pad[:, axis].contiguous()
         else:
             index = PointIndex(pts32)

@@ -1,16 +1,17 @@
 // flood_cell.hip - coverage sweep through wave-local cell grids in LDS (gfx950; dim 2 and 3).
 //
 // One WAVE owns a chunk of 256 consecutive samples of one simplex (4 per lane; the host orders the
-// barycentric weights along a Morton curve, so a chunk is a compact patch).  No workgroup barrier is
-// used anywhere: the four waves of a block are independent and each has its own LDS partition.
+// barycentric weights by recursive bisection - core.sample_order - so a chunk is a compact patch of the
+// simplex).  No workgroup barrier is used anywhere: the four waves of a block are independent and each has
+// its own LDS partition.
 //
 //   0. samples   rebuilt in registers from vertices x weights; chunk bounding box by DPP reductions.
-//   1. density   the box tree over the Morton-sorted cloud is walked breadth-first (lane = child box)
-//                for the leaves overlapping the chunk box; N0 = points inside the box gives the local
+//   1. density   the box tree over the curve-sorted (Hilbert) cloud is walked breadth-first (lane = child
+//                box) for the leaves overlapping the chunk box; N0 = points inside the box gives the local
 //                spacing h = (V / N0)^(1/3) and the first cell size c = alpha * h.
 //   2. stage     leaves overlapping the box grown by c are gathered again; their points are filtered
 //                (box grown by c, within c of every face plane of the simplex) and counting-sorted by
-//                cell into the wave's LDS partition (<= 512 points, <= 10^3 cells).
+//                cell into the wave's LDS partition (<= 480 points, <= 10^3 cells).
 //   3. query     each lane visits, for each of its samples, the 3^dim cells around it - 3^(dim-1)
 //                contiguous runs of the staged list - and keeps the minimum direct-difference d^2.
 //   4. verify    a minimum <= (0.999 c)^2 is provably the nearest neighbour (every point that close is
@@ -188,11 +189,28 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       ext = __builtin_fmaxf(ext, bhi[k] - blo[k]);
       vol *= (bhi[k] - blo[k]);
     }
-    // outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f)
-    float pn[DIM + 1][DIM], po[DIM + 1];
+    // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
+    // pn . (x - org) <= po relative to the LOCAL origin org = vertex 0 (no cancellation for clouds far from the
+    // coordinate origin).  A point within c of a sample lies within c of every such half-space; the test below
+    // allows c plus the fp32 error of the plane itself: the direction of a cross product of two edges is off by
+    // about 4 eps / sin(angle between them), which the per-plane slack pslack (8 eps / sin) times the simplex
+    // extent covers.  Needle faces (sin < 1e-4), flat simplices (height below 1e-4 of the extent: the sign of
+    // `side` is not trustworthy) and degenerate faces switch their plane off.
+    float pn[DIM + 1][DIM], po[DIM + 1], pslack[DIM + 1], org[DIM];
+    float sext2 = 0.f;  // squared extent of the simplex around org (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) org[k] = vs[k];
+    for (int j = 1; j < k1; ++j) {
+      float e2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) e2 = __builtin_fmaf(vs[j * DIM + k] - org[k], vs[j * DIM + k] - org[k], e2);
+      sext2 = __builtin_fmaxf(sext2, e2);
+    }
+    const float sext = __builtin_sqrtf(sext2);
 #pragma unroll
     for (int f = 0; f <= DIM; ++f) {
       po[f] = 3.0e38f;  // disabled plane: the test below always passes
+      pslack[f] = 0.f;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) pn[f][k] = 0.f;
     }
@@ -205,21 +223,27 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         for (int j = 0; j <= DIM; ++j)
           if (j != f) id[qq++] = j;
         float nrm[DIM];
+        float l12;  // |e1|^2 |e2|^2 (3D) or |e|^2 (2D): len2 / l12 = sin^2 of the angle between the edges
         if constexpr (DIM == 3) {
           float e1[3], e2[3];
+          float l1 = 0.f, l2 = 0.f;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             e1[k] = vs[id[1] * 3 + k] - vs[id[0] * 3 + k];
             e2[k] = vs[id[2] * 3 + k] - vs[id[0] * 3 + k];
+            l1 = __builtin_fmaf(e1[k], e1[k], l1);
+            l2 = __builtin_fmaf(e2[k], e2[k], l2);
           }
           nrm[0] = e1[1] * e2[2] - e1[2] * e2[1];
           nrm[1] = e1[2] * e2[0] - e1[0] * e2[2];
           nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
+          l12 = l1 * l2;
         } else {
           const float ex = vs[id[1] * 2 + 0] - vs[id[0] * 2 + 0];
           const float ey = vs[id[1] * 2 + 1] - vs[id[0] * 2 + 1];
           nrm[0] = ey;
           nrm[1] = -ex;
+          l12 = ex * ex + ey * ey;
         }
         float len2 = 0.f, side = 0.f;
 #pragma unroll
@@ -227,15 +251,16 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           len2 = __builtin_fmaf(nrm[k], nrm[k], len2);
           side = __builtin_fmaf(nrm[k], vs[f * DIM + k] - vs[id[0] * DIM + k], side);
         }
-        const bool ok = len2 > 1e-30f;
+        const bool ok = len2 > 1e-30f && len2 >= 1e-8f * l12 && side * side >= 1e-8f * len2 * sext2;
         const float sc = ok ? (side > 0.f ? -1.f : 1.f) / __builtin_sqrtf(len2) : 0.f;
         float off = 0.f;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
           pn[f][k] = nrm[k] * sc;
-          off = __builtin_fmaf(pn[f][k], vs[id[0] * DIM + k], off);
+          off = __builtin_fmaf(pn[f][k], vs[id[0] * DIM + k] - org[k], off);
         }
-        po[f] = ok ? off : 3.0e38f;  // degenerate face: plane test always passes
+        po[f] = ok ? off : 3.0e38f;
+        pslack[f] = ok ? 1e-6f * __builtin_sqrtf(l12 / len2) : 0.f;
       }
     }
 
@@ -359,7 +384,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         nc[k] = n;
         ncells *= n;
       }
-      const float plane_tol = c * 1.001f + 1e-6f * ext;
+      float plane_tol[DIM + 1];
+#pragma unroll
+      for (int f = 0; f <= DIM; ++f) plane_tol[f] = c * 1.001f + pslack[f] * (sext + c) + 1e-6f * sext;
       auto cell_of = [&](const float (&x)[DP]) {
         int id = 0;
 #pragma unroll
@@ -374,12 +401,15 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         bool in = true;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) in = in && (x[k] >= qlo[k]) && (x[k] <= qhi[k]);
+        float xr[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) xr[k] = x[k] - org[k];
 #pragma unroll
         for (int f = 0; f <= DIM; ++f) {
           float dd = -po[f];
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], x[k], dd);
-          in = in && (dd <= plane_tol);
+          for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], xr[k], dd);
+          in = in && (dd <= plane_tol[f]);
         }
         return in;
       };

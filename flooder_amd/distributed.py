@@ -29,7 +29,7 @@ import torch.distributed as dist
 
 from .core import flood_complex
 
-__all__ = ["shard_points", "min_reduce_hook", "global_widest_axis", "flood_complex_sharded"]
+__all__ = ["shard_points", "min_reduce_hook", "global_widest_axis", "sync_cpu_rng", "flood_complex_sharded"]
 
 
 def shard_points(points: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
@@ -63,16 +63,40 @@ def global_widest_axis(points_shard: torch.Tensor, group: Optional[dist.ProcessG
     return int(torch.argmax(hi - lo).item())
 
 
+def sync_cpu_rng(device: torch.device, group: Optional[dist.ProcessGroup] = None, src: int = 0) -> None:
+    """Give every rank rank ``src``'s global CPU generator state.
+
+    ``generate_uniform_weights`` (``core.py:405-427`` of the reference) draws the random barycentric
+    weights from the global CPU generator.  Column r of the (S, R) buffer that ``all_reduce(MIN)`` combines
+    must be the same sample point on every rank, and in ``mode="simplices"`` every rank's simplices must be
+    sampled with the weights an unsharded run would use, so the generator state is broadcast (about 5 KB)
+    before the weights are drawn: the result equals the unsharded result under rank ``src``'s seed,
+    whatever the other ranks' generators held."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    state = torch.get_rng_state()
+    buf = state.to(device) if device.type == "cuda" else state.clone()
+    dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    torch.set_rng_state(buf.cpu())
+
+
 def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, mode: str = "simplices",
                           group: Optional[dist.ProcessGroup] = None, **kwargs):
     """``flood_complex`` over all ranks of ``group``; every rank returns the full result.
 
     ``mode="simplices"``: ``points`` is the FULL cloud on every rank, simplices are interleaved over the
     ranks.  ``mode="points"``: ``points`` is this rank's shard of the cloud (``shard_points``).  The
-    landmark tensor must be identical on every rank.  Other arguments as ``flood_complex``."""
+    landmark tensor must be identical on every rank.  Other arguments as ``flood_complex``.
+
+    With ``num_rand`` the sample weights come from the global CPU generator; rank 0's generator state is
+    broadcast first (``sync_cpu_rng``), so seeding rank 0 is enough and the result equals the unsharded
+    one under that seed."""
     if not isinstance(landmarks, torch.Tensor):
         raise TypeError("flood_complex_sharded needs explicit landmark coordinates (identical on every "
                         "rank); run generate_landmarks on the full cloud first")
+    num_rand = kwargs.get("num_rand", args[2] if len(args) > 2 else None)
+    if num_rand is not None:
+        sync_cpu_rng(points.device, group)
     if mode == "points":
         axis = global_widest_axis(points, group)
         return flood_complex(points, landmarks, *args, reduce_hook=min_reduce_hook(group), sort_axis=axis,

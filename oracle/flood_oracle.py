@@ -257,6 +257,46 @@ def exact_fps(points: np.ndarray, n_lms: int, start_idx: int = 0) -> np.ndarray:
     return idx
 
 
+def check_fps(points: np.ndarray, idx: np.ndarray, rtol: float = 2e-6) -> Dict[str, float]:
+    """Replay a farthest-point selection ``idx`` in float64 and check the defining property of every pick:
+    it is a farthest point from the picks before it.  Pick i must attain the maximum of the running minimum
+    squared distance exactly (then it is what ``exact_fps`` would pick, up to the order of exact ties) or within
+    ``rtol`` relative - a float32 implementation cannot separate candidates whose float64 distances differ by
+    less than its rounding (about 1e-7 relative per distance), and on clouds of 10^7 points such near-ties do
+    occur.  Raises AssertionError otherwise.  Returns the number of exact arg-max picks (and how many of them are
+    also the FIRST index holding the maximum, ``exact_fps``' tie break: when every pick is, ``idx`` equals
+    ``exact_fps(points, len(idx), idx[0])``), the number of near-tie picks and the worst relative shortfall.  Cost: one pass over the cloud per pick (fine for a few hundred picks at
+    16 M points)."""
+    pts = np.asarray(points)
+    cols = [np.ascontiguousarray(pts[:, k], dtype=np.float64) for k in range(pts.shape[1])]
+    idx = np.asarray(idx, dtype=np.int64)
+    assert len(set(idx.tolist())) == len(idx) or pts.shape[0] < len(idx), "a point was picked twice"
+    d2 = np.full(pts.shape[0], np.inf)
+    tmp = np.empty_like(d2)
+    acc = np.empty_like(d2)
+    n_exact = n_near = n_first = 0
+    worst = 0.0
+    for i, j in enumerate(idx):
+        if i > 0:
+            m = float(d2.max())
+            got = float(d2[j])
+            if got == m:
+                n_exact += 1
+                n_first += int(j == int(np.argmax(d2)))   # exact_fps' tie break: the first index holding the max
+            else:
+                short = (m - got) / m if m > 0 else 0.0
+                assert short <= rtol, f"pick {i} (index {j}) is not a farthest point: d2 {got:.9g} vs max {m:.9g}"
+                n_near += 1
+                worst = max(worst, short)
+        acc.fill(0.0)
+        for c in cols:
+            np.subtract(c, c[j], out=tmp)
+            np.multiply(tmp, tmp, out=tmp)
+            acc += tmp
+        np.minimum(d2, acc, out=d2)
+    return dict(exact=n_exact, exact_first_index=n_first, near_ties=n_near, worst_rel_shortfall=worst)
+
+
 # --------------------------------------------------------------------------- inputs
 
 

@@ -34,7 +34,8 @@ def _worker(rank, world, port, name, out_dir, mode):
         z, kw, keys = load_e2e(name)
         pts = torch.as_tensor(z["points"])
         lms = torch.as_tensor(z["landmarks"])
-        torch.manual_seed(int(z["weight_seed"]))
+        # only rank 0 holds the seed the golden was drawn with: flood_complex_sharded broadcasts its generator state
+        torch.manual_seed(int(z["weight_seed"]) if rank == 0 else 987654321 + rank)
         if mode == "points":
             fc = flood_complex_sharded(shard_points(pts, rank, world), lms, mode="points", **kw)
         else:

@@ -1,0 +1,139 @@
+"""BASELINE.json configurations at their full sizes on one MI355X (-m gpu).
+
+cfg 2 / cfg 3 live in ``test_gpu_parity.py`` (``test_full_size_*``); here: landmark selection at 1 M / 1 k and
+16 M / 4 k against the float64 oracle, cfg 5 (16 M swiss cheese, 4 k landmarks) and cfg 4 (2 M points in 6D, 2 k
+landmarks, ``max_dimension=2``, ``points_per_edge=8``) end to end.  The reference's own large-scale checks are
+``tests/test_flooder.py:119-157`` (cross-path agreement within 1e-4) and ``:207-211`` (monotone filtration)."""
+import numpy as np
+import pytest
+import torch
+
+import flooder_amd as fa
+from flooder_amd import _native, core
+from oracle import flood_oracle as fo
+from helpers import assert_close_filtration
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    _native.load()  # fails loudly when the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _assert_fps(points_np, got_idx):
+    """Float64 replay of the selection: every pick is a farthest point (near-ties within float32 rounding
+    allowed and counted); picks that attain the float64 maximum exactly must also follow ``exact_fps``' tie break
+    (first index), so with no near-tie the selection IS ``exact_fps``' selection."""
+    rep = fo.check_fps(points_np, got_idx)
+    assert rep["exact"] + rep["near_ties"] == len(got_idx) - 1
+    assert rep["exact_first_index"] == rep["exact"], rep
+    return rep
+
+
+def test_fps_1m_1k_matches_exact_fps(dev):
+    """cfg 2's landmark selection: 1 M Gaussian points, 1000 landmarks, every pick replayed in float64."""
+    torch.manual_seed(42)
+    pts = torch.randn(1_000_000, 3)
+    got = core.fps_indices(pts.to(dev), 1000, 0).cpu().numpy()
+    rep = _assert_fps(pts.numpy(), got)
+    assert rep["near_ties"] <= 3, rep
+    assert np.array_equal(got[:48], fo.exact_fps(pts.numpy(), 48, 0))
+
+
+@pytest.fixture(scope="module")
+def cheese16m(dev):
+    pts = fa.generate_swiss_cheese_points(16_000_000, k=6, seed=42)[0]
+    tp = pts.to(dev)
+    idx = core.fps_indices(tp, 4000, 0)
+    return pts, tp, idx
+
+
+def test_cfg5_fps_16m_4k(cheese16m):
+    """cfg 5's landmark selection: the first 128 picks replayed in float64 over all 16 M points (a uniform
+    cloud of 16 M points does produce float64 near-ties below float32 resolution; they are counted, and the
+    picks are index-equal to ``exact_fps`` when there is none), all 4000 picks distinct and well separated."""
+    pts, tp, idx = cheese16m
+    got = idx.cpu().numpy()
+    assert len(set(got.tolist())) == 4000
+    _assert_fps(pts.numpy(), got[:128])
+    # FPS is a greedy 2-approximation of the k-centre problem: the picks are pairwise at least as far apart as the
+    # covering radius after the last pick (checked on the landmark set with a kd-tree, float64)
+    from scipy.spatial import cKDTree
+    L = pts.numpy()[got].astype(np.float64)
+    dd, _ = cKDTree(L).query(L, k=2)
+    sep = dd[:, 1].min()
+    rng = np.random.default_rng(0)
+    probe = pts.numpy()[rng.choice(pts.shape[0], 200_000, replace=False)].astype(np.float64)
+    cover = cKDTree(L).query(probe)[0].max()
+    assert sep >= cover * (1 - 1e-5), (sep, cover)
+
+
+def test_cfg5_full_size_16m_cheese(cheese16m, dev):
+    """BASELINE cfg 5 at full size: 16 M swiss-cheese points (five-level box tree, 256 MB cloud), 4000
+    landmarks, points_per_edge 30.  The tetrahedra reaching deepest into the voids plus a random sample are
+    compared with scipy's kd-tree over all 16 M points."""
+    from scipy.spatial import cKDTree
+    pts, tp, idx = cheese16m
+    lms = tp[idx]
+    st = fa.flood_complex(tp, lms, return_simplex_tree=True)
+    tets = st.simplices_of_dimension(3)
+    vals = st.filtrations_of_dimension(3)
+    assert len(tets) > 20_000 and np.isfinite(vals).all()
+    assert all(st.filtration([i]) == 0.0 for i in range(0, 4000, 97))
+    P, L = pts.numpy(), lms.cpu().numpy()
+    tree = cKDTree(P, balanced_tree=False, compact_nodes=False)
+    w, _, _ = fo.generate_grid(30, 3)
+    rng = np.random.default_rng(1)
+    big = np.argsort(-vals)[:15]
+    pick = np.unique(np.concatenate([big, rng.choice(len(tets), size=40, replace=False)]))
+    samples = np.matmul(w[None], L[tets[pick]])
+    dist, _ = tree.query(samples, workers=-1)
+    assert_close_filtration(vals[pick], dist.max(axis=1), P, "cfg5 tetrahedra sample")
+    assert float(vals[big].min()) > 5 * float(np.median(vals))
+    for d in (1, 2, 3):  # monotone: faces never above cofaces (tests/test_flooder.py:207-211)
+        rows = st.simplices_of_dimension(d)
+        own = st.filtrations_of_dimension(d)
+        for j in range(d + 1):
+            loc = st._locate(d - 1, np.delete(rows, j, axis=1))
+            assert (loc >= 0).all() and (st.filtrations_of_dimension(d - 1)[loc] <= own).all()
+
+
+def test_cfg4_full_size_2m_6d(dev):
+    """BASELINE cfg 4 at full size: 2 M Gaussian points in 6D, 2000 landmarks, max_dimension 2,
+    points_per_edge 8 (the tractable setting).  A sample of triangles is compared with a 6-D
+    kd-tree; edges and vertices through the monotone rule; all assigned values finite."""
+    from scipy.spatial import cKDTree
+    torch.manual_seed(42)
+    pts = torch.randn(2_000_000, 6)
+    tp = pts.to(dev)
+    lms = fa.generate_landmarks(tp, 2000, start_idx=0)
+    P = pts.numpy()
+    got_idx = core.fps_indices(tp, 2000, 0).cpu().numpy()
+    _assert_fps(P, got_idx[:64])
+    st = fa.flood_complex(tp, lms, max_dimension=2, points_per_edge=8, return_simplex_tree=True)
+    tris = st.simplices_of_dimension(2)
+    vals = st.filtrations_of_dimension(2)
+    assert len(tris) > 500_000 and np.isfinite(vals).all()
+    L = lms.cpu().numpy()
+    tree = cKDTree(P)
+    w, _, _ = fo.generate_grid(8, 2)
+    rng = np.random.default_rng(2)
+    pick = np.unique(np.concatenate([np.argsort(-vals)[:10], rng.choice(len(tris), size=60, replace=False)]))
+    samples = np.matmul(w[None], L[tris[pick]])          # (n, 36, 6)
+    dist, _ = tree.query(samples, workers=-1)
+    assert_close_filtration(vals[pick], dist.max(axis=1), P, "cfg4 triangle sample")
+    e = st.simplices_of_dimension(1)
+    ev = st.filtrations_of_dimension(1)
+    assert np.isfinite(ev).all() and (st.filtrations_of_dimension(0) == 0.0).all()
+    for j in range(3):  # monotone over all triangles
+        loc = st._locate(1, np.delete(tris, j, axis=1))
+        assert (loc >= 0).all() and (ev[loc] <= vals).all()
+    # edges: their own samples (the 8 lattice points of the edge) against the kd-tree
+    pe = rng.choice(len(e), size=80, replace=False)
+    w1 = np.linspace(0.0, 1.0, 8, dtype=np.float32)
+    seg = (1 - w1)[None, :, None] * L[e[pe, 1]][:, None, :] + w1[None, :, None] * L[e[pe, 0]][:, None, :]
+    d1, _ = tree.query(seg, workers=-1)
+    assert_close_filtration(ev[pe], d1.max(axis=1), P, "cfg4 edge sample")

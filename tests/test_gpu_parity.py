@@ -419,3 +419,28 @@ def test_degenerate_density_clouds_gpu(dev):
         assert (vals[pick] >= own * (1 - 1e-5) - 1e-6).all(), name
         # and equals it whenever no face exceeds it (always true here: faces are subsets of the samples)
         assert_close_filtration(vals[pick], own, P, f"{name} tetrahedra sample")
+
+
+def test_needle_and_sliver_simplices_cell_equals_tree(dev):
+    """Ill-conditioned simplices (near-collinear landmark triples, near-coplanar quadruples), also far from the
+    coordinate origin: the cell sweep's face-plane filter must never drop a true nearest neighbour, i.e. the cell
+    sweep equals the tree sweep (which has no such filter) bit for bit, and both match the kd-tree oracle."""
+    rng = np.random.default_rng(77)
+    for case, (offset, eps) in enumerate([(0.0, 1e-4), (0.0, 1e-6), (300.0, 1e-5), (0.0, 0.0)]):
+        cloud = rng.normal(size=(30_000, 3)).astype(np.float64)
+        t = np.linspace(-1.5, 1.5, 12)
+        line = np.stack([t, 0.3 * t, -0.2 * t], axis=1) + rng.normal(size=(12, 3)) * eps      # needles
+        u, v = np.meshgrid(np.linspace(-1, 1, 5), np.linspace(-1, 1, 5))
+        plane = np.stack([u.ravel(), v.ravel(), 0.5 + 0.1 * u.ravel()], axis=1) + rng.normal(size=(25, 3)) * eps  # slivers
+        extra = cloud[fo.exact_fps(cloud.astype(np.float32), 20, 0)]
+        lms = np.concatenate([line, plane, extra]) + offset
+        pts = np.concatenate([cloud + offset, lms]).astype(np.float32)   # landmarks are points of the cloud
+        lms = pts[-lms.shape[0]:]
+        tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
+        a = fa.flood_complex(tp, tl, points_per_edge=12, method="cell")
+        b = fa.flood_complex(tp, tl, points_per_edge=12, method="bvh")
+        assert a == b, f"case {case}"
+        ref = fo.flood_complex_oracle(pts, lms, points_per_edge=12)
+        keys = sorted(ref)
+        assert set(keys) == set(a)
+        assert_close_filtration(dict_values(a, keys), dict_values(ref, keys), pts, f"needles case {case}")
