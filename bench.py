@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the Flood-complex coverage sweep on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py                       # 1 GPU, cfg 2, 50 steps
+    python bench.py --gpus N ...          # starts its own N ranks (torch.distributed.run child, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # what the driver runs for N > 1
 
-A "step" is one full coverage sweep of the workload, as SURVEY.md section 8d defines t_sweep: from the
-sorted (here: Morton-sorted and box-tree-indexed) cloud and the simplices resident in HBM to the per-face
-filtration values in HBM - every top-dimensional Delaunay simplex of the landmarks against the whole cloud
-(sweep -> exact finish -> [all_reduce(MIN) across ranks] -> per-face maxima).  FPS, Delaunay, the cloud sort /
-index build (the counterpart of the reference's argsort, core.py:140-144) and the Python dict / SimplexTree
-hand-off are outside the step; the index build is timed separately ("ms_index_build") and
-"value_including_index_build" charges it to every step.
+A "step" is one full coverage sweep of the workload from the RAW cloud and the simplices resident in HBM to the
+per-face filtration values in HBM: index build (bounding box, Hilbert codes, radix argsort, gather, box tree - the
+counterpart of the reference's argsort, core.py:140-144, run once per flood_complex call) -> cell sweep -> exact
+finish -> [all_reduce(MIN) across ranks] -> per-face maxima.  FPS, Delaunay and the Python dict / SimplexTree
+hand-off are outside the step (t_sweep); "value_sweep_only" leaves the index build out as
+section 8d's wording ("from sorted points") would allow.
 
 value = N_points x S_top / t_step / 1e6  [M points x simplices / s], whole job over all ranks.
 With N ranks the simplices are interleaved over the ranks (every rank holds the whole cloud) and the per-face
@@ -22,13 +22,12 @@ fixed: "scaling": "strong".
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -44,15 +43,32 @@ WORKLOADS = {
                  gen="gauss", n=1_000_000, dim=3, n_lms=1000, ppe=30),
     "cfg3": dict(desc="1M-point 3D noisy torus, 1k landmarks, points_per_edge 30 (BASELINE.json configs[2])",
                  gen="torus", n=1_000_000, dim=3, n_lms=1000, ppe=30),
-    "cfg5": dict(desc="16M-point 3D swiss cheese (6 voids), 4k landmarks, points_per_edge 30 (BASELINE.json configs[4], "
-                      "cloud resident in HBM)",
+    "cfg5": dict(desc="16M-point 3D swiss cheese (6 voids), 4k landmarks, points_per_edge 30 (BASELINE.json "
+                      "configs[4]; cloud resident in HBM: 256 MB of 288 GB - host-pinned streaming is not needed, "
+                      "the H2D copy is reported as h2d_ms)",
                  gen="cheese", n=16_000_000, dim=3, n_lms=4000, ppe=30),
     "small": dict(desc="100k-point 3D Gaussian, 300 landmarks, points_per_edge 12 (debug)",
                   gen="gauss", n=100_000, dim=3, n_lms=300, ppe=12),
 }
 
+KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "fallback": "sweep_bvh_kernel (exact finish)",
+                  "face_max": "face_max_kernel", "reduce": "all_reduce(MIN)", "index": "index build",
+                  "ball_count": "ball_scan_kernel<count>", "ball_fill": "ball_scan_kernel<fill>"}
+
+
+def kernel_source_sha() -> str:
+    """Fingerprint of the kernel sources: profiles/traffic.json entries carry the value they were measured with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "flooder_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def make_points(w):
+    import torch
+
     torch.manual_seed(42)
     if w["gen"] == "gauss":
         return torch.randn(w["n"], w["dim"])
@@ -70,27 +86,14 @@ def make_points(w):
     raise ValueError(w["gen"])
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the CPU baseline sample")
-    ap.add_argument("--variant", type=int, default=None, help="sweep_variant option of the library")
-    ap.add_argument("--bvh-ks", type=int, default=None, help="samples per lane of the culled sweep (1,2,4,8)")
-    ap.add_argument("--bvh-refine-pct", type=int, default=None,
-                    help="tree sweep: cost-model threshold of the transposed refine in percent (100 = model, 1000000 = off)")
-    ap.add_argument("--bvh-leaf-batch", type=int, default=None, help="exact finish: leaves fetched per step (1 or 4)")
-    ap.add_argument("--curve", type=int, default=None, help="order of the cloud in the index: 0 Morton, 1 Hilbert (default)")
-    ap.add_argument("--cell-exh-sparse", type=int, default=None,
-                    help="cell sweep: most kept points a chunk with an (almost) empty box evaluates exhaustively")
-    ap.add_argument("--cell-exh-dense", type=int, default=None,
-                    help="cell sweep: most kept points a dense chunk evaluates exhaustively before it goes to the tree sweep")
-    ap.add_argument("--cell-grid", type=int, default=None, help="persistent blocks of the cell sweep")
-    ap.add_argument("--bvh-grid", type=int, default=None, help="persistent blocks of the tree sweep")
-    ap.add_argument("--bvh-subs", type=int, default=None, help="waves per flagged tile in the exact finish")
+    ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the 1-core CPU baseline sample")
     ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
@@ -100,60 +103,74 @@ def main():
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
-    args = ap.parse_args()
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
+                    help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
+    return ap.parse_args()
 
-    import torch.distributed as dist
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD torch.distributed.run before this
+    process has touched the GPU (a GPU-initialised process must never exec another program)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # (test rigs may put several ranks on one GPU)
+    n_dev = max(torch.cuda.device_count(), 1)
+    shared_gpu = world > n_dev          # test rigs may put several ranks on one GPU (then gloo, RCCL refuses)
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("FLOODER_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("FLOODER_DIST_BACKEND", "gloo" if shared_gpu else "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    else:
+        backend = None
 
     import flooder_amd as fa
     from flooder_amd import _native, core
     from flooder_amd.distributed import min_reduce_hook
 
     lib = _native.load()  # no fallback: fails here if the HIP library is missing
-    if args.variant is not None:
-        _native.check(lib.flooder_set_option(b"sweep_variant", args.variant), "set_option")
-
-    if args.bvh_ks is not None:
-        _native.check(lib.flooder_set_option(b"bvh_ks", args.bvh_ks), "set_option")
-    if args.bvh_refine_pct is not None:
-        _native.check(lib.flooder_set_option(b"bvh_refine_pct", args.bvh_refine_pct), "set_option")
-    if args.bvh_leaf_batch is not None:
-        _native.check(lib.flooder_set_option(b"bvh_leaf_batch", args.bvh_leaf_batch), "set_option")
-    if args.curve is not None:
-        _native.check(lib.flooder_set_option(b"curve", args.curve), "set_option")
-    if args.cell_exh_sparse is not None:
-        _native.check(lib.flooder_set_option(b"cell_exh_sparse", args.cell_exh_sparse), "set_option")
-    if args.cell_exh_dense is not None:
-        _native.check(lib.flooder_set_option(b"cell_exh_dense", args.cell_exh_dense), "set_option")
-    if args.cell_grid is not None:
-        _native.check(lib.flooder_set_option(b"cell_grid", args.cell_grid), "set_option")
-    if args.bvh_grid is not None:
-        _native.check(lib.flooder_set_option(b"bvh_grid", args.bvh_grid), "set_option")
-    if args.bvh_subs is not None:
-        _native.check(lib.flooder_set_option(b"bvh_subs", args.bvh_subs), "set_option")
+    for opt in args.option:
+        name, val = opt.split("=")
+        _native.check(lib.flooder_set_option(name.encode(), int(val)), f"set_option {opt}")
     if args.alpha is not None:
         core.CELL_ALPHA = args.alpha
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
+    torch.cuda.synchronize()
+    t_h0 = time.perf_counter()
     pts_full = pts_cpu.to(dev)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t_h0) * 1e3     # pageable host memory -> HBM, once per call (not in the step)
     fa.generate_landmarks(pts_full, 8, start_idx=0)  # warm-up
     torch.cuda.synchronize()
     t_fps0 = time.perf_counter()
@@ -206,27 +223,20 @@ def main():
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
     plan = core.SamplePlan(weights, faces)
 
-    def build_index():
-        if args.method in ("cell", "bvh"):
-            return core.PointIndex(shard_raw)
-        o = torch.argsort(shard_raw[:, axis])
-        pts_pad = core._pad_rows(shard_raw[o], dp)
-        return (pts_pad, pts_pad[:, axis].contiguous())
-
-    # the sort / index build: once per flood_complex call, like the reference's argsort (timed on its own)
-    index = build_index()
-    torch.cuda.synchronize()
-    t_i0 = time.perf_counter()
-    for _ in range(5):
-        index = build_index()
-    torch.cuda.synchronize()
-    ms_index = (time.perf_counter() - t_i0) / 5 * 1e3
+    def build_index(timer=None):
+        with core._span(timer, "index"):
+            if args.method in ("cell", "bvh"):
+                return core.PointIndex(shard_raw)
+            o = torch.argsort(shard_raw[:, axis])
+            pts_pad = core._pad_rows(shard_raw[o], dp)
+            return (pts_pad, pts_pad[:, axis].contiguous())
 
     def step(timer=None, with_stats=False):
-        """indexed cloud + simplices in HBM -> per-face filtration values in HBM (t_sweep).
-        The work counters are collected by ONE extra, untimed step: flood_complex() never asks for them, and
-        thousands of waves adding to the same few words cost ~0.1 ms."""
+        """raw cloud + simplices in HBM -> per-face filtration values in HBM.  The work counters are collected by
+        ONE extra, untimed step: flood_complex() never asks for them, and thousands of waves adding to the same
+        few words cost ~0.1 ms."""
         core.LAST_STATS.reset()
+        index = build_index(timer)
         st = stats if with_stats else None
         if args.method == "cell":
             stats.zero_()
@@ -258,9 +268,12 @@ def main():
         out = step()
     sync_all()
     timer = core._KernelTimer()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # on the launch stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step(timer)
+        marks[i + 1].record()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -269,50 +282,71 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = w["n"] * S_all / (elapsed / args.steps) / 1e6
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
 
     out = step(None, with_stats=True)  # untimed: work counters for the report
     torch.cuda.synchronize()
 
-    # ------------------------------------------------------------------ per-kernel numbers
-    k_ms = timer.totals_ms()
-    k_n = timer.counts()
-    sweep_ms = k_ms["sweep"] / k_n["sweep"]
-    slab_local = core.LAST_STATS.slab_points
-    # algorithmic bytes of one sweep launch on this rank: every candidate row read
-    # once per simplex, vertices, weights, and the (S, R) minimum buffer written once
+    # ------------------------------------------------------------------ per-kernel numbers (rank 0's share)
+    k_ms = {k: v / args.steps for k, v in timer.totals_ms().items()}   # HIP events on the launch stream
+    ms_index = k_ms.get("index", 0.0)
+    ms_sweep_only = ms_per_step - ms_index
+    # algorithmic bytes of one step on this rank: every candidate row read once per
+    # simplex (P x 4 x dim), vertices, weights, and the (S, R) minimum buffer written once
     alg_bytes = P_local * w["dim"] * 4 + S * (d + 1) * w["dim"] * 4 + R * (d + 1) * 4 + S * R * 4
-    achieved_gbs = alg_bytes / (sweep_ms * 1e-3) / 1e9
     pair_evals = P_local * R                       # what the reference's formulation evaluates
+    st_h = None
+    per_kernel = {}                                # span -> dict(pairs, share of the step's units)
     if args.method == "bvh":
-        st_h = stats.cpu().tolist()
-        ks = args.bvh_ks or (2 if R > 64 else 1)
-        done_evals = st_h[0] * 16 * 64 * ks        # leaves evaluated x 16 points x tile samples
-        st_h = {"leaves_evaluated": st_h[0], "leaves_tested": st_h[1], "nodes_expanded": st_h[2]}
+        sh = stats.cpu().tolist()
+        ks = 2 if R > 64 else 1
+        per_kernel["sweep"] = dict(pairs=sh[0] * 16 * 64 * ks, share=1.0)
+        st_h = {"leaves_evaluated": sh[0], "leaves_tested": sh[1], "nodes_expanded": sh[2]}
     elif args.method == "cell":
-        st_h = stats.cpu().tolist()
-        done_evals = st_h[0] + st_h[9] * 16 * 64
-        st_h = {"cell_pairs": st_h[0], "points_staged": st_h[1], "tiles_flagged": st_h[2],
-                "restage_rounds": st_h[3], "tiles_total": S * ((R + 63) // 64),
+        sh = stats.cpu().tolist()
+        tiles_total = S * ((R + 63) // 64)
+        flagged = sh[2]
+        per_kernel["sweep"] = dict(pairs=sh[0], share=(tiles_total - flagged) / max(tiles_total, 1))
+        per_kernel["fallback"] = dict(pairs=sh[9] * 16 * 64, share=flagged / max(tiles_total, 1))
+        st_h = {"cell_pairs": sh[0], "points_staged": sh[1], "tiles_flagged": sh[2],
+                "restage_rounds": sh[3], "tiles_total": tiles_total,
                 "chunks_total": S * ((R + 255) // 256),
-                "giveup_gather_density": st_h[4], "giveup_gather_stage": st_h[5], "giveup_lds_full": st_h[6],
-                "giveup_doublings": st_h[7], "exhaustive_rounds": st_h[8],
-                "fallback_leaves_evaluated": st_h[9], "fallback_leaves_tested": st_h[10],
-                "fallback_nodes_expanded": st_h[11], "fallback_max_tests_one_tile": st_h[12],
-                "fine_rows_swept": st_h[13], "fine_rows_total": st_h[14]}
+                "giveup_gather_density": sh[4], "giveup_gather_stage": sh[5], "giveup_lds_full": sh[6],
+                "giveup_doublings": sh[7], "exhaustive_rounds": sh[8],
+                "fallback_leaves_evaluated": sh[9], "fallback_leaves_tested": sh[10],
+                "fallback_nodes_expanded": sh[11], "fallback_max_tests_one_tile": sh[12],
+                "fine_rows_swept": sh[13], "fine_rows_total": sh[14]}
     else:
-        st_h = None
-        done_evals = pair_evals
-    valu_tflops = 10.0 * done_evals / (sweep_ms * 1e-3) / 1e12  # 3d+1 flop per evaluated pair, d = 3
+        per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)
+    done_evals = sum(v["pairs"] for v in per_kernel.values())
+    kernels = {}
+    for span, ms in sorted(k_ms.items(), key=lambda kv: -kv[1]):
+        rec = {"kernel": KERNEL_OF_SPAN.get(span, span), "ms_per_step": round(ms, 4)}
+        if span in per_kernel and ms > 0:
+            pk = per_kernel[span]
+            gbs = alg_bytes * pk["share"] / (ms * 1e-3) / 1e9
+            tf = 10.0 * pk["pairs"] / (ms * 1e-3) / 1e12       # 3d+1 flop per evaluated pair, d = 3
+            rec.update({"unit_share": round(pk["share"], 5), "algorithmic_GBs": round(gbs, 2),
+                        "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "pairs_evaluated": int(pk["pairs"]),
+                        "valu_TFLOPs": round(tf, 2), "valu_frac": round(tf / VALU_PEAK_TFLOPS, 4)})
+        kernels[span] = rec
+    dom = max((s for s in k_ms if s in per_kernel), key=lambda s: k_ms[s])      # dominant compute kernel
+    dom_rec = kernels[dom]
+    step_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
 
-    # measured HBM traffic of the dominant kernel (rocprofv3 PMC passes, tools/collect_profiles.sh ->
-    # profiles/traffic.json; FETCH_SIZE doubled for 16 B/lane loads as MI355X_MICROARCH.md prescribes)
-    traffic = None
+    # measured HBM traffic and issue utilisation of the dominant kernel: rocprofv3 PMC passes
+    # (tools/collect_profiles.sh -> profiles/traffic.json), valid only for the kernel sources they were taken with
+    traffic = traffic_src = issue_util = None
     try:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.workload}:{args.method}", {}).get("bytes_per_launch")
+            ent = json.load(open(tpath)).get(f"{args.workload}:{args.method}:{dom}")
+            if ent and ent.get("kernel_src_sha") == kernel_source_sha():
+                traffic, traffic_src, issue_util = ent.get("bytes_per_launch"), ent.get("source"), ent.get("issue_util")
+            elif ent:
+                traffic_src = f"stale ({ent.get('source')} was measured with other kernel sources)"
     except Exception:
-        traffic = None
+        pass
     result = {
         "metric": "M points×simplices/s (coverage sweep)",
         "value": round(value, 3),
@@ -320,9 +354,14 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "ms_index_build": round(ms_index, 3),
-        "value_including_index_build": round(w["n"] * S_all / ((ms_per_step + ms_index) * 1e-3) / 1e6, 3),
+        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_mean": round(float(step_ms.mean()), 4),
+        "ms_per_step_std": round(float(step_ms.std()), 4),
+        "ms_per_step_min": round(float(step_ms.min()), 4),
+        "ms_index_build": round(ms_index, 4),
+        "value_sweep_only": round(w["n"] * S_all / (ms_sweep_only * 1e-3) / 1e6, 3),
+        "step_definition": "raw cloud + simplices in HBM -> index build (Hilbert sort + box tree) -> sweep -> exact "
+                           "finish -> [all_reduce] -> per-face values in HBM; value_sweep_only leaves the index build out",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -332,24 +371,33 @@ def main():
             "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S_all,
             "top_simplices_rank0": S,
             "samples_per_simplex": R, "candidate_pairs_rank0": P_local, "pair_evals_rank0": pair_evals,
-            "ball_tests_rank0": slab_local, "parallelism": (f"{args.shard}-shard x{world}" if world > 1 else "single GPU"),
-            "method": args.method, "pair_evals_done_rank0": done_evals,
+            "parallelism": (f"{args.shard}-shard x{world} ({backend})" if world > 1 else "single GPU"),
+            "method": args.method, "pair_evals_done_rank0": int(done_evals),
             "sweep_stats_rank0": st_h,
             "sweep_stats_note": "work counters come from one extra untimed step (the timed steps run without them, as flood_complex does)",
+            "h2d_ms": round(h2d_ms, 3),
         },
+        # the metric's roofline (BASELINE.json asks for HBM GB/s): algorithmic bytes of the dominant kernel's
+        # share of the step / that kernel's average launch duration.  The kernel is NOT HBM-bound (SURVEY.md 8d:
+        # the path is arithmetic/latency-bound): "limiter" says what binds it, "valu" gives that roofline.
         "roofline": {
-            "kernel": {"cell": "cell_sweep_kernel", "bvh": "sweep_bvh_kernel", "ball": "sweep_kernel"}[args.method], "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "algorithmic_bytes": alg_bytes, "avg_launch_ms": round(sweep_ms, 4),
+            "kernel": dom_rec["kernel"], "bound": "hbm", "achieved": dom_rec["algorithmic_GBs"],
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_rec["hbm_frac"], "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes": int(alg_bytes * dom_rec["unit_share"]), "avg_launch_ms": dom_rec["ms_per_step"],
+            "limiter": "VALU issue + dependent-latency chains (occupancy-limited by LDS), not HBM",
+            "issue_util": issue_util,
+            "valu": {"achieved": dom_rec["valu_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dom_rec["valu_frac"], "flop_per_pair": 10, "pairs": dom_rec["pairs_evaluated"]},
+            "step": {"algorithmic_bytes": int(alg_bytes), "ms": round(ms_per_step, 4),
+                     "achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5)},
             "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + (S,R) minima "
-                    "(SURVEY.md 8d); the kernel itself is fp32-VALU/latency-bound, see valu",
-            "valu": {"achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flop_per_pair": 10},
+                    "(SURVEY.md 8d), apportioned to a kernel by the share of (simplex, sample) units it resolves",
         },
+        "kernels": kernels,
         "emulated_shard": args.emulate_shard,
-        "kernels_ms_per_step": {k: round(v / args.steps, 4) for k, v in k_ms.items()},
-        # landmark selection (generate_landmarks, outside the step): one distance-update + arg-max sweep of
-        # the cloud per landmark; algorithmic bytes = (4*dim + 8) B per point and iteration
+        # landmark selection (generate_landmarks, outside the step): algorithmic bytes of the brute-force
+        # formulation = (4*dim + 8) B per point and iteration
         "fps": {"points": w["n"], "landmarks": w["n_lms"], "ms": round(t_fps * 1e3, 3),
                 "us_per_landmark": round(t_fps / w["n_lms"] * 1e6, 3),
                 "algorithmic_GBs": round((4 * w["dim"] + 8) * w["n"] * w["n_lms"] / t_fps / 1e9, 1),
@@ -360,8 +408,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import flood_oracle as fo
 
-        cb = fo.kdtree_sweep_sample(pts_cpu.numpy(), lms.cpu().numpy(), simp.cpu().numpy(), w["ppe"], d,
-                                    n_sample=min(args.cpu_sample, S_all), seed=0, workers=1)
+        P_np, L_np, simp_np = pts_cpu.numpy(), lms.cpu().numpy(), simp.cpu().numpy()
+        cb = fo.kdtree_sweep_sample(P_np, L_np, simp_np, w["ppe"], d, n_sample=min(args.cpu_sample, S_all), seed=0,
+                                    workers=1)
         got = out.cpu().numpy()[cb["picked"]]
         ref = cb["face_max"]
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6 * float(pts_cpu.abs().max()))
@@ -375,6 +424,14 @@ def main():
         result["parity"] = {"checked_simplices": int(cb["n_sample"]), "values": int(got.size),
                             "max_abs_err": float(np.abs(got - ref).max()),
                             "max_rel_err": float(rel.max())}
+        n_all = min(S_all, max(args.cpu_sample, 6000))
+        ca = fo.kdtree_sweep_sample(P_np, L_np, simp_np, w["ppe"], d, n_sample=n_all, seed=1, workers=-1)
+        all_value = w["n"] * ca["n_sample"] / (ca["query_s"] + ca["build_s"] * ca["n_sample"] / S_all) / 1e6
+        result["cpu_baseline_all_cores"] = {
+            "value": round(all_value, 4), "unit": "M points×simplices/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"same sweep with scipy workers=-1 on {ca['n_sample']} of {S_all} tetrahedra; tree build "
+                      f"{ca['build_s']:.2f}s (single-threaded, charged pro rata), query {ca['query_s']:.2f}s",
+        }
 
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False))

@@ -1,15 +1,28 @@
-"""Turn gpurun_out/prof_final_<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/:
+   profiles/<name>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (average duration per kernel)
+   profiles/<name>_pmc.json           mean counter values per launch and kernel (separate --pmc passes)
+   profiles/<name>_bench_under_rocprof.json   the bench line of the traced run
+   profiles/traffic.json              what bench.py quotes: HBM bytes per launch (FETCH_SIZE x 2 for 16 B/lane loads,
+                                      as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and the VALU issue
+                                      utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz),
+                                      tagged with the fingerprint of the kernel sources they were measured with."""
 import csv, glob, collections, json, os, shutil, sys
 
+sys.path.insert(0, ".")
+from bench import kernel_source_sha
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-name = sys.argv[2] if len(sys.argv) > 2 else f"r1_final_{tag}"
-src = f"gpurun_out/prof_final_{tag}"
+name = sys.argv[2] if len(sys.argv) > 2 else f"r2_{tag}"
+src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")[0]
+stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{name}_kernel_stats.csv")
+avg_ns = {}
+for row in csv.DictReader(open(stats)):
+    avg_ns[row["Name"]] = float(row["AverageNs"])
 out = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    files = glob.glob(f"{src}/{sub}/runc/*_counter_collection.csv")
+    files = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")
     if not files:
         continue
     agg = collections.defaultdict(list)
@@ -20,17 +33,27 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
             key = k.split("(anonymous namespace)::")[1].split("(")[0]
             out.setdefault(key, {})[c + "_mean_per_launch"] = round(sum(v) / len(v), 1)
             out[key]["launches_profiled"] = len(v)
+for k, ns in avg_ns.items():
+    if "anonymous namespace" in k:
+        key = k.split("(anonymous namespace)::")[1].split("(")[0]
+        if key in out:
+            out[key]["avg_duration_us_kernel_trace"] = round(ns / 1e3, 2)
 json.dump(out, open(f"profiles/{name}_pmc.json", "w"), indent=1)
-# traffic table used by bench.py: HBM bytes per launch of the dominant kernel, corrected as
-# MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE (KB) under-reports wide 16 B/lane loads by 2x,
-# WRITE_SIZE (KB) is exact
 traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
-for kern, method in (("cell_sweep_kernel<3>", "cell"), ("sweep_bvh_kernel<3, 8>", "bvh"), ("sweep_kernel<3, true>", "ball")):
+sha = kernel_source_sha()
+for kern, method, span in (("cell_sweep_kernel<3>", "cell", "sweep"), ("sweep_bvh_kernel<3, 1, 1>", "cell", "fallback"),
+                           ("sweep_bvh_kernel<3, 2, 1>", "bvh", "sweep"), ("sweep_kernel<3, true>", "ball", "sweep")):
     if kern in out and "FETCH_SIZE_mean_per_launch" in out[kern]:
         f, w = out[kern]["FETCH_SIZE_mean_per_launch"], out[kern].get("WRITE_SIZE_mean_per_launch", 0.0)
-        traffic[f"{tag}:{method}"] = {"kernel": kern, "fetch_size_kb": f, "write_size_kb": w, "fetch_correction": 2.0,
-                                      "bytes_per_launch": int((2.0 * f + w) * 1024),
-                                      "source": f"profiles/{name}_pmc.json"}
+        ent = {"kernel": kern, "fetch_size_kb": f, "write_size_kb": w, "fetch_correction": 2.0,
+               "bytes_per_launch": int((2.0 * f + w) * 1024), "source": f"profiles/{name}_pmc.json",
+               "kernel_src_sha": sha}
+        us = out[kern].get("avg_duration_us_kernel_trace")
+        valu = out[kern].get("SQ_INSTS_VALU_mean_per_launch")
+        if us and valu:
+            ent["issue_util"] = round(valu * 2.0 / (1024 * us * 1e-6 * 2.4e9), 4)
+            ent["issue_util_note"] = "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz)"
+        traffic[f"{tag}:{method}:{span}"] = ent
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 bench = f"{src}/bench_trace.json"
 if os.path.exists(bench):
