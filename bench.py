@@ -103,6 +103,10 @@ def parse_args():
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
+    ap.add_argument("--order", default="axis", choices=["axis", "ball", "weight"],
+                    help="queue order of the simplices: axis (sorted along the widest axis, as the reference), ball "
+                         "(experiment: reference candidate count, descending), weight (core.simplex_order)")
+    ap.add_argument("--unfused", action="store_true", help="sweep -> finish -> face_max over the full (S, R) buffer")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
     return ap.parse_args()
@@ -163,6 +167,8 @@ def main():
         _native.check(lib.flooder_set_option(name.encode(), int(val)), f"set_option {opt}")
     if args.alpha is not None:
         core.CELL_ALPHA = args.alpha
+    if args.unfused:
+        core.FUSED_FACES = False
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
@@ -188,6 +194,26 @@ def main():
     weights, vertex_idxs, face_idxs = core.generate_grid(w["ppe"], d, dev, torch.float32)
     faces = core._FaceTable(face_idxs, weights.shape[0], dev)
     S_all = verts.shape[0]
+    dp = lib.flooder_padded_dim(w["dim"])
+
+    # reference-defined work of this input (untimed): candidate pairs per simplex |X n ball_s| (core.py:156-217)
+    pts_pad0 = core._pad_rows(pts_full[torch.argsort(pts_full[:, axis])], dp)
+    search0 = pts_pad0[:, axis].contiguous()
+    lo0 = torch.searchsorted(search0, (centers[:, axis] - radii).contiguous(), right=False)
+    hi0 = torch.searchsorted(search0, (centers[:, axis] + radii).contiguous(), right=True)
+    cnt0 = torch.zeros(S_all, dtype=torch.int32, device=dev)
+    _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad0), pts_pad0.shape[0], w["dim"], dp,
+                                             _native.ptr(centers.contiguous()), _native.ptr(radii.contiguous()),
+                                             _native.ptr(lo0), _native.ptr(hi0), S_all, _native.ptr(cnt0),
+                                             _native.current_stream_ptr(dev)), "ball_count")
+    del pts_pad0, search0, lo0, hi0
+    if args.order == "ball":  # experiment: heaviest simplices (by the reference's candidate count) first
+        perm = torch.argsort(cnt0, descending=True)
+        verts, centers, radii, simp, cnt0 = verts[perm], centers[perm], radii[perm], simp[perm], cnt0[perm]
+    elif args.order == "weight":  # the product's order: core.simplex_order (device-side estimate, untimed here)
+        perm = core.simplex_order(core.PointIndex(pts_full), verts)
+        verts, centers, radii, simp, cnt0 = verts[perm], centers[perm], radii[perm], simp[perm], cnt0[perm]
+
     if world > 1 and args.shard == "points":
         order_p = torch.argsort(pts_full[:, axis])
         shard_raw = pts_full[order_p][rank::world].contiguous()  # this rank's interleaved share (raw rows)
@@ -204,22 +230,11 @@ def main():
         face_hook = lambda t: t  # noqa: E731  (the 360 KB all_reduce is not emulated)
     if mine is not None:
         verts, centers, radii = verts[mine].contiguous(), centers[mine].contiguous(), radii[mine].contiguous()
-    dp = lib.flooder_padded_dim(w["dim"])
+        cnt0 = cnt0[mine]
     del pts_full
     S, R = verts.shape[0], weights.shape[0]
-
-    # reference-defined work of this input (untimed): candidate pairs P = sum_s |X n ball_s|
-    pts_pad0 = core._pad_rows(shard_raw[torch.argsort(shard_raw[:, axis])], dp)
-    search0 = pts_pad0[:, axis].contiguous()
-    lo0 = torch.searchsorted(search0, (centers[:, axis] - radii).contiguous(), right=False)
-    hi0 = torch.searchsorted(search0, (centers[:, axis] + radii).contiguous(), right=True)
-    cnt0 = torch.zeros(S, dtype=torch.int32, device=dev)
-    _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad0), pts_pad0.shape[0], w["dim"], dp,
-                                             _native.ptr(centers.contiguous()), _native.ptr(radii.contiguous()),
-                                             _native.ptr(lo0), _native.ptr(hi0), S, _native.ptr(cnt0),
-                                             _native.current_stream_ptr(dev)), "ball_count")
-    P_local = int(cnt0.sum().item())
-    del pts_pad0, search0, lo0, hi0, cnt0
+    P_local = int(cnt0.sum().item()) if not (world > 1 and args.shard == "points") else int(cnt0.sum().item()) // world
+    del cnt0
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
     plan = core.SamplePlan(weights, faces)
 
@@ -315,7 +330,9 @@ def main():
                 "giveup_doublings": sh[7], "exhaustive_rounds": sh[8],
                 "fallback_leaves_evaluated": sh[9], "fallback_leaves_tested": sh[10],
                 "fallback_nodes_expanded": sh[11], "fallback_max_tests_one_tile": sh[12],
-                "fine_rows_swept": sh[13], "fine_rows_total": sh[14]}
+                "finish_tiles_dropped_on_arrival": sh[13], "finish_samples_live_on_arrival": sh[14],
+                "finish_focus_rounds": sh[15],
+                "fused_faces": bool(core.FUSED_FACES)}
     else:
         per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)
     done_evals = sum(v["pairs"] for v in per_kernel.values())

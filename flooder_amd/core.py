@@ -441,6 +441,21 @@ class PointIndex:
                           "flooder_bvh_build_f32")
 
 
+def simplex_order(index: "PointIndex", verts: torch.Tensor) -> torch.Tensor:
+    """Work order of the simplices for the culled sweeps: descending estimated number of cloud points inside the
+    simplex's bounding box (``flooder_simplex_weight_f32``).  Work per simplex is heavy-tailed - a tetrahedron in
+    the dense core of a Gaussian cloud takes 100x the median - and the persistent kernels pop simplices in queue
+    order, so the long ones go first and the short ones fill the tail.  Device-side, no synchronisation."""
+    lib = _native.load()
+    verts = verts.to(torch.float32).contiguous()
+    S, k1, _ = verts.shape
+    wgt = torch.empty(S, dtype=torch.float32, device=verts.device)
+    _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts), k1, S,
+                                                 _native.ptr(wgt), _native.current_stream_ptr(verts.device)),
+                  "flooder_simplex_weight_f32")
+    return torch.argsort(wgt, descending=True)
+
+
 def sample_order(weights: torch.Tensor) -> np.ndarray:
     """Permutation that groups the barycentric samples into compact patches: recursive bisection along the
     widest axis (coordinates of the regular simplex), cutting at multiples of 256, then 64, then 16 samples.
@@ -548,6 +563,13 @@ class SamplePlan:
         self.w_perm = weights.to(torch.float32)[torch.as_tensor(perm, device=dev)].contiguous()
         self.rows_perm = self.inv[faces.rows.long()].to(torch.int32).contiguous()
         self.faces = faces
+        # row (in sweep order) -> bit mask of the faces it lies on: the fused face maxima of the cell sweep
+        self.memb_all = None
+        if n_faces <= 32:
+            memb_all = np.zeros(R, dtype=np.uint32)
+            for f in range(n_faces):
+                memb_all[inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]] |= np.uint32(1 << f)
+            self.memb_all = torch.as_tensor(memb_all.view(np.int32), device=dev)
         if self.prune:
             from scipy.spatial import cKDTree
 
@@ -612,6 +634,10 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 
 
 CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spacing
+# Per-face maxima folded into the cell sweep and its exact finish (only when neither the per-sample distances nor
+# a cross-shard reduction of them is wanted): no (S, R) store, no face-max pass, and the finish skips every sample
+# that cannot raise a face maximum.  False: sweep -> finish -> flooder_face_max_f32 over the full (S, R) buffer.
+FUSED_FACES = True
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
@@ -629,7 +655,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     ``stats`` (optional, 16 zeroed int64): [0:9] cell sweep {pairs, points staged, tiles flagged,
     re-staging rounds, 4 give-up reasons, exhaustive rounds}, [9:13] finishing tree sweep {leaves
     evaluated, leaves tested, nodes expanded, most tests by one tile}, [13] fine rows swept after pruning,
-    [14] fine rows in total (both 0 when pruning is off).
+    [14] fine rows in total (both 0 when pruning is off); on the fused path [13] = tiles the last finish pass
+    dropped on arrival, [14] = samples still live on arrival in that pass.
     """
     lib = _native.load()
     dev = index.pts.device
@@ -643,6 +670,39 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
 
     def sub(a, b):
         return None if stats is None else stats[a:b]
+
+    if S == 0:
+        return (torch.empty((0, faces.n_faces), dtype=torch.float32, device=dev),
+                torch.empty((0, R), dtype=torch.float32, device=dev) if want_dist else None)
+    if FUSED_FACES and not prune and not want_dist and reduce_hook is None and plan.memb_all is not None:
+        # ---- only the per-face maxima are wanted: fused path.  The cell sweep delivers every settled sample to
+        # face_bits (integer atomic max), the finish drops what cannot raise a face maximum, the (S, R) buffer is
+        # scratch that only the flagged tiles touch.
+        F = faces.n_faces
+        tiles = (R + 63) // 64
+        ctl = torch.zeros(16, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish
+        face_bits = torch.zeros((S, F), dtype=torch.int32, device=dev)
+        top = torch.zeros(S, dtype=torch.int64, device=dev)
+        top_list = torch.empty(S, dtype=torch.int32, device=dev)
+        d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
+        flags = torch.empty(S * tiles, dtype=torch.int32, device=dev)
+        with _span(timer, "sweep"):
+            _native.check(lib.flooder_sweep_cell_faces_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
+                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(flags), ctl[1:].data_ptr(),
+                _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_faces_f32")
+        with _span(timer, "fallback"):
+            _native.check(lib.flooder_finish_faces_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[4:].data_ptr(),
+                _native.ptr(top), _native.ptr(top_list), _native.ptr(d2), _native.ptr(plan.memb_all), F,
+                _native.ptr(face_bits), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
+        out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
+        with _span(timer, "face_max"):
+            _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), S * F, _native.ptr(out_face), st),
+                          "flooder_face_values_f32")
+        return out_face, None
 
     ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # work-queue heads + flag counters
 

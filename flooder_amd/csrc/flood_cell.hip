@@ -33,9 +33,10 @@ constexpr int SPL = CHUNK / 64;   // samples per lane
 constexpr int CAPW = 480;         // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
 constexpr int MAXLEAF = 896;      // leaves gathered per wave item (14 K points before filtering)
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
-constexpr int MAX_TRIES = 3;
+constexpr int MAX_TRIES = 3;      // cell sizes tried per chunk at most (option cell_tries)
 constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively at most (sparse chunk box)
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
+constexpr int BRUTE_CAP = CAPW - CAPW / 4 - 4;  // compacted points the classification pass may leave in the stage
 
 template <int DIM>
 struct CellCfg {
@@ -83,9 +84,9 @@ template <int DIM>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats, RowSel sel) {
+    unsigned long long* __restrict__ stats, RowSel sel, FaceAcc acc) {
   constexpr int DP = padded_dim(DIM);
   constexpr int G = CellCfg<DIM>::G;
   constexpr int NC = CellCfg<DIM>::NC;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #ifdef FLOODER_PHASE_TIMERS
     unsigned long long d_info = 0, d_tb = 0, d_flush = 0, d_wait = 0;  // diagnostics of the last attempt
 #endif
-    for (int attempt = 0; attempt < MAX_TRIES && !give_up; ++attempt) {
+    for (int attempt = 0; attempt < max_tries && !give_up; ++attempt) {
       c = __builtin_fmaxf(c, ext / (float)(G - 3));
       const float inv_c = 1.f / c;
       int nc[DIM];
@@ -442,6 +443,14 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
             cell_add(cid + 1);
             const int slot = n_keep + lane_rank(m);
             if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
+            if (slot < BRUTE_CAP) {  // (below the kept-list alias) small sets are evaluated straight from here
+              float4 v;
+              v.x = x[u][0];
+              v.y = x[u][1];
+              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+              v.w = 0.f;
+              s_pts[slot] = v;
+            }
           }
           n_keep += __popcll(m);
         }
@@ -456,6 +465,50 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
       if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) { give_up = true; ++g_cap; break; }
+      if (n_keep <= brute_max) {
+        // ---- few kept points: every sample against every one of them, straight from the compacted list the
+        // classification pass left in the stage (broadcast LDS reads, no cell table, no second pass over the
+        // candidates).  Cheaper than the cell query's dependent LDS chains while the list is short.
+        if (lane < 4) s_pts[n_keep + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+        wave_lds_sync();
+        for (int j = 0; j < n_keep; j += 4) {
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+#pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            float bb = best[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float t0 = p[i][0] - x[u].x;
+              float d2 = t0 * t0;
+              t0 = p[i][1] - x[u].y;
+              d2 = __builtin_fmaf(t0, t0, d2);
+              if constexpr (DIM == 3) {
+                t0 = p[i][2] - x[u].z;
+                d2 = __builtin_fmaf(t0, t0, d2);
+              }
+              bb = __builtin_fminf(bb, d2);
+            }
+            best[i] = bb;
+          }
+        }
+        if (stats) n_pairs += (unsigned long long)n_keep * SPL;
+        n_staged += (unsigned long long)n_keep;
+        bool any_open = false;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          open[i] = open[i] && !(best[i] <= c_ok);
+          any_open = any_open || open[i];
+        }
+        if (attempt > 0) ++n_retries;
+        wave_lds_sync();
+        PHASE(8);
+        if (__ballot(any_open) == 0ull) break;
+        if (attempt == max_tries - 1) ++g_tries;
+        c *= 2.f;
+        continue;
+      }
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
@@ -542,7 +595,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         if (attempt > 0) ++n_retries;
         PHASE(9);
         if (__ballot(any_open) == 0ull) break;
-        if (attempt == MAX_TRIES - 1) ++g_tries;
+        if (attempt == max_tries - 1) ++g_tries;
         c *= 2.f;
         continue;
       }
@@ -675,20 +728,58 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
       PHASE(8);
       if (__ballot(any_open) == 0ull) break;
-      if (attempt == MAX_TRIES - 1) ++g_tries;
+      if (attempt == max_tries - 1) ++g_tries;
       c *= 2.f;
     }
 
     // ---- results; tiles of 64 samples that are still open go to the exact tree sweep
+    if (acc.face_bits) {
+      // fused face maxima: every settled sample raises the running maximum of each face it lies on (one integer
+      // atomic per face present in the chunk: interior chunks touch one face); the (S, R) buffer is only
+      // written for the tiles the finish has to look at (bit 31 = already settled)
+      uint32_t mb[SPL], um = 0u;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-      if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
-      if (__ballot(open[i]) != 0ull) {
-        if (lane == 0) {
-          const int pos = atomicAdd(flag_count, 1);
-          flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+      for (int i = 0; i < SPL; ++i) {
+        const bool settled = (q * CHUNK + i * 64 + lane < n_live) && !open[i];
+        mb[i] = settled ? acc.memb[row[i]] : 0u;
+        um |= mb[i];
+      }
+      um = wave_or_u32(um);
+      while (um) {  // (wave-uniform)
+        const int f = __builtin_ctz(um);
+        um &= um - 1u;
+        uint32_t v = 0u;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          const uint32_t b = ((mb[i] >> f) & 1u) ? __float_as_uint(best[i]) : 0u;
+          v = b > v ? b : v;
         }
-        ++n_flagged;
+        v = wave_max_u32(v);
+        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
+      }
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        if (__ballot(open[i]) != 0ull) {
+          if (q * CHUNK + i * 64 + lane < n_live)
+            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
+          if (lane == 0) {
+            const int pos = atomicAdd(flag_count, 1);
+            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+          }
+          ++n_flagged;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
+        if (__ballot(open[i]) != 0ull) {
+          if (lane == 0) {
+            const int pos = atomicAdd(flag_count, 1);
+            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+          }
+          ++n_flagged;
+        }
       }
     }
     PHASE(10);
@@ -729,7 +820,7 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 RowSel sel, hipStream_t st) {
+                 RowSel sel, FaceAcc acc, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
@@ -739,13 +830,41 @@ struct CellOp {
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, queue, out, flag_list, flag_count, stats, sel);
+                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP, g_cell_tries, queue, out, flag_list, flag_count, stats, sel, acc);
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
     }
   }
 };
+
+}  // namespace
+
+namespace {
+
+int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
+                     const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
+                     uint32_t* out_d2, int ld_out, const int32_t* row_list, const int32_t* row_cnt, int list_stride,
+                     int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc, void* stream,
+                     const char* who) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f) || ld_out < 1 ||
+      (row_list && (!row_cnt || list_stride < 1)))
+    return fail(FLOODER_E_ARG, who);
+  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
+  if (dim != 2 && dim != 3) return fail(FLOODER_E_ARG, "cell sweep: only dim 2 and 3");
+  if (n_simplices * (int64_t)(((row_list ? list_stride : R) + 63) / 64) > 0x7fffffffLL)
+    return fail(FLOODER_E_ARG, "cell sweep: too many (simplex, tile) pairs");
+  const Levels lv = make_levels(n_pts);
+  // the kernel addresses rows and node boxes with 32-bit byte offsets
+  if ((n_pts + FLOODER_BVH_LEAF) * (int64_t)(padded_dim(dim) * sizeof(float)) >= (1LL << 32) ||
+      total_nodes(lv) * (int64_t)(2 * padded_dim(dim) * sizeof(float)) >= (1LL << 32))
+    return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
+  return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
+                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel, acc,
+                              (hipStream_t)stream);
+}
 
 }  // namespace
 
@@ -756,23 +875,22 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            float alpha, int32_t* queue, uint32_t* out_d2, int ld_out,
                            const int32_t* row_list, const int32_t* row_cnt, int list_stride,
                            int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
+  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
+                          ld_out, row_list, row_cnt, list_stride, flag_list, flag_count, stats,
+                          FaceAcc{nullptr, nullptr, 0}, stream, "flooder_sweep_cell_f32: bad argument");
+}
+
+int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                 const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                 float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
+                                 int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
+                                 uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
-  if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f) || ld_out < 1 ||
-      (row_list && (!row_cnt || list_stride < 1)))
-    return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: bad argument");
-  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
-  if (dim != 2 && dim != 3) return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
-  if (n_simplices * (int64_t)(((row_list ? list_stride : R) + 63) / 64) > 0x7fffffffLL)
-    return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: too many (simplex, tile) pairs");
-  const Levels lv = make_levels(n_pts);
-  // the kernel addresses rows and node boxes with 32-bit byte offsets
-  if ((n_pts + FLOODER_BVH_LEAF) * (int64_t)(padded_dim(dim) * sizeof(float)) >= (1LL << 32) ||
-      total_nodes(lv) * (int64_t)(2 * padded_dim(dim) * sizeof(float)) >= (1LL << 32))
-    return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: cloud too large for the cell sweep (use the tree sweep)");
-  return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
-                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel,
-                              (hipStream_t)stream);
+  if (!memb || !face_bits || n_faces < 1 || n_faces > 32)
+    return fail(FLOODER_E_ARG, "flooder_sweep_cell_faces_f32: bad argument");
+  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
+                          d2_scratch, R, nullptr, nullptr, 0, flag_list, flag_count, stats,
+                          FaceAcc{memb, face_bits, n_faces}, stream, "flooder_sweep_cell_faces_f32: bad argument");
 }
 
 }  // extern "C"

@@ -19,6 +19,9 @@ extern int g_cell_exh_dense;
 extern int g_bvh_leaf_batch;
 extern int g_bvh_refine_pct;
 extern int g_cell_exh_sparse;
+extern int g_cell_brute_max;
+extern int g_finish_focus_pct;
+extern int g_cell_tries;
 extern int g_curve;
 char* err_buf();
 int fail(int code, const char* msg);
@@ -109,6 +112,38 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
   t = dpp_move_u32<0x143, 0xC>(x); x = t < x ? t : x;
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  uint32_t t;
+  t = dpp_move_u32<0xB1, 0xF>(x); x = t > x ? t : x;
+  t = dpp_move_u32<0x4E, 0xF>(x); x = t > x ? t : x;
+  t = dpp_move_u32<0x141, 0xF>(x); x = t > x ? t : x;
+  t = dpp_move_u32<0x140, 0xF>(x); x = t > x ? t : x;
+  t = dpp_move_u32<0x142, 0xA>(x); x = t > x ? t : x;
+  t = dpp_move_u32<0x143, 0xC>(x); x = t > x ? t : x;
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+  x |= dpp_move_u32<0xB1, 0xF>(x);
+  x |= dpp_move_u32<0x4E, 0xF>(x);
+  x |= dpp_move_u32<0x141, 0xF>(x);
+  x |= dpp_move_u32<0x140, 0xF>(x);
+  x |= dpp_move_u32<0x142, 0xA>(x);
+  x |= dpp_move_u32<0x143, 0xC>(x);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// Fused per-face maxima (flooder_sweep_cell_faces_f32 / flooder_finish_faces_f32): memb[r] = bit mask of the
+// faces sample row r lies on, face_bits[s * n_faces + f] = running maximum of the d2 bits over the samples of
+// face f whose nearest neighbour is settled.  In this mode the d2 buffer is scratch: only tiles handed to the
+// finish are written, and bit 31 of a word marks a sample the cell sweep has already settled.
+constexpr uint32_t SETTLED_BIT = 0x80000000u;
+struct FaceAcc {
+  const uint32_t* memb;
+  uint32_t* face_bits;
+  int n_faces;
+};
 
 // Which sample rows of a simplex a sweep works on: all R rows of the weight table (list == nullptr), or
 // the first cnt[s] entries of the simplex's segment list[s*stride .. ) (rows that survived pruning).

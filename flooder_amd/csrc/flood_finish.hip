@@ -1,0 +1,523 @@
+// flood_finish.hip - exact finish of the cell sweep's open tiles when only per-face MAXIMA are wanted (gfx950).
+//
+// The filtration value of a face is a maximum over its samples, so a sample whose upper bound cannot exceed the
+// running maximum of every face it lies on needs no exact nearest neighbour.  face_bits[s, f] holds the running
+// maximum over the samples of face f that are settled (exact); it only ever receives exact values, so it never
+// exceeds the true maximum, and a sample i with  best_i <= min over its faces f of face_bits[s, f]  can be dropped:
+// true_i <= best_i <= face_bits[s, f] <= max_f.  The sample that attains max_f is dropped only when another sample
+// has already delivered the same value, otherwise it stays live to the end of its traversal, is then exact, and
+// delivers it.  Face values therefore equal the exhaustive result bit for bit.
+//
+// Three passes over the list of flagged tiles (64 consecutive samples of a simplex each):
+//   probe  one greedy descent of the box tree per tile (nearest child at every level, one leaf evaluated) gives
+//          every sample a finite upper bound; the tile with the largest one becomes its simplex's "top" tile;
+//   top    the top tile of every simplex is finished exactly first (one per simplex, all at once): it usually holds
+//          the simplex's deepest sample, so face_bits of the full simplex is (almost) final afterwards;
+//   rest   all other tiles: most of their samples are dropped against face_bits straight away; what stays live
+//          (samples on lower-dimensional faces, near-ties) is traversed with bounds that only consider the live
+//          samples (tile box, pruning radius M, refine loop over live lanes only).
+// Traversal as in flood_bvh.hip: wave-uniform, nearest first, lane = child box, leaf points through SGPRs.
+
+#include "flood_common.hpp"
+#include "flood_bvh.hpp"
+
+using namespace flooder;
+
+namespace {
+
+constexpr float SAFE = 0.99999f;
+constexpr int REFRESH = 4;  // leaf evaluations between two reloads of the face maxima
+constexpr int SHORT_LIST = 1024;
+
+template <int DIM>
+__global__ __launch_bounds__(256) void finish_faces_kernel(
+    const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
+    const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
+    int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_count,
+    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int refine_pct, float focus_frac, int32_t* __restrict__ queue,
+    uint32_t* __restrict__ d2, FaceAcc acc, unsigned long long* __restrict__ top,
+    int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, unsigned long long* __restrict__ stats) {
+  constexpr int DP = padded_dim(DIM);
+  __shared__ float s_lb[4][MAXL][FAN];
+  __shared__ int64_t s_grp[4][MAXL];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tiles = (R + 63) >> 6;
+  const int n_list = flag_count[0];
+  // few items: split each tile over several waves (short tail, tight boxes); many: 64 distinct samples per wave
+  int subs = 1;
+  const int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
+  if (mode != 0) {
+    subs = subs_max;
+    while (subs > 1 && n_base * subs > 32768) subs >>= 1;
+    if (subs_max > 1 && n_base * 64 <= (int64_t)gridDim.x * 4) subs = 64;
+  }
+  if (n_base == 0) return;
+  // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
+  if (mode == 0 && n_list <= SHORT_LIST) return;
+  const int64_t n_items = n_base * subs;
+  const int per_sub = 64 / subs;
+  const int topl = lv.n_levels - 1;
+  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, n_dropped = 0, n_live0 = 0, n_rounds = 0;
+
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
+  const bool static_deal = n_items <= (int64_t)gridDim.x * 4;
+  bool dealt = false;
+  for (;;) {
+    int64_t g;
+    if (static_deal) {
+      if (dealt || wave_id >= n_items) break;
+      dealt = true;
+      g = wave_id;
+    } else {
+      int g32 = 0;
+      if (lane == 0) g32 = atomicAdd(queue, 1);
+      g = (int64_t)wave_uniform(g32);
+      if (g >= n_items) break;
+    }
+    const int sub = (int)(g % subs);
+    g /= subs;
+    int64_t s;
+    int item;  // global tile id: simplex * tiles + tile
+    if (mode == 1) {
+      s = top_list[g];
+      item = (int)(uint32_t)(top[s] & 0xffffffffull);
+    } else {
+      item = flag_list[g];
+      s = item / tiles;
+      if (mode == 2 && top[s] != 0ull && (int)(uint32_t)(top[s] & 0xffffffffull) == item) continue;
+    }
+    const int tile = item - (int)(s * tiles);
+    const int slane = sub * per_sub + (lane & (per_sub - 1));  // sample slot of this lane inside the tile
+    const bool mine = lane < per_sub;                           // (other lanes hold replicas)
+    int r = tile * 64 + slane;
+    const bool exists = r < R;
+    if (!exists) r = R - 1;
+
+    // ---- this lane's sample, its seed and the faces it lies on
+    float p[DIM];
+    const float* vs = verts + s * (int64_t)k1 * DIM;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) p[k] = 0.f;
+    for (int j = 0; j < k1; ++j) {
+      const float w = weights[(int64_t)r * k1 + j];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(w, vs[j * DIM + k], p[k]);
+    }
+    const uint32_t seed = d2[s * (int64_t)R + r];
+    const bool settled = !exists || (seed & SETTLED_BIT) != 0u;  // settled by the cell sweep: delivered already
+    float best = __uint_as_float(seed & ~SETTLED_BIT);
+    const uint32_t mb = settled ? 0u : acc.memb[r];
+    const uint32_t* fbase = acc.face_bits + s * (int64_t)acc.n_faces;
+
+    // ---- live set: unsettled samples whose upper bound still exceeds the running maximum of one of their faces
+    bool live, done = settled || mb == 0u;  // done: settled exactly and delivered (or nothing to deliver)
+    float M, tlo[DIM], thi[DIM];
+    auto refresh = [&]() {
+      const uint32_t fb = lane < acc.n_faces
+                              ? __hip_atomic_load(fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : 0xffffffffu;
+      uint32_t thr = 0xffffffffu;
+      uint32_t um = wave_or_u32(mb);
+      while (um) {  // (wave-uniform)
+        const int f = __builtin_ctz(um);
+        um &= um - 1u;
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)fb, f);
+        if ((mb >> f) & 1u) thr = v < thr ? v : thr;
+      }
+      live = !done && __float_as_uint(best) > thr;
+      M = wave_max_f32(live ? best : -1.f);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        tlo[k] = wave_min_f32(live ? p[k] : __builtin_inff());
+        thi[k] = wave_max_f32(live ? p[k] : -__builtin_inff());
+      }
+    };
+    refresh();
+    if (mode == 0) {  // the probe descends for every unsettled sample (their bounds order the tiles)
+      M = wave_max_f32(settled ? -1.f : best);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        tlo[k] = wave_min_f32(settled ? __builtin_inff() : p[k]);
+        thi[k] = wave_max_f32(settled ? -__builtin_inff() : p[k]);
+      }
+    }
+    if (sub == 0) n_live0 += __popcll(__ballot(live && mine));
+    if (!(M >= 0.f)) {  // nothing to do for this tile
+      if (sub == 0) ++n_dropped;
+      continue;
+    }
+
+    // child `lane` of group `grp` at level `lvl`: its box (registers) and the lower bound to the live box
+    float c_lo[DIM], c_hi[DIM];
+    auto child_bounds = [&](int lvl, int64_t grp) -> float {
+      const int64_t idx = grp * FAN + lane;
+      float lb = __builtin_inff();
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) { c_lo[k] = __builtin_inff(); c_hi[k] = -__builtin_inff(); }
+      if (idx < lv.count[lvl]) {
+        float lo[DP], hi[DP];
+        const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
+        load_row<DP>(nb, lo);
+        load_row<DP>(nb + DP, hi);
+        lb = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          c_lo[k] = lo[k];
+          c_hi[k] = hi[k];
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
+          lb = __builtin_fmaf(gap, gap, lb);
+        }
+      }
+      return lb;
+    };
+    // all 16 points of leaf c against this lane's sample (points through the scalar cache)
+    auto eval_leaf = [&](int64_t c) {
+      const float* cp = pts + c * (int64_t)LEAF * DP;
+#pragma unroll
+      for (int h = 0; h < LEAF; h += 8) {
+        typename RowVec<DP>::type cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          float da, db;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float ta = p[k] - cc[u][k];
+            const float tb = p[k] - cc[u + 1][k];
+            if (k == 0) {
+              da = ta * ta;
+              db = tb * tb;
+            } else {
+              da = __builtin_fmaf(ta, ta, da);
+              db = __builtin_fmaf(tb, tb, db);
+            }
+          }
+          best = __builtin_fminf(best, __builtin_fminf(da, db));
+        }
+      }
+      ++n_leaf_eval;
+    };
+
+    if (mode == 0) {
+      // ---- probe: greedy descent, nearest child at every level, then the nearest leaf of that group
+      int64_t grp = 0;
+      for (int lvl = topl; lvl >= 0; --lvl) {
+        const float lb = child_bounds(lvl, grp);
+        ++n_node_test;
+        const float mn = wave_min_f32(lb);
+        const int j = __builtin_ctzll(__ballot(lb == mn));
+        grp = grp * FAN + j;
+      }
+      eval_leaf(grp);
+      if (exists && !settled) d2[s * (int64_t)R + r] = __float_as_uint(best);
+      // upper bound of the tile among the samples that still matter
+      const uint32_t fb = lane < acc.n_faces ? fbase[lane] : 0xffffffffu;
+      uint32_t thr = 0xffffffffu, um = wave_or_u32(mb);
+      while (um) {
+        const int f = __builtin_ctz(um);
+        um &= um - 1u;
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)fb, f);
+        if ((mb >> f) & 1u) thr = v < thr ? v : thr;
+      }
+      const bool lv_ = !settled && mb != 0u && __float_as_uint(best) > thr;
+      const uint32_t key = wave_max_u32(lv_ ? __float_as_uint(best) : 0u);
+      if (lane == 0 && key != 0u) {
+        const unsigned long long old = atomicMax(&top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)item);
+        if (old == 0ull) top_list[atomicAdd(top_count, 1)] = (int)s;  // first tile of this simplex that matters
+      }
+      continue;
+    }
+
+    // ---- exact traversal in FOCUS ROUNDS.  A round settles only the live samples whose bound is within
+    // FOCUS of the largest one (squared distances): its pruning radius, its box and its per-leaf tests look at
+    // them alone - a few nearby points instead of a 64-sample tile - while every leaf it evaluates still tightens
+    // the bounds of all lanes.  The settled values are delivered, face_bits rises, and most of the remaining
+    // samples drop out without a search of their own; whatever is still live forms the next round.
+    for (;;) {
+      bool focus = live && best >= focus_frac * M;
+      float Mf;
+      auto rebound = [&]() {
+        Mf = wave_max_f32(focus ? best : -1.f);
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          tlo[k] = wave_min_f32(focus ? p[k] : __builtin_inff());
+          thi[k] = wave_max_f32(focus ? p[k] : -__builtin_inff());
+        }
+      };
+      rebound();
+      ++n_rounds;
+      int lvl = topl;
+      float lb0 = child_bounds(topl, 0);
+      int64_t grp0 = 0;
+      ++n_node_test;
+      if (topl > 0) {
+        s_lb[wv][topl][lane] = lb0;
+        if (lane == 0) s_grp[wv][topl] = 0;
+      }
+      int since = 0;
+      for (;;) {
+        if (lvl > 0) {
+          const float lbv = s_lb[wv][lvl][lane];
+          const float mn = wave_min_f32(lbv);
+          if (!(mn * SAFE < Mf)) {  // nothing left at this level can improve a focus sample
+            if (++lvl > topl) break;
+            continue;
+          }
+          const int j = __builtin_ctzll(__ballot(lbv == mn));
+          if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
+          const int64_t c = s_grp[wv][lvl] * FAN + j;
+          --lvl;
+          const float lb = child_bounds(lvl, c);
+          ++n_node_test;
+          if (lvl > 0) {
+            s_lb[wv][lvl][lane] = lb;
+            if (lane == 0) s_grp[wv][lvl] = c;
+          } else {
+            lb0 = lb;
+            grp0 = c;
+            // transposed refine: the 64 leaf boxes of the group (one per lane) against every FOCUS sample
+            const bool cand = lb * SAFE < Mf;
+            unsigned long long lm = __ballot(focus && mine);
+            constexpr int PER_LEAF = 4 * DIM + 40, PER_SAMPLE = 4 * DIM + 3;
+            if ((int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 > (int64_t)__popcll(lm) * PER_SAMPLE * refine_pct) {
+              bool need = false;
+              while (lm) {  // (wave-uniform)
+                const int src = __builtin_ctzll(lm);
+                lm &= lm - 1ull;
+                float lbp = 0.f;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                  const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[k]), src));
+                  const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
+                  lbp = __builtin_fmaf(gap, gap, lbp);
+                }
+                const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), src));
+                need = need || (lbp * SAFE < bi);
+              }
+              if (!(cand && need)) lb0 = __builtin_inff();
+            }
+          }
+          continue;
+        }
+        // ---- leaf level: nearest unvisited leaf of the current group
+        const float mn = wave_min_f32(lb0);
+        if (!(mn * SAFE < Mf)) {
+          if (++lvl > topl) break;
+          continue;
+        }
+        const int j = __builtin_ctzll(__ballot(lb0 == mn));
+        if (lane == j) lb0 = __builtin_inff();  // visited
+        const int64_t c = grp0 * FAN + j;
+        ++n_leaf_test;
+        float blo[DIM], bhi[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          blo[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
+          bhi[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
+        }
+        float lbp = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[k], p[k] - bhi[k]), 0.f);
+          lbp = __builtin_fmaf(gap, gap, lbp);
+        }
+        if (__ballot(focus && (lbp * SAFE < best)) == 0ull) continue;
+        eval_leaf(c);
+        if (++since >= REFRESH) {
+          since = 0;
+          refresh();  // other waves may have raised the face maxima meanwhile: focus samples may drop out
+          focus = focus && live;
+          rebound();
+        } else {
+          Mf = wave_max_f32(focus ? best : -1.f);
+        }
+        if (!(Mf >= 0.f)) break;
+      }
+      // ---- deliver the round: focus samples that stayed live to its end are exact (a focus sample that dropped out
+      // on the way is below the running maximum of each of its faces: its atomic changes nothing)
+      {
+        const uint32_t mbm = (mine && focus) ? mb : 0u;
+        uint32_t um = wave_or_u32(mbm);
+        while (um) {
+          const int f = __builtin_ctz(um);
+          um &= um - 1u;
+          const uint32_t v = wave_max_u32(((mbm >> f) & 1u) ? __float_as_uint(best) : 0u);
+          if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
+        }
+      }
+      done = done || focus;
+      refresh();
+      if (!(M >= 0.f)) break;
+    }
+  }
+  if (stats && lane == 0 && (n_node_test | n_leaf_test | n_dropped) != 0ull) {
+    atomicAdd(&stats[0], n_leaf_eval);
+    atomicAdd(&stats[1], n_leaf_test);
+    atomicAdd(&stats[2], n_node_test);
+    if (mode == 2) {
+      atomicAdd(&stats[4], n_dropped);
+      atomicAdd(&stats[5], n_live0);
+    }
+    atomicAdd(&stats[6], n_rounds);
+  }
+}
+
+__global__ void face_values_kernel(const uint32_t* __restrict__ bits, int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = __builtin_sqrtf(__uint_as_float(bits[i]));
+}
+
+template <int DIM>
+struct FinishOp {
+  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
+                 int k1, int R, int64_t ns, const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                 uint32_t* d2, FaceAcc acc, unsigned long long* top, int32_t* top_list, unsigned long long* stats,
+                 hipStream_t st) {
+    const int grid = g_bvh_grid;
+    for (int mode = 0; mode < 3; ++mode) {  // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile
+      hipLaunchKernelGGL((finish_faces_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, k1,
+                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, ctl + mode, d2, acc, top,
+                         top_list, ctl + 3, stats);
+    }
+    return check_launch("finish_faces");
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                             const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                             const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                             uint64_t* top, int32_t* top_list, uint32_t* d2_scratch, const uint32_t* memb,
+                             int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !flag_list || !flag_count || !ctl || !top || !top_list || !d2_scratch ||
+      !memb || !face_bits || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 1 || n_faces < 1 || n_faces > 32)
+    return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<FinishOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, flag_list,
+                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces},
+                                reinterpret_cast<unsigned long long*>(top), top_list,
+                                reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
+}
+
+int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_face, void* stream) {
+  if (n == 0) return FLOODER_OK;
+  if (!face_bits || !out_face || n < 0) return fail(FLOODER_E_ARG, "flooder_face_values_f32: bad argument");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(face_values_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, face_bits, n, out_face);
+  return check_launch("face_values");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------ simplex weights
+// Rough number of cloud points inside each simplex's bounding box: the box tree is walked from the top to level 1
+// (1024 points per node); every node overlapping the box contributes its point count times the overlapped
+// fraction of its own box.  Heavy simplices (dense regions) take 100x longer than the median one in the sweeps; the
+// host queues the simplices by descending weight so that the long ones start first and the short ones fill the tail.
+namespace {
+
+constexpr int WFRONT = 256;
+
+template <int DIM>
+__global__ __launch_bounds__(256) void simplex_weight_kernel(const float* __restrict__ nodes, Levels lv,
+                                                             const float* __restrict__ verts, int k1,
+                                                             int64_t n_simplices, float* __restrict__ weight) {
+  constexpr int DP = padded_dim(DIM);
+  __shared__ int s_front[4][2][WFRONT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int topl = lv.n_levels - 1;
+  const int stop = topl >= 1 ? 1 : 0;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wv; s < n_simplices; s += (int64_t)gridDim.x * 4) {
+    float blo[DIM], bhi[DIM];
+    const float* vs = verts + s * (int64_t)k1 * DIM;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      float mn = vs[k], mx = vs[k];
+      for (int j = 1; j < k1; ++j) {
+        mn = __builtin_fminf(mn, vs[j * DIM + k]);
+        mx = __builtin_fmaxf(mx, vs[j * DIM + k]);
+      }
+      blo[k] = mn;
+      bhi[k] = mx;
+    }
+    float acc = 0.f;  // per lane
+    int* fa = s_front[wv][0];
+    int* fb = s_front[wv][1];
+    int na = 1;
+    if (lane == 0) fa[0] = 0;  // pseudo-parent of the top level: group 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int lvl = topl; lvl >= stop; --lvl) {
+      float per_node = (float)LEAF;
+      for (int l = 0; l < lvl; ++l) per_node *= (float)FAN;
+      int nb = 0;
+      for (int f = 0; f < na; ++f) {
+        const int grp = wave_uniform(fa[f]);
+        const int64_t idx = (int64_t)grp * FAN + lane;
+        bool hit = idx < lv.count[lvl];
+        float frac = 0.f;
+        if (hit) {
+          float lo[DP], hi[DP];
+          const float* nbp = nodes + (lv.off[lvl] + idx) * 2 * DP;
+          load_row<DP>(nbp, lo);
+          load_row<DP>(nbp + DP, hi);
+          frac = 1.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float ov = __builtin_fminf(hi[k], bhi[k]) - __builtin_fmaxf(lo[k], blo[k]);
+            const float ext = hi[k] - lo[k];
+            hit = hit && ov >= 0.f;
+            frac *= ext > 0.f ? __builtin_fminf(__builtin_fmaxf(ov, 0.f) / ext, 1.f) : 1.f;
+          }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int cnt = __popcll(m);
+        if (lvl > stop && nb + cnt <= WFRONT) {
+          if (hit) fb[nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (int)idx;
+          nb += cnt;
+        } else if (hit) {
+          acc += per_node * frac;  // last level, or no room to descend: estimate at this level
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      int* t = fa; fa = fb; fb = t;
+      na = nb;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) weight[s] = acc;
+  }
+}
+
+template <int DIM>
+struct WeightOp {
+  static int run(const float* nodes, const Levels& lv, const float* verts, int k1, int64_t ns, float* weight,
+                 hipStream_t st) {
+    int64_t blocks = (ns + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((simplex_weight_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, nodes, lv, verts, k1, ns, weight);
+    return check_launch("simplex_weight");
+  }
+};
+
+}  // namespace
+
+extern "C" int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
+                                          int64_t n_simplices, float* weight, void* stream) {
+  if (n_simplices == 0) return FLOODER_OK;
+  if (!nodes || !verts || !weight || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS)
+    return fail(FLOODER_E_ARG, "flooder_simplex_weight_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<WeightOp>(dim, nodes, lv, verts, k1, n_simplices, weight, (hipStream_t)stream);
+}

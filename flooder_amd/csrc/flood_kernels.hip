@@ -619,6 +619,18 @@ int flooder_set_option(const char* name, int value) {
     g_cell_exh_sparse = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "finish_focus_pct") == 0 && value >= 0 && value <= 100) {
+    g_finish_focus_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_tries") == 0 && value >= 1 && value <= 8) {
+    g_cell_tries = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_brute_max") == 0 && value >= 0) {
+    g_cell_brute_max = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_exh_dense") == 0 && value >= 512) {
     g_cell_exh_dense = value;
     return FLOODER_OK;

@@ -197,6 +197,46 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream);
 
 /*
+ * Cell sweep fused with the per-face maxima (core.py:251-276 folded into the sweep): as flooder_sweep_cell_f32 over
+ * all R rows, but every sample whose nearest neighbour is settled raises face_bits[s * n_faces + f] (integer
+ * atomic max on the d2 bits; zeroed by the caller) for each face f whose bit is set in memb[r] (n_faces <= 32;
+ * random mode: one face, every memb word = 1).  The (S, R) buffer becomes scratch: only the tiles appended to
+ * flag_list are written (bit 31 of a word = that sample is already settled), the other cells stay undefined.
+ * Followed by flooder_finish_faces_f32 and flooder_face_values_f32.
+ */
+int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                 const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                 float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
+                                 int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
+                                 uint64_t* stats, void* stream);
+
+/*
+ * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
+ * exceed the running maximum of every face it lies on cannot change a result and is dropped; the others are
+ * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Three passes: a probe (one
+ * greedy descent per tile: finite upper bounds, and per simplex the tile with the largest one), the top tile of
+ * every simplex, then all other tiles.  Face values equal the exhaustive result bit for bit.
+ *   ctl: 8 zeroed int32 (queue heads, counters); top: n_simplices zeroed uint64; top_list: n_simplices int32;
+ *   stats: NULL or 7 zeroed uint64 {leaves evaluated, leaves tested, nodes expanded, -, tiles dropped on arrival in
+ *   the last pass, samples live on arrival in the last pass, -}.
+ */
+int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                             const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                             const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                             uint64_t* top, int32_t* top_list, uint32_t* d2_scratch, const uint32_t* memb,
+                             int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream);
+
+/* out_face[i] = sqrt(float(face_bits[i])), i < n: the filtration values (core.py:257, 272: distances, not squares). */
+int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_face, void* stream);
+
+/* weight[s] = rough number of cloud points inside the bounding box of simplex s (walk of the box tree down to its
+ * 1024-point nodes, overlapped volume fractions).  The host queues the simplices by descending weight: work per
+ * simplex is heavy-tailed and the long ones should start first.  Replaces the sort by ball centre of core.py:174-179
+ * as the work order (the order of the simplices never changes a value). */
+int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
+                               int64_t n_simplices, float* weight, void* stream);
+
+/*
  * Row selection (both sweeps above): row_list == NULL sweeps all R rows of `weights` and writes
  * out_d2[s * ld_out + r]; otherwise simplex s sweeps only rows row_list[s * list_stride + i], i < row_cnt[s]
  * (work items and flag ids are then counted in slots of the list: ceil(list_stride / 64) tiles per simplex).

@@ -444,3 +444,48 @@ def test_needle_and_sliver_simplices_cell_equals_tree(dev):
         keys = sorted(ref)
         assert set(keys) == set(a)
         assert_close_filtration(dict_values(a, keys), dict_values(ref, keys), pts, f"needles case {case}")
+
+
+@pytest.mark.parametrize("cloud", ["torus", "gauss", "cheese", "eight2d"])
+def test_fused_face_maxima_equal_unfused(dev, cloud, monkeypatch):
+    """The cell sweep with the per-face maxima folded in (settled samples delivered by atomic max, the finish dropping
+    every sample that cannot raise a face maximum) against sweep -> finish -> face-max over the full (S, R) buffer:
+    identical dictionaries, grid and random mode."""
+    if cloud == "torus":
+        pts = fo.noisy_torus(300_000, seed=7)
+        n_l, dim = 250, 3
+    elif cloud == "gauss":
+        pts = np.random.default_rng(7).normal(size=(300_000, 3)).astype(np.float32)
+        n_l, dim = 250, 3
+    elif cloud == "cheese":
+        pts = fa.generate_swiss_cheese_points(400_000, k=6, seed=7)[0].numpy()
+        n_l, dim = 300, 3
+    else:
+        pts = fa.generate_figure_eight_points_2d(200_000, noise_std=0.01, seed=7).numpy().astype(np.float32)
+        n_l, dim = 200, 2
+    tp = torch.as_tensor(pts, device=dev)
+    tl = fa.generate_landmarks(tp, n_l, start_idx=0)
+    for kw in (dict(points_per_edge=20), dict(points_per_edge=None, num_rand=700)):
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(core, "FUSED_FACES", fused)
+            torch.manual_seed(11)
+            res[fused] = fa.flood_complex(tp, tl, method="cell", **kw)
+        assert res[True] == res[False], (cloud, kw)
+
+
+def test_simplex_weight_orders_dense_simplices_first(dev):
+    """flooder_simplex_weight_f32: the estimate tracks the true number of points in each simplex's bounding box."""
+    pts = np.random.default_rng(3).normal(size=(400_000, 3)).astype(np.float32)
+    tp = torch.as_tensor(pts, device=dev)
+    tl = fa.generate_landmarks(tp, 200, start_idx=0)
+    _, simplices = core._build_complex(tl, 3)
+    verts = tl[torch.as_tensor(simplices[3], device=dev)]
+    index = core.PointIndex(tp)
+    order = core.simplex_order(index, verts).cpu().numpy()
+    assert sorted(order.tolist()) == list(range(verts.shape[0]))
+    V = verts.cpu().numpy()
+    lo, hi = V.min(axis=1), V.max(axis=1)
+    true = np.array([((pts >= lo[i]) & (pts <= hi[i])).all(axis=1).sum() for i in range(V.shape[0])])
+    top = set(np.argsort(-true)[: len(true) // 10].tolist())
+    assert len(top & set(order[: len(true) // 5].tolist())) >= 0.8 * len(top)

@@ -26,6 +26,45 @@ for s in $STEPS; do
             timeout 300 python tools/bvh_phase.py cfg3 > $OUT/bvh_phase_cfg3.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/phase_timers.txt; head -20 $OUT/chunk_times_1.txt; cat $OUT/bvh_phase_cfg3.txt ;;
+    ab:*)   # ab:<workload>:<name>:<flags with , for space>   one bench line per variant
+            IFS=: read -r _ wl name flags <<< "$s"
+            timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 ${flags//,/ } > $OUT/ab_${wl}_${name}.json 2> $OUT/ab_${wl}_${name}.err
+            python - "$OUT/ab_${wl}_${name}.json" "$wl $name" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    st = d["config"]["sweep_stats_rank0"] or {}
+    print(sys.argv[2], "ms/step", d["ms_per_step"], "+-", d["ms_per_step_std"], {k: v["ms_per_step"] for k, v in d["kernels"].items()},
+          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds")})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-600:])
+PY
+            ;;
+    pytest:*) k="${s#pytest:}"; timeout 1200 python -m pytest tests -m gpu -x -q -k "${k//,/ }" > $OUT/pytest_k.txt 2>&1; tail -8 $OUT/pytest_k.txt ;;
+    trace:*) # per-dispatch durations of the finish passes (probe, top, rest) from a kernel trace
+            wl=${s#trace:}
+            ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace_$wl.json 2> $OUT/trace_$wl.err )
+            python - $OUT/trace_$wl <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+fin = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "finish_faces" in r["Kernel_Name"]]
+print("finish passes (us), triples probe/top/rest:", [round(x, 1) for x in fin[-9:]])
+agg = collections.defaultdict(list)
+for r in rows:
+    agg[r["Kernel_Name"].split("(")[0][-60:]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
+    print(f"{k:62s} n={len(v):4d} mean {sum(v)/len(v):9.1f} us")
+PY
+            rm -rf $OUT/trace_$wl ;;
+    ptimers:*) wl=${s#ptimers:}
+            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            timeout 300 python tools/phase_timers.py $wl > $OUT/phase_timers_$wl.txt 2>&1
+            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            cat $OUT/phase_timers_$wl.txt ;;
+    tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
   esac
 done

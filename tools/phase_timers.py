@@ -1,4 +1,5 @@
-"""Diagnostic: per-phase cycle shares of the cell sweep (library built with -DFLOODER_PHASE_TIMERS)."""
+"""Diagnostic: per-phase cycle shares of the cell sweep (library built with -DFLOODER_PHASE_TIMERS).
+usage: python tools/phase_timers.py [cfg2|cfg3]"""
 import sys, torch, numpy as np
 sys.path.insert(0, '.')
 import flooder_amd as fa
@@ -6,7 +7,11 @@ from flooder_amd import _native, core
 lib = _native.load()
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
-pts = torch.randn(1_000_000, 3).to(dev)
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+if which == "cfg3":
+    pts = fa.generate_noisy_torus_points_3d(1_000_000, seed=42).to(dev)
+else:
+    pts = torch.randn(1_000_000, 3).to(dev)
 lms = fa.generate_landmarks(pts, 1000, start_idx=0)
 stree, simplices = core._build_complex(lms, 3)
 simp = torch.as_tensor(simplices[3], device=dev)
