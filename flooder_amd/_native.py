@@ -45,10 +45,10 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_finish_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                         c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_face_values_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "flooder_simplex_weight_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "flooder_prune_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -56,6 +56,9 @@ SIGNATURES = {
                                        c_int, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
+    "flooder_fps_bucket_count": (c_int64, [c_int64]),
+    "flooder_fps_indexed_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
 }

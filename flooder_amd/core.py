@@ -108,13 +108,15 @@ def generate_uniform_weights(num_rand: int, dim: int, device, dtype) -> torch.Te
 
 # ------------------------------------------------------------------------------ landmarks
 def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int] = None,
-                       start_idx: Union[int, None] = None) -> torch.Tensor:
+                       start_idx: Union[int, None] = None, *, index: Optional["PointIndex"] = None) -> torch.Tensor:
     """Farthest-point-sampling landmarks (interface of ``core.py:291-343``).
 
     The reference delegates to ``fpsample.bucket_fps_kdline_sampling`` on the CPU (a kd-tree
     accelerated *exact* FPS); ``fps_h`` is that library's tree height and is accepted for
-    compatibility.  Here the selection runs on the GPU for ROCm tensors (``flooder_fps_f32``:
-    one distance-update + arg-max sweep of the cloud per landmark) and in numpy for CPU tensors.
+    compatibility.  Here the selection runs on the GPU for ROCm tensors - bucketed over the curve-sorted
+    cloud like the reference's library (``flooder_fps_indexed_f32``; ``index``, keyword-only, passes a
+    ``PointIndex`` of ``points`` to reuse) or, for small clouds and dim > 3, one distance-update + arg-max
+    sweep of the cloud per landmark (``flooder_fps_f32``) - and in numpy for CPU tensors.
     Returns ``points[index_set]`` in selection order, same device and dtype as ``points``.
     """
     if n_lms <= 0:
@@ -125,12 +127,21 @@ def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int]
         start_idx = int(torch.randint(n_pts, (1,)).item())
     if not (0 <= start_idx < n_pts):
         raise RuntimeError(f"start_idx ({start_idx}) out of range for {n_pts} points")
-    index_set = fps_indices(points, n_lms, start_idx)
+    index_set = fps_indices(points, n_lms, start_idx, index=index)
     return points[index_set]
 
 
-def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0) -> torch.Tensor:
-    """Indices of the exact FPS order starting at ``start_idx`` (int64, on ``points.device``)."""
+FPS_METHOD = "auto"   # "bucket" (dim <= 3: bucketed over the curve-sorted cloud), "brute" (one full sweep per landmark)
+FPS_BUCKET_MIN_POINTS = 200_000   # below this a brute-force step costs no more than its launch
+
+
+def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Optional[str] = None,
+                index: Optional["PointIndex"] = None) -> torch.Tensor:
+    """Indices of the exact FPS order starting at ``start_idx`` (int64, on ``points.device``).
+
+    ROCm tensors: ``method="bucket"`` (default for dim <= 3 and large clouds) runs ``flooder_fps_indexed_f32`` over
+    the Hilbert-sorted copy of the cloud (``index``: a ``PointIndex`` of ``points`` to reuse, else built here);
+    ``method="brute"`` runs ``flooder_fps_f32``.  Both give the same indices."""
     if points.is_cuda:
         lib = _native.load()
         dim = points.shape[1]
@@ -138,7 +149,28 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0) -> torch.T
             raise RuntimeError("flooder_amd: ambient dimension > 8 is not supported by the HIP kernels")
         pts = points.detach().to(torch.float32).contiguous()
         n = pts.shape[0]
+        method = FPS_METHOD if method is None else method
+        if method == "auto":
+            method = "bucket" if dim <= 3 and (n >= FPS_BUCKET_MIN_POINTS or index is not None) and n_lms > 64 else "brute"
+        if method not in ("bucket", "brute"):
+            raise ValueError("method must be 'bucket' or 'brute'")
+        if method == "bucket" and dim > 3:
+            raise ValueError("bucketed FPS supports ambient dimension <= 3")
         out_idx = torch.empty(n_lms, dtype=torch.int64, device=pts.device)
+        if method == "bucket":
+            index = index if index is not None else PointIndex(pts)
+            nb = int(lib.flooder_fps_bucket_count(n))
+            rows = torch.empty(4 * index.pts.shape[0], dtype=torch.float32, device=pts.device)
+            box = torch.empty(8 * nb, dtype=torch.float32, device=pts.device)
+            key = torch.empty(nb, dtype=torch.int64, device=pts.device)
+            work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
+            with torch.cuda.device(pts.device):
+                st = _native.current_stream_ptr(pts.device)
+                _native.check(lib.flooder_fps_indexed_f32(
+                    _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
+                    int(start_idx), _native.ptr(out_idx), _native.ptr(rows), _native.ptr(box), _native.ptr(key),
+                    _native.ptr(work_best), st), "flooder_fps_indexed_f32")
+            return out_idx
         work_min = torch.empty(4 * n, dtype=torch.float32, device=pts.device)
         work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
         with torch.cuda.device(pts.device):
@@ -428,6 +460,7 @@ class PointIndex:
             _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
                                                  _native.ptr(codes), st), "flooder_morton_f32")
         order = torch.argsort(codes)
+        self.order32 = order.to(torch.int32)  # sorted row -> original index (bucketed FPS reports original indices)
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
         pts = torch.full((n_pad, self.dp), float("inf"), dtype=torch.float32, device=dev)
         pts[:n, :dim] = pts32[order]
@@ -638,6 +671,7 @@ CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spac
 # a cross-shard reduction of them is wanted): no (S, R) store, no face-max pass, and the finish skips every sample
 # that cannot raise a face maximum.  False: sweep -> finish -> flooder_face_max_f32 over the full (S, R) buffer.
 FUSED_FACES = True
+CELL_PROBE = True    # the finish's probe (one greedy tree descent per flagged tile) runs inside the cell sweep
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
@@ -680,7 +714,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # scratch that only the flagged tiles touch.
         F = faces.n_faces
         tiles = (R + 63) // 64
-        ctl = torch.zeros(16, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish
+        ctl = torch.zeros(16, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish ([7]: top count)
         face_bits = torch.zeros((S, F), dtype=torch.int32, device=dev)
         top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
@@ -691,12 +725,14 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(flags), ctl[1:].data_ptr(),
-                _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_faces_f32")
+                _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
+                ctl[7:].data_ptr() if CELL_PROBE else None, _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[4:].data_ptr(),
-                _native.ptr(top), _native.ptr(top_list), _native.ptr(d2), _native.ptr(plan.memb_all), F,
+                _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
+                _native.ptr(plan.memb_all), F,
                 _native.ptr(face_bits), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
@@ -827,8 +863,13 @@ def flood_complex(
         raise ValueError("method 'cell' supports ambient dimension 2 and 3 only")
     if max_dimension is None:
         max_dimension = points.shape[1]
+    shared_index = None  # one curve-sorted copy of the cloud serves the landmark selection and the sweep
     if isinstance(landmarks, Integral):
-        landmarks = generate_landmarks(points, min(landmarks, points.shape[0]), fps_h, start_idx=start_idx)
+        if (points.is_cuda and method != "ball" and points.shape[1] <= 3 and points.dtype in SUPPORTED_DTYPES
+                and _has_hip_kernels() and points.shape[0] >= FPS_BUCKET_MIN_POINTS and landmarks > 64):
+            shared_index = PointIndex(points.to(torch.float32))
+        landmarks = generate_landmarks(points, min(landmarks, points.shape[0]), fps_h, start_idx=start_idx,
+                                       index=shared_index)
     if landmarks.device != points.device:
         raise RuntimeError(f"landmarks.device ({landmarks.device}) != points.device ({points.device})")
     if landmarks.dtype != points.dtype:
@@ -875,7 +916,7 @@ def flood_complex(
             pts_pad = _pad_rows(pts32[torch.argsort(pts32[:, axis])], dp)
             search = pts_pad[:, axis].contiguous()
         else:
-            index = PointIndex(pts32)
+            index = shared_index if shared_index is not None else PointIndex(pts32)
 
     results: List[Tuple[np.ndarray, np.ndarray]] = []  # (simplices (n,k), values (n,)) in update order
     for d in range(max_dimension + 1):

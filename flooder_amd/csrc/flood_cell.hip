@@ -84,7 +84,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, RowSel sel, FaceAcc acc) {
   constexpr int DP = padded_dim(DIM);
@@ -265,6 +265,25 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
 
+    // The chunk's own extent along every face normal (a 2(DIM+1)-plane polytope around its samples, tighter than
+    // the bounding box for skewed simplices and than the simplex's half-spaces for chunks in its interior): a
+    // point within c of a sample has pn.(x - org) within c of that sample's value.
+    float slo[DIM + 1], shi[DIM + 1];
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+      float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        float dd = -po[f];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], p[i][k] - org[k], dd);
+        mn = __builtin_fminf(mn, dd);
+        mx = __builtin_fmaxf(mx, dd);
+      }
+      slo[f] = wave_min_f32(mn);
+      shi[f] = wave_max_f32(mx);
+    }
+
     PHASE(1);
     // ---- gather: leaves of the box tree overlapping [qlo, qhi]; returns their number or -1 (overflow)
     float qlo[DIM], qhi[DIM];
@@ -385,9 +404,13 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         nc[k] = n;
         ncells *= n;
       }
-      float plane_tol[DIM + 1];
+      float slab_lo[DIM + 1], slab_hi[DIM + 1];
 #pragma unroll
-      for (int f = 0; f <= DIM; ++f) plane_tol[f] = c * 1.001f + pslack[f] * (sext + c) + 1e-6f * sext;
+      for (int f = 0; f <= DIM; ++f) {
+        const float tol = c * 1.001f + (pslack[f] + 1e-6f) * (sext + c);
+        slab_lo[f] = slo[f] - tol;
+        slab_hi[f] = shi[f] + tol;
+      }
       auto cell_of = [&](const float (&x)[DP]) {
         int id = 0;
 #pragma unroll
@@ -410,7 +433,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           float dd = -po[f];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], xr[k], dd);
-          in = in && (dd <= plane_tol[f]);
+          in = in && (dd <= slab_hi[f]) && (dd >= slab_lo[f]);
         }
         return in;
       };
@@ -509,6 +532,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         c *= 2.f;
         continue;
       }
+      if (n_keep > CAPW && attempt >= exh_tries) { give_up = true; ++g_cap; break; }  // leave it to the finish
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
@@ -760,6 +784,62 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         if (__ballot(open[i]) != 0ull) {
+          if (acc.top) {
+            // probe: one greedy descent of the box tree for the tile's open samples (nearest child box at every
+            // level, one leaf evaluated) gives each of them a finite upper bound; the tile with the largest one
+            // becomes its simplex's "top" tile, which the finish settles first
+            float tlo[DIM], thi[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              tlo[k] = wave_min_f32(open[i] ? p[i][k] : __builtin_inff());
+              thi[k] = wave_max_f32(open[i] ? p[i][k] : -__builtin_inff());
+            }
+            int grp = 0;
+            for (int lvl = top; lvl >= 0; --lvl) {
+              const int idx = grp * FAN + lane;
+              const bool ok = idx < (int)lv.count[lvl];
+              float lo[DP], hi[DP];
+              const uint32_t nb_ = (uint32_t)((int)lv.off[lvl] + (ok ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+              load_row_at<DP>(nodes, nb_, lo);
+              load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
+              float lb = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
+                lb = __builtin_fmaf(gap, gap, lb);
+              }
+              lb = ok ? lb : __builtin_inff();
+              const float mn = wave_min_f32(lb);
+              grp = grp * FAN + __builtin_ctzll(__ballot(lb == mn));
+            }
+            const float* cp = pts + (int64_t)grp * LEAF * DP;
+            float bb = best[i];
+#pragma unroll
+            for (int h = 0; h < LEAF; h += 8) {
+              typename RowVec<DP>::type cc[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float t0 = p[i][0] - cc[u][0];
+                float d2 = t0 * t0;
+                t0 = p[i][1] - cc[u][1];
+                d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = p[i][2] - cc[u][2];
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                bb = __builtin_fminf(bb, d2);
+              }
+            }
+            best[i] = bb;
+            const uint32_t key = wave_max_u32(open[i] ? __float_as_uint(bb) : 0u);
+            if (lane == 0 && key != 0u) {
+              const unsigned long long old =
+                  atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)(s * tiles64 + q * SPL + i));
+              if (old == 0ull) acc.top_list[atomicAdd(acc.top_count, 1)] = (int)s;
+            }
+          }
           if (q * CHUNK + i * 64 + lane < n_live)
             out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
           if (lane == 0) {
@@ -830,7 +910,7 @@ struct CellOp {
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP, g_cell_tries, queue, out, flag_list, flag_count, stats, sel, acc);
+                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP, g_cell_tries, g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc);
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
@@ -877,20 +957,24 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           ld_out, row_list, row_cnt, list_stride, flag_list, flag_count, stats,
-                          FaceAcc{nullptr, nullptr, 0}, stream, "flooder_sweep_cell_f32: bad argument");
+                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, stream,
+                          "flooder_sweep_cell_f32: bad argument");
 }
 
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* stats, void* stream) {
+                                 uint64_t* top, int32_t* top_list, int32_t* top_count, uint64_t* stats,
+                                 void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
-  if (!memb || !face_bits || n_faces < 1 || n_faces > 32)
+  if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)))
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_faces_f32: bad argument");
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, R, nullptr, nullptr, 0, flag_list, flag_count, stats,
-                          FaceAcc{memb, face_bits, n_faces}, stream, "flooder_sweep_cell_faces_f32: bad argument");
+                          FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
+                                  top_count},
+                          stream, "flooder_sweep_cell_faces_f32: bad argument");
 }
 
 }  // extern "C"

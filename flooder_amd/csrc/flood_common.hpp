@@ -22,6 +22,10 @@ extern int g_cell_exh_sparse;
 extern int g_cell_brute_max;
 extern int g_finish_focus_pct;
 extern int g_cell_tries;
+extern int g_cell_exh_tries;
+extern int g_finish_items_cap;
+extern int g_fps_switch;
+extern int g_fps_rpl;
 extern int g_curve;
 char* err_buf();
 int fail(int code, const char* msg);
@@ -143,6 +147,11 @@ struct FaceAcc {
   const uint32_t* memb;
   uint32_t* face_bits;
   int n_faces;
+  // per simplex: (largest upper bound of an open sample << 32 | tile id) of its flagged tiles, and the list of
+  // simplices that have one; filled by the cell sweep's probe, read by the finish (may be null: no probe)
+  unsigned long long* top;
+  int32_t* top_list;
+  int32_t* top_count;
 };
 
 // Which sample rows of a simplex a sweep works on: all R rows of the weight table (list == nullptr), or

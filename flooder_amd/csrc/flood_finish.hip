@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_count,
-    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int refine_pct, float focus_frac, int32_t* __restrict__ queue,
+    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int items_cap, int refine_pct, float focus_frac, int32_t* __restrict__ queue,
     uint32_t* __restrict__ d2, FaceAcc acc, unsigned long long* __restrict__ top,
     int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
@@ -49,12 +49,12 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   const int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
   if (mode != 0) {
     subs = subs_max;
-    while (subs > 1 && n_base * subs > 32768) subs >>= 1;
+    while (subs > 1 && n_base * subs > items_cap) subs >>= 1;
     if (subs_max > 1 && n_base * 64 <= (int64_t)gridDim.x * 4) subs = 64;
   }
   if (n_base == 0) return;
   // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
-  if (mode == 0 && n_list <= SHORT_LIST) return;
+  if (mode != 2 && n_list <= SHORT_LIST) return;
   const int64_t n_items = n_base * subs;
   const int per_sub = 64 / subs;
   const int topl = lv.n_levels - 1;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
     } else {
       item = flag_list[g];
       s = item / tiles;
-      if (mode == 2 && top[s] != 0ull && (int)(uint32_t)(top[s] & 0xffffffffull) == item) continue;
+      if (mode == 2 && n_list > SHORT_LIST && top[s] != 0ull && (int)(uint32_t)(top[s] & 0xffffffffull) == item) continue;
     }
     const int tile = item - (int)(s * tiles);
     const int slane = sub * per_sub + (lane & (per_sub - 1));  // sample slot of this lane inside the tile
@@ -374,12 +374,14 @@ template <int DIM>
 struct FinishOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                  int k1, int R, int64_t ns, const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
-                 uint32_t* d2, FaceAcc acc, unsigned long long* top, int32_t* top_list, unsigned long long* stats,
-                 hipStream_t st) {
+                 uint32_t* d2, FaceAcc acc, unsigned long long* top, int32_t* top_list, int probed,
+                 unsigned long long* stats, hipStream_t st) {
     const int grid = g_bvh_grid;
-    for (int mode = 0; mode < 3; ++mode) {  // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile
+    // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile (filled by the probe -
+    // the cell sweep's when `probed`, else pass 0 here)
+    for (int mode = probed ? 1 : 0; mode < 3; ++mode) {
       hipLaunchKernelGGL((finish_faces_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, k1,
-                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, ctl + mode, d2, acc, top,
+                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, ctl + mode, d2, acc, top,
                          top_list, ctl + 3, stats);
     }
     return check_launch("finish_faces");
@@ -393,16 +395,16 @@ extern "C" {
 int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                              const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
-                             uint64_t* top, int32_t* top_list, uint32_t* d2_scratch, const uint32_t* memb,
-                             int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream) {
+                             uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
+                             const uint32_t* memb, int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !flag_list || !flag_count || !ctl || !top || !top_list || !d2_scratch ||
       !memb || !face_bits || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 1 || n_faces < 1 || n_faces > 32)
     return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<FinishOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, flag_list,
-                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces},
-                                reinterpret_cast<unsigned long long*>(top), top_list,
+                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces, nullptr, nullptr, nullptr},
+                                reinterpret_cast<unsigned long long*>(top), top_list, probed,
                                 reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
 }
 

@@ -623,6 +623,22 @@ int flooder_set_option(const char* name, int value) {
     g_finish_focus_pct = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "fps_switch") == 0 && value >= 0) {
+    g_fps_switch = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "fps_rpl") == 0 && (value == 0 || value == 1 || value == 4)) {
+    g_fps_rpl = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_exh_tries") == 0 && value >= 0 && value <= 8) {
+    g_cell_exh_tries = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "finish_items_cap") == 0 && value >= 1024) {
+    g_finish_items_cap = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_tries") == 0 && value >= 1 && value <= 8) {
     g_cell_tries = value;
     return FLOODER_OK;

@@ -202,13 +202,17 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * atomic max on the d2 bits; zeroed by the caller) for each face f whose bit is set in memb[r] (n_faces <= 32;
  * random mode: one face, every memb word = 1).  The (S, R) buffer becomes scratch: only the tiles appended to
  * flag_list are written (bit 31 of a word = that sample is already settled), the other cells stay undefined.
- * Followed by flooder_finish_faces_f32 and flooder_face_values_f32.
+ * top / top_list / top_count (all NULL, or n_simplices zeroed uint64 / n_simplices int32 / one zeroed int32): the
+ * probe of the finish folded into the sweep - every flagged tile gets one greedy tree descent for its open samples
+ * (finite upper bounds) while they are still in registers, and top[s] = (largest such bound << 32 | tile id).
+ * Followed by flooder_finish_faces_f32 (probed = 1 when top was passed here) and flooder_face_values_f32.
  */
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* stats, void* stream);
+                                 uint64_t* top, int32_t* top_list, int32_t* top_count, uint64_t* stats,
+                                 void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
@@ -216,15 +220,17 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Three passes: a probe (one
  * greedy descent per tile: finite upper bounds, and per simplex the tile with the largest one), the top tile of
  * every simplex, then all other tiles.  Face values equal the exhaustive result bit for bit.
- *   ctl: 8 zeroed int32 (queue heads, counters); top: n_simplices zeroed uint64; top_list: n_simplices int32;
+ *   ctl: 8 zeroed int32 (queue heads; ctl[3] = number of entries of top_list, which the cell sweep's probe may
+ *   already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64 (zeroed unless
+ *   probed); top_list: n_simplices int32;
  *   stats: NULL or 7 zeroed uint64 {leaves evaluated, leaves tested, nodes expanded, -, tiles dropped on arrival in
  *   the last pass, samples live on arrival in the last pass, -}.
  */
 int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                              const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
-                             uint64_t* top, int32_t* top_list, uint32_t* d2_scratch, const uint32_t* memb,
-                             int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream);
+                             uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
+                             const uint32_t* memb, int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream);
 
 /* out_face[i] = sqrt(float(face_bits[i])), i < n: the filtration values (core.py:257, 272: distances, not squares). */
 int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_face, void* stream);
@@ -271,6 +277,23 @@ int flooder_fill_u32(uint32_t* buf, int64_t n, uint32_t value, void* stream);
  */
 int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms, int64_t start,
                     int64_t* out_idx, float* work_min, uint64_t* work_best, void* stream);
+
+/*
+ * Bucketed exact farthest-point sampling (dim <= 3) over the curve-sorted copy of the cloud that the sweeps use.
+ * Replaces fpsample.bucket_fps_kdline_sampling (flooder/core.py:337-343: exact FPS accelerated by kd-tree buckets):
+ * buckets of 64 or 256 consecutive sorted rows carry a bounding box and their largest running minimum; a new
+ * landmark only updates the buckets whose box is closer to it than that maximum.  Same selection as
+ * flooder_fps_f32, bit for bit (same per-point arithmetic; ties: lowest original index).
+ *   pts / ld: the cloud in its ORIGINAL order (out_idx refers to it); pts_sorted: padded rows in curve order;
+ *   order: int32, order[j] = original index of sorted row j;
+ *   rows: 4 * n_pts float32 scratch (16-byte aligned); bucket_box: 8 * flooder_fps_bucket_count(n_pts) float32;
+ *   bucket_key: flooder_fps_bucket_count(n_pts) uint64; work_best: 64 * n_lms uint64, zeroed by the caller.
+ * Options "fps_switch" (first bucketed iteration; 0 = auto) and "fps_rpl" (rows per lane and bucket: 1 or 4; 0 = auto).
+ */
+int64_t flooder_fps_bucket_count(int64_t n_pts);
+int flooder_fps_indexed_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,
+                            const int32_t* order, int n_lms, int64_t start, int64_t* out_idx, float* rows,
+                            float* bucket_box, uint64_t* bucket_key, uint64_t* work_best, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,40 @@ def test_cfg4_full_size_2m_6d(dev):
     seg = (1 - w1)[None, :, None] * L[e[pe, 1]][:, None, :] + w1[None, :, None] * L[e[pe, 0]][:, None, :]
     d1, _ = tree.query(seg, workers=-1)
     assert_close_filtration(ev[pe], d1.max(axis=1), P, "cfg4 edge sample")
+
+
+@pytest.mark.parametrize("case", ["gauss1m", "torus300k", "eight2d", "line1d", "dups"])
+def test_bucketed_fps_equals_brute_force(dev, case):
+    """flooder_fps_indexed_f32 (buckets over the Hilbert-sorted cloud, as the reference's bucket FPS) selects exactly
+    what flooder_fps_f32 (one full sweep per landmark) selects - every index, including ties (duplicated points)."""
+    g = torch.Generator().manual_seed(5)
+    if case == "gauss1m":
+        pts, k, start = torch.randn(1_000_000, 3, generator=g), 1000, 0
+    elif case == "torus300k":
+        pts, k, start = torch.as_tensor(fo.noisy_torus(300_000, seed=5)), 700, 1234
+    elif case == "eight2d":
+        pts, k, start = fa.generate_figure_eight_points_2d(400_000, noise_std=0.02, seed=5).float(), 500, 7
+    elif case == "line1d":
+        pts, k, start = torch.rand(250_000, 1, generator=g), 300, 0
+    else:
+        base = torch.rand(150_000, 3, generator=g)
+        pts, k, start = torch.cat([base, base[:100_000]]), 400, 3       # 100 k exact duplicates
+    tp = pts.to(dev)
+    a = core.fps_indices(tp, k, start, method="brute").cpu().numpy()
+    b = core.fps_indices(tp, k, start, method="bucket").cpu().numpy()
+    assert np.array_equal(a, b)
+    lib = _native.load()
+    for rpl, sw in ((4, 8), (1, 1), (4, 1)):
+        try:
+            assert lib.flooder_set_option(b"fps_rpl", rpl) == 0 and lib.flooder_set_option(b"fps_switch", sw) == 0
+            c = core.fps_indices(tp, min(k, 200), start, method="bucket").cpu().numpy()
+        finally:
+            lib.flooder_set_option(b"fps_rpl", 0)
+            lib.flooder_set_option(b"fps_switch", 0)
+        assert np.array_equal(a[:len(c)], c), (rpl, sw)
+
+
+def test_bucketed_fps_16m_equals_brute_force(cheese16m):
+    pts, tp, idx = cheese16m            # (the fixture's selection runs the default = bucketed path)
+    brute = core.fps_indices(tp, 600, 0, method="brute").cpu().numpy()
+    assert np.array_equal(idx.cpu().numpy()[:600], brute)

@@ -64,6 +64,7 @@ PY
             timeout 300 python tools/phase_timers.py $wl > $OUT/phase_timers_$wl.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/phase_timers_$wl.txt ;;
+    tfps) timeout 600 python tools/time_fps.py > $OUT/time_fps.txt 2>&1; cat $OUT/time_fps.txt ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
   esac
