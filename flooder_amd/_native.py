@@ -33,6 +33,10 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "flooder_bbox_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_curve_key_bits": (c_int, [c_int]),
+    "flooder_index_sort_bytes": (c_int64, [c_int64]),
+    "flooder_index_sort": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "flooder_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_bvh_node_count": (c_int64, [c_int64]),
     "flooder_bvh_build_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

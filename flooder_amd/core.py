@@ -459,14 +459,21 @@ class PointIndex:
         with _span(timer, "morton"):
             _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
                                                  _native.ptr(codes), st), "flooder_morton_f32")
-        order = torch.argsort(codes)
-        self.order32 = order.to(torch.int32)  # sorted row -> original index (bucketed FPS reports original indices)
+        # sorted row -> original index (int32); radix sort over the bits the codes use
+        self.order32 = torch.empty(n, dtype=torch.int32, device=dev)
+        codes_sorted = torch.empty(n, dtype=torch.int64, device=dev)
+        tmp_bytes = int(lib.flooder_index_sort_bytes(n))
+        if tmp_bytes < 0:
+            raise RuntimeError("flooder_index_sort_bytes failed")
+        tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+        with _span(timer, "sort"):
+            _native.check(lib.flooder_index_sort(_native.ptr(codes), n, int(lib.flooder_curve_key_bits(dim)),
+                                                 _native.ptr(codes_sorted), _native.ptr(self.order32), _native.ptr(tmp),
+                                                 tmp_bytes, st), "flooder_index_sort")
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
-        pts = torch.full((n_pad, self.dp), float("inf"), dtype=torch.float32, device=dev)
-        pts[:n, :dim] = pts32[order]
-        if self.dp > dim:
-            pts[:n, dim:] = 0.0
-        self.pts = pts
+        self.pts = torch.empty((n_pad, self.dp), dtype=torch.float32, device=dev)
+        _native.check(lib.flooder_gather_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
+                                                  _native.ptr(self.pts), n_pad, st), "flooder_gather_rows_f32")
         n_nodes = int(lib.flooder_bvh_node_count(n))
         self.nodes = torch.empty((n_nodes, 2 * self.dp), dtype=torch.float32, device=dev)
         with _span(timer, "bvh_build"):

@@ -30,10 +30,20 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 97; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 3; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 97; int g_curve_bits = 0; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
+// bits per axis of the curve codes: option "curve_bits" (default 12: 36-bit keys in 3D, five radix passes; a finer
+// curve than the 4096^3 grid does not make the 16-point leaves measurably tighter), at most floor(63 / dim) and 21
+inline int curve_bits_per_axis(int dim) {
+  int cap = 63 / dim;
+  if (cap > 21) cap = 21;
+  int b = g_curve_bits > 0 ? g_curve_bits : 12;
+  if (dim == 1) b = cap;          // (one axis: the code is the coordinate; keep its full resolution)
+  return b < cap ? b : cap;
+}
+
 struct Box {
   float lo[FLOODER_MAX_DIM];
   float scale[FLOODER_MAX_DIM];
@@ -93,10 +103,10 @@ __global__ __launch_bounds__(64) void bbox_final_kernel(const float* __restrict_
 template <int DIM>
 __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
                                                      const float* __restrict__ dbox, int64_t* __restrict__ codes,
-                                                     int curve) {
+                                                     int curve, int BITS) {
   // curve 0: Morton (Z-order) codes; 1: Hilbert codes (Skilling's axes-to-transpose transform, then the same
-  // bit interleave) - consecutive codes are neighbours in space, so 16 consecutive points make tighter leaves
-  constexpr int BITS = 63 / DIM > 21 ? 21 : 63 / DIM;
+  // bit interleave) - consecutive codes are neighbours in space, so 16 consecutive points make tighter leaves.
+  // BITS per axis (flooder_curve_key_bits(dim) / dim): the radix sort of the codes costs one pass per 8 key bits
   Box box;
 #pragma unroll
   for (int k = 0; k < DIM; ++k) {
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ p
     }
     uint64_t code = 0;
     if (curve == 1 && DIM > 1) {
-      constexpr uint32_t MTOP = 1u << (BITS - 1);
+      const uint32_t MTOP = 1u << (BITS - 1);
       for (uint32_t Q = MTOP; Q > 1u; Q >>= 1) {
         const uint32_t P = Q - 1u;
 #pragma unroll
@@ -621,7 +631,8 @@ struct MortonOp {
   static int run(const float* pts, int64_t n, int ld, const float* box, int64_t* codes, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes, g_curve);
+    hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes, g_curve,
+                       curve_bits_per_axis(DIM));
     return check_launch("morton");
   }
 };
@@ -719,6 +730,11 @@ int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const f
   if (!pts || !box || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
     return fail(FLOODER_E_ARG, "flooder_morton_f32: bad argument");
   return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, (hipStream_t)stream);
+}
+
+int flooder_curve_key_bits(int dim) {
+  if (dim < 1 || dim > FLOODER_MAX_DIM) return 0;
+  return curve_bits_per_axis(dim) * dim;
 }
 
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream) {

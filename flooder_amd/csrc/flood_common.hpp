@@ -22,6 +22,7 @@ extern int g_cell_exh_sparse;
 extern int g_cell_brute_max;
 extern int g_finish_focus_pct;
 extern int g_cell_tries;
+extern int g_curve_bits;
 extern int g_cell_exh_tries;
 extern int g_finish_items_cap;
 extern int g_fps_switch;

@@ -639,6 +639,10 @@ int flooder_set_option(const char* name, int value) {
     g_finish_items_cap = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "curve_bits") == 0 && value >= 0 && value <= 21) {
+    g_curve_bits = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_tries") == 0 && value >= 1 && value <= 8) {
     g_cell_tries = value;
     return FLOODER_OK;

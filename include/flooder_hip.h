@@ -58,7 +58,11 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "bvh_refine_pct": threshold of the tree sweep's transposed refine in percent of its cost model (100;
  *                     the full sweep uses three times the value), "bvh_leaf_batch": leaves fetched per step
  *                     by the work-list tree sweep (1, or 4 through LDS);
- *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32;
+ *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32; "curve_bits": bits per axis;
+ *   "cell_brute_max": kept points up to which a chunk is evaluated straight from the compacted list (160);
+ *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
+ *                     evaluation (3); "finish_focus_pct", "finish_items_cap": focus rounds and tile splitting of
+ *                     flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
@@ -148,6 +152,22 @@ int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* bo
  * 16-point leaves of the box tree are tight - the tree sweep of cfg 2 takes 3.3 ms instead of 6.5 ms. */
 int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
                        void* stream);
+
+/* Number of low bits a curve code of flooder_morton_f32 occupies for ambient dimension dim (bits per axis x dim;
+ * option "curve_bits": bits per axis, default 12, at most floor(63 / dim) and 21). */
+int flooder_curve_key_bits(int dim);
+
+/* Sort of the curve codes: order[j] = index of the point with the j-th smallest code (stable), codes_sorted = the
+ * codes in that order.  rocprim::radix_sort_pairs over the low key_bits bits only (flooder_curve_key_bits).
+ * tmp: flooder_index_sort_bytes(n_pts) bytes of device scratch.  Replaces torch.argsort of core.py:143. */
+int64_t flooder_index_sort_bytes(int64_t n_pts);
+int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
+                       void* tmp, int64_t tmp_bytes, void* stream);
+
+/* out (n_pad x flooder_padded_dim(dim) floats) = rows order[0], order[1], ... of pts, padding columns 0, then
+ * +inf rows up to n_pad (a multiple of FLOODER_BVH_LEAF).  Replaces points[indices] of core.py:143. */
+int flooder_gather_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* out,
+                            int64_t n_pad, void* stream);
 
 /* Number of nodes (all levels, each padded to a multiple of 64) of the tree over n_pts points. */
 int64_t flooder_bvh_node_count(int64_t n_pts);
