@@ -51,8 +51,9 @@ WORKLOADS = {
                   gen="gauss", n=100_000, dim=3, n_lms=300, ppe=12),
 }
 
-KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "fallback": "sweep_bvh_kernel (exact finish)",
-                  "face_max": "face_max_kernel", "reduce": "all_reduce(MIN)", "index": "index build",
+KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
+                  "face_max": "face_values_kernel", "reduce": "all_reduce(MIN)",
+                  "index": "index build (bbox, curve codes, rocprim radix sort, gather, box tree)",
                   "ball_count": "ball_scan_kernel<count>", "ball_fill": "ball_scan_kernel<fill>"}
 
 
@@ -103,7 +104,7 @@ def parse_args():
     ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
-    ap.add_argument("--order", default="axis", choices=["axis", "ball", "weight"],
+    ap.add_argument("--order", default="axis", choices=["axis", "ball", "weight", "axis_rev", "random", "middle_out", "ends_in"],
                     help="queue order of the simplices: axis (sorted along the widest axis, as the reference), ball "
                          "(experiment: reference candidate count, descending), weight (core.simplex_order)")
     ap.add_argument("--unfused", action="store_true", help="sweep -> finish -> face_max over the full (S, R) buffer")
@@ -209,6 +210,20 @@ def main():
     del pts_pad0, search0, lo0, hi0
     if args.order == "ball":  # experiment: heaviest simplices (by the reference's candidate count) first
         perm = torch.argsort(cnt0, descending=True)
+        verts, centers, radii, simp, cnt0 = verts[perm], centers[perm], radii[perm], simp[perm], cnt0[perm]
+    elif args.order in ("axis_rev", "random", "middle_out", "ends_in"):  # experiments on the queue order
+        ar = torch.arange(S_all, device=dev)
+        if args.order == "axis_rev":
+            perm = ar.flip(0)
+        elif args.order == "random":
+            perm = torch.randperm(S_all, generator=torch.Generator().manual_seed(0)).to(dev)
+        else:
+            half = S_all // 2
+            a, b = ar[:half].flip(0), ar[half:]                   # from the median outwards
+            n = min(len(a), len(b))
+            perm = torch.cat([torch.stack([b[:n], a[:n]], 1).reshape(-1), b[n:], a[n:]])
+            if args.order == "ends_in":
+                perm = perm.flip(0)
         verts, centers, radii, simp, cnt0 = verts[perm], centers[perm], radii[perm], simp[perm], cnt0[perm]
     elif args.order == "weight":  # the product's order: core.simplex_order (device-side estimate, untimed here)
         perm = core.simplex_order(core.PointIndex(pts_full), verts)

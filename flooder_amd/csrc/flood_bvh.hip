@@ -85,18 +85,33 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float* __restri
 }
 
 template <int DIM>
-__global__ __launch_bounds__(64) void bbox_final_kernel(const float* __restrict__ partial, int n_partial,
-                                                        float* __restrict__ box) {
+__global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict__ partial, int n_partial,
+                                                         float* __restrict__ box) {
+  // all partials in flight at once (256 threads x 16 floats), then wave + block reduction
+  float lo[DIM], hi[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
+  for (int i = threadIdx.x; i < n_partial; i += 256) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      lo[k] = __builtin_fminf(lo[k], partial[i * 16 + k]);
+      hi[k] = __builtin_fmaxf(hi[k], partial[i * 16 + 8 + k]);
+    }
+  }
+  __shared__ float s_lo[4][DIM], s_hi[4][DIM];
 #pragma unroll
   for (int k = 0; k < DIM; ++k) {
-    float a = __builtin_inff(), b = -__builtin_inff();
-    for (int i = threadIdx.x; i < n_partial; i += 64) {
-      a = __builtin_fminf(a, partial[i * 16 + k]);
-      b = __builtin_fmaxf(b, partial[i * 16 + 8 + k]);
-    }
-    a = wave_min_f32(a);
-    b = wave_max_f32(b);
-    if (threadIdx.x == 0) { box[k] = a; box[8 + k] = b; }
+    const float a = wave_min_f32(lo[k]);
+    const float b = wave_max_f32(hi[k]);
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][k] = a; s_hi[threadIdx.x >> 6][k] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < DIM) {
+    const int k = threadIdx.x;
+    float a = s_lo[0][k], b = s_hi[0][k];
+    for (int w = 1; w < 4; ++w) { a = __builtin_fminf(a, s_lo[w][k]); b = __builtin_fmaxf(b, s_hi[w][k]); }
+    box[k] = a;
+    box[8 + k] = b;
   }
 }
 
@@ -192,28 +207,32 @@ __global__ __launch_bounds__(256) void bvh_leaf_kernel(const float* __restrict__
 template <int DIM>
 __global__ __launch_bounds__(256) void bvh_inner_kernel(const float* __restrict__ child, int64_t n_child,
                                                         int64_t n_nodes_pad, float* __restrict__ nodes) {
+  // one WAVE per node: lane = child box, 2 x DIM wave reductions (the 64 child boxes are one coalesced read)
   constexpr int DP = padded_dim(DIM);
-  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= n_nodes_pad) return;
   float lo[DP], hi[DP];
 #pragma unroll
   for (int k = 0; k < DP; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
-  for (int u = 0; u < FAN; ++u) {
-    const int64_t c = node * FAN + u;
-    if (c < n_child) {
-      float a[DP], b[DP];
-      load_row<DP>(child + c * 2 * DP, a);
-      load_row<DP>(child + c * 2 * DP + DP, b);
+  const int64_t c = node * FAN + lane;
+  if (c < n_child) {
+    float a[DP], b[DP];
+    load_row<DP>(child + c * 2 * DP, a);
+    load_row<DP>(child + c * 2 * DP + DP, b);
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) {
-        lo[k] = __builtin_fminf(lo[k], a[k]);
-        hi[k] = __builtin_fmaxf(hi[k], b[k]);
-      }
-    }
+    for (int k = 0; k < DIM; ++k) { lo[k] = a[k]; hi[k] = b[k]; }
   }
-  float* dst = nodes + node * 2 * DP;
 #pragma unroll
-  for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+  for (int k = 0; k < DIM; ++k) {
+    lo[k] = wave_min_f32(lo[k]);
+    hi[k] = wave_max_f32(hi[k]);
+  }
+  if (lane == 0) {
+    float* dst = nodes + node * 2 * DP;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+  }
 }
 
 // ------------------------------------------------------------------------------------ sweep
@@ -644,7 +663,7 @@ struct BboxOp {
     if (blocks > FLOODER_BBOX_BLOCKS) blocks = FLOODER_BBOX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bbox_partial_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, partial);
-    hipLaunchKernelGGL((bbox_final_kernel<DIM>), dim3(1), dim3(64), 0, st, partial, (int)blocks, box);
+    hipLaunchKernelGGL((bbox_final_kernel<DIM>), dim3(1), dim3(256), 0, st, partial, (int)blocks, box);
     return check_launch("bbox");
   }
 };
@@ -658,7 +677,7 @@ struct BuildOp {
                        pts, n_pts, pad0, nodes + lv.off[0] * 2 * DP);
     for (int l = 1; l < lv.n_levels; ++l) {
       int64_t pad = (lv.count[l] + FAN - 1) / FAN * FAN;
-      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 255) / 256)), dim3(256), 0, st,
+      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 3) / 4)), dim3(256), 0, st,
                          nodes + lv.off[l - 1] * 2 * DP, lv.count[l - 1], pad, nodes + lv.off[l] * 2 * DP);
     }
     return check_launch("bvh_build");

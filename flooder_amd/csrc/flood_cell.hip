@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   unsigned long long t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   unsigned long long g_gather0 = 0, g_gather = 0, g_cap = 0, g_tries = 0, g_brute = 0;
+#ifdef FLOODER_WAVE_END
+  const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (;;) {
     PHASE_T0();
@@ -874,6 +877,17 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     }
 #endif
   }
+#ifdef FLOODER_WAVE_END
+  // diagnostic build: when did every wave start and finish?  (plain per-wave stores instead of the shared counters,
+  // whose same-address atomics would themselves stretch the end of the kernel)
+  if (stats) {
+    if (lane == 0) {
+      stats[64 + 2 * (blockIdx.x * 4 + wv)] = t_wave0;
+      stats[65 + 2 * (blockIdx.x * 4 + wv)] = __builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
+#endif
   if (stats) {
 #ifdef FLOODER_PHASE_TIMERS
     if (lane == 0)

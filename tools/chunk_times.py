@@ -44,3 +44,32 @@ for g in late:
 edges = np.linspace(t0, t1, 21)
 busy = [(np.minimum(t[ok, 1], b) - np.maximum(t[ok, 0], a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
 print("busy waves per 5% time slice:", np.round(busy).astype(int).tolist())
+
+# where in the queue do the long chunks sit?  (queue position = simplex-major chunk id)
+pos = np.nonzero(ok)[0]
+d = dur[ok]
+for a, b in zip(np.linspace(0, len(pos), 11)[:-1].astype(int), np.linspace(0, len(pos), 11)[1:].astype(int)):
+    seg = d[a:b]
+    print(f"queue {a:7d}..{b:7d}: mean {seg.mean():7.0f} p50 {np.percentile(seg, 50):7.0f} p99 {np.percentile(seg, 99):8.0f} max {seg.max():8.0f} ticks; started {(t[pos[a:b], 0] - t0).min():8.0f}..{(t[pos[a:b], 0] - t0).max():8.0f}")
+# chunks still running in the last 15 % of the kernel: how long are they, when did they start?
+late = ok & (t[:, 1] > t0 + 0.85 * (t1 - t0))
+print(f"chunks ending in the last 15%: {late.sum()}, of them longer than 10x the mean: {(dur[late] > 10 * dur[ok].mean()).sum()}, "
+      f"total wave-time {dur[late].sum() / (t1 - t0):.0f} wave-spans; exhaustive {((t[late, 2] >> 44) & 1).sum()}")
+hist, edges2 = np.histogram(np.log10(np.maximum(d, 1)), bins=12)
+print("log10(duration ticks) histogram:", [(round(float(e), 2), int(h)) for e, h in zip(edges2[:-1], hist)])
+print("share of total wave-time by duration class (ticks): " + ", ".join(
+    f"{lo}-{hi}: {d[(d >= lo) & (d < hi)].sum() / d.sum() * 100:.1f}%" for lo, hi in ((0, 2000), (2000, 5000), (5000, 10000), (10000, 20000), (20000, 10**9))))
+
+print("longest chunks:")
+names = ["pop", "samples", "gather0", "density", "gather1", "count", "prefix", "scatter", "query", "brute", "output"]
+for g in np.argsort(-dur)[:40]:
+    s_, q = divmod(int(g), chunks)
+    info = int(t[g, 2])
+    ph = " ".join(f"{n}={int(v) // 1000}" for n, v in zip(names, t[g, 5:16]) if int(v) >= 20000)
+    print(f"  dur {dur[g]:7.0f} start {t[g, 0] - t0:8.0f} simplex {s_:5d} q {q:2d} n_cand {info & 0xfffff:6d} n_keep {(info >> 20) & 0xfffff:6d} "
+          f"att {(info >> 40) & 15} exh {(info >> 44) & 1} steps {t[g, 3] >> 40:4d} | kcyc {ph}")
+# how the long chunks split by kind
+longm = ok & (dur > 10000)
+exh = ((t[:, 2] >> 44) & 1).astype(bool)
+print(f"chunks > 10000 ticks: {longm.sum()} (exhaustive {np.sum(longm & exh)}), wave-time share {dur[longm].sum() / dur[ok].sum() * 100:.1f}%; "
+      f"phase shares inside them: " + " ".join(f"{n}={t[longm, 5 + i].sum() / t[longm, 5:16].sum() * 100:.0f}%" for i, n in enumerate(names)))

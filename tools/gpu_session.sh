@@ -16,7 +16,9 @@ for s in $STEPS; do
     bench3) timeout 600 python bench.py --workload cfg3 --no-cpu-baseline > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ;;
     bench5) timeout 900 python bench.py --workload cfg5 --no-cpu-baseline --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ;;
     bench2) timeout 600 python bench.py --gpus 2 --no-cpu-baseline > $OUT/bench_cfg2_2ranks.json 2> $OUT/bench_cfg2_2ranks.err; cut -c1-400 $OUT/bench_cfg2_2ranks.json; tail -3 $OUT/bench_cfg2_2ranks.err ;;
-    prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -5 $OUT/collect_${s#prof:}.log ;;
+    prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
+            python tools/summarize_profiles.py ${s#prof:} r2_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
+            mkdir -p $OUT/profiles && cp profiles/r2_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
     timers) cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
@@ -53,17 +55,32 @@ fin = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows
 print("finish passes (us), triples probe/top/rest:", [round(x, 1) for x in fin[-9:]])
 agg = collections.defaultdict(list)
 for r in rows:
-    agg[r["Kernel_Name"].split("(")[0][-60:]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
+    nm = r["Kernel_Name"]
+    nm = nm.split("(anonymous namespace)::")[1] if "(anonymous namespace)::" in nm else nm
+    agg[nm.split("(")[0][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:22]:
     print(f"{k:62s} n={len(v):4d} mean {sum(v)/len(v):9.1f} us")
 PY
             rm -rf $OUT/trace_$wl ;;
+    ctimes:*) W=${s#ctimes:}
+            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            timeout 300 python tools/chunk_times.py $W > $OUT/chunk_times_$W.txt 2>&1
+            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            grep -v "^  ends\|kcycles" $OUT/chunk_times_$W.txt ;;
+    wends:*) IFS=: read -r _ wl W <<< "$s"
+            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
+            FLOODER_HIPCC_FLAGS=-DFLOODER_WAVE_END python -m flooder_amd.build --force > $OUT/build_wend.log 2>&1
+            timeout 300 python tools/wave_ends.py $wl ${W:-1} > $OUT/wave_ends_${wl}_${W:-1}.txt 2>&1
+            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            tail -2 $OUT/wave_ends_${wl}_${W:-1}.txt ;;
     ptimers:*) wl=${s#ptimers:}
             cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
             timeout 300 python tools/phase_timers.py $wl > $OUT/phase_timers_$wl.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/phase_timers_$wl.txt ;;
+    sortbench) hipcc -O3 --offload-arch=gfx950 tools/sort_bench.hip -o /tmp/sort_bench > $OUT/sort_build.log 2>&1 && timeout 120 /tmp/sort_bench > $OUT/sort_bench.txt 2>&1; cat $OUT/sort_bench.txt ;;
     tfps) timeout 600 python tools/time_fps.py > $OUT/time_fps.txt 2>&1; cat $OUT/time_fps.txt ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
