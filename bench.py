@@ -108,6 +108,8 @@ def parse_args():
                     help="queue order of the simplices: axis (sorted along the widest axis, as the reference), ball "
                          "(experiment: reference candidate count, descending), weight (core.simplex_order)")
     ap.add_argument("--unfused", action="store_true", help="sweep -> finish -> face_max over the full (S, R) buffer")
+    ap.add_argument("--units", default=None, help="cut sizes of the sample bisection, e.g. 1024/256/64/16")
+    ap.add_argument("--no-super", action="store_true", help="cell sweep chunk by chunk (no shared stage per run of four)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
     return ap.parse_args()
@@ -170,6 +172,10 @@ def main():
         core.CELL_ALPHA = args.alpha
     if args.unfused:
         core.FUSED_FACES = False
+    if args.no_super:
+        core.CELL_SUPER = False
+    if args.units:
+        core.SAMPLE_UNITS = tuple(int(v) for v in args.units.split("/"))
     w = WORKLOADS[args.workload]
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
@@ -347,7 +353,7 @@ def main():
                 "fallback_nodes_expanded": sh[11], "fallback_max_tests_one_tile": sh[12],
                 "finish_tiles_dropped_on_arrival": sh[13], "finish_samples_live_on_arrival": sh[14],
                 "finish_focus_rounds": sh[15],
-                "fused_faces": bool(core.FUSED_FACES)}
+                "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks}
     else:
         per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)
     done_evals = sum(v["pairs"] for v in per_kernel.values())

@@ -277,6 +277,7 @@ class SweepStats:
         self.samples_per_simplex = 0
         self.slab_points = 0         # ball tests
         self.groups = 0
+        self.deferred_chunks = 0     # chunks the run-of-four launch handed to the per-chunk launch
 
 
 LAST_STATS = SweepStats()
@@ -506,7 +507,7 @@ def sample_order(weights: torch.Tensor) -> np.ndarray:
     R, k1 = w.shape
     if k1 <= 1 or R <= 64:
         return np.arange(R, dtype=np.int64)
-    key = (R, k1, hash(w.tobytes()))                     # grid tables repeat from call to call: 5 ms saved
+    key = (R, k1, hash(w.tobytes()), SAMPLE_UNITS)       # grid tables repeat from call to call: 5 ms saved
     hit = _SAMPLE_ORDER_CACHE.get(key)
     if hit is not None:
         return hit.copy()
@@ -518,6 +519,9 @@ def sample_order(weights: torch.Tensor) -> np.ndarray:
 
 
 _SAMPLE_ORDER_CACHE: Dict[tuple, np.ndarray] = {}
+# cut sizes of the recursive bisection, coarse to fine: every aligned run of that many samples is a compact patch
+# (1024 = a run of four chunks of the cell sweep, 256 = a chunk, 64 = a tile of the tree sweeps)
+SAMPLE_UNITS = (1024, 256, 64, 16)
 
 
 def _sample_order_bisect(w: np.ndarray) -> np.ndarray:
@@ -526,7 +530,7 @@ def _sample_order_bisect(w: np.ndarray) -> np.ndarray:
     corners = np.eye(k1) - 1.0 / k1                      # regular simplex, centred
     basis = np.linalg.qr(corners.T)[0][:, :nd]           # orthonormal basis of its hyperplane
     X = w @ (corners @ basis)
-    units = (256, 64, 16)
+    units = SAMPLE_UNITS
     out: List[np.ndarray] = []
     stack = [np.arange(R, dtype=np.int64)]
     while stack:
@@ -679,6 +683,7 @@ CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spac
 # that cannot raise a face maximum.  False: sweep -> finish -> flooder_face_max_f32 over the full (S, R) buffer.
 FUSED_FACES = True
 CELL_PROBE = True    # the finish's probe (one greedy tree descent per flagged tile) runs inside the cell sweep
+CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
@@ -721,19 +726,31 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # scratch that only the flagged tiles touch.
         F = faces.n_faces
         tiles = (R + 63) // 64
-        ctl = torch.zeros(16, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish ([7]: top count)
+        ctl = torch.zeros(24, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish ([7]: top count), [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices, lists on
         face_bits = torch.zeros((S, F), dtype=torch.int32, device=dev)
         top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
         d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
         flags = torch.empty(S * tiles, dtype=torch.int32, device=dev)
+        chunks = (R + 255) // 256
+        defer_list = torch.empty(S * chunks, dtype=torch.int32, device=dev) if CELL_SUPER else None
+        defer_c = torch.empty(S * chunks, dtype=torch.float32, device=dev) if CELL_SUPER else None
+        wgt = None
+        split = torch.empty((2, S), dtype=torch.int32, device=dev) if CELL_SUPER else None  # light / heavy simplices
+        if CELL_SUPER:  # rough point count per simplex box: dense simplices skip the run-of-four launch
+            wgt = torch.empty(S, dtype=torch.float32, device=dev)
+            _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
+                                                         k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
         with _span(timer, "sweep"):
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(flags), ctl[1:].data_ptr(),
                 _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
-                ctl[7:].data_ptr() if CELL_PROBE else None, _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_faces_f32")
+                ctl[7:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
+                ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
+                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(sub(0, 9)), st),
+                "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
@@ -741,6 +758,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
                 _native.ptr(plan.memb_all), F,
                 _native.ptr(face_bits), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
+        if stats is not None:  # (diagnostic runs only: a host synchronisation)
+            LAST_STATS.deferred_chunks = int(ctl[12].item())
         out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
             _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), S * F, _native.ptr(out_face), st),

@@ -80,14 +80,36 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 #define PHASE(i) do {} while (0)
 #endif
 
-template <int DIM>
+// Chunks that a SUPER launch hands on to the per-chunk launch: entry = (simplex * chunks + chunk) << 1 | seeded;
+// seeded: the (S, R) buffer holds the minima found so far and c[] the next cell size to try.
+struct DeferList {
+  int32_t* list;
+  float* c;
+  int32_t* count;
+  // simplices split by their rough point count (flooder_simplex_weight_f32; both lists null: no split): the light
+  // ones are worked off in runs of four chunks by the SUPER launch, the heavy ones - no run of theirs would fit the
+  // stage - chunk by chunk by the second launch, ahead of the deferred chunks.  split[0], split[1] = list lengths.
+  const int32_t* light;
+  const int32_t* heavy;
+  const int32_t* split;
+  int n0_limit;         // a run with more points than this inside its box is not staged either
+};
+
+// SUPER = true: a work item is a run of GS consecutive chunks of one simplex (1024 samples: with the bisection order
+// of the samples still a compact patch).  The points around the whole run are gathered, filtered and staged ONCE
+// (one density estimate, one cell size) and the chunks are then queried one after the other against that stage - the
+// per-chunk cost of tree walks and classification, half of a chunk's instructions, is shared by four chunks.  Runs
+// whose neighbourhood does not fit the stage, and chunks that keep open samples (they would need a larger cell
+// size, i.e. a new stage), are appended to a deferred list that a SUPER = false launch works off chunk by chunk.
+template <int DIM, bool SUPER>
 __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats, RowSel sel, FaceAcc acc) {
+    unsigned long long* __restrict__ stats, RowSel sel, FaceAcc acc, DeferList dl) {
   constexpr int DP = padded_dim(DIM);
+  constexpr int GS = SUPER ? 4 : 1;  // chunks per work item
   constexpr int G = CellCfg<DIM>::G;
   constexpr int NC = CellCfg<DIM>::NC;
   // LDS per wave: 7.5 KB point stage + 2 KB cell table (16-bit entries, two per word) + 3.5 KB leaf list = 13 KB,
@@ -118,7 +140,13 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
   const int chunks = (n_slots + CHUNK - 1) / CHUNK;
   const int tiles64 = (n_slots + 63) >> 6;
-  const int64_t n_items = n_simplices * chunks;
+  const int supers = (chunks + GS - 1) / GS;
+  // (split[2] == 0: the split kernel found the cloud too dense for runs of four - the SUPER launch has no items and
+  // this one takes every chunk of every simplex in plain order, no lists)
+  const bool use_lists = !SUPER && dl.list && (!dl.split || dl.split[2] != 0);
+  const int64_t n_heavy_items = (use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
+  const int64_t n_items = SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
+                                : (use_lists ? n_heavy_items + (int64_t)dl.count[0] : n_simplices * chunks);
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
 #ifdef FLOODER_PHASE_TIMERS
   unsigned long long t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -140,59 +168,77 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     if (lane == 0) g32 = atomicAdd(queue, 1);
     const int64_t g = (int64_t)wave_uniform(g32);
     if (g >= n_items) break;
-    const int64_t s = g / chunks;
-    const int q = (int)(g - s * chunks);
+    int64_t s;
+    int q;            // current chunk of the simplex
+    int n_sub = 1;    // chunks of this work item
+    bool seeded = false;
+    float c_seed = 0.f;
+    if constexpr (SUPER) {
+      s = g / supers;
+      q = (int)(g - s * supers) * GS;
+      n_sub = chunks - q < GS ? chunks - q : GS;
+      if (dl.light) s = dl.light[s];
+    } else if (use_lists && g < n_heavy_items) {
+      s = g / chunks;
+      q = (int)(g - s * chunks);
+      s = dl.heavy[s];
+    } else if (use_lists) {
+      const int e = dl.list[g - n_heavy_items];
+      seeded = (e & 1) != 0;
+      c_seed = dl.c[g - n_heavy_items];
+      s = (int64_t)(e >> 1) / chunks;
+      q = (int)((e >> 1) - s * chunks);
+    } else {
+      s = g / chunks;
+      q = (int)(g - s * chunks);
+    }
+    const int q_first = q;
     const float* vs = verts + s * (int64_t)k1 * DIM;
     const int n_live = sel.list ? sel.cnt[s] : R;  // live slots of this simplex (wave-uniform)
     if (q * CHUNK >= n_live) continue;
+    auto defer = [&](int qq, int seeded_flag, float c_next) {
+      if (lane == 0) {
+        const int pos = atomicAdd(dl.count, 1);
+        dl.list[pos] = (int)(((s * chunks + qq) << 1) | seeded_flag);
+        dl.c[pos] = c_next;
+      }
+    };
     PHASE(0);
 
-    // ---- 0. samples and chunk box
+    // ---- 0. samples of the current chunk q (rebuilt from vertices x weights)
     float p[SPL][DIM];
     float best[SPL];
     bool open[SPL];  // still unverified
     int row[SPL];    // row of the weight table / column of the output
     float blo[DIM], bhi[DIM];
+    auto make_samples = [&]() {
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-      int slot = q * CHUNK + i * 64 + lane;
-      open[i] = slot < n_live;
-      if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
-      const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
-      row[i] = r;
+      for (int i = 0; i < SPL; ++i) {
+        int slot = q * CHUNK + i * 64 + lane;
+        open[i] = slot < n_live;
+        if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
+        const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
+        row[i] = r;
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
-      if (k1 == 4) {  // tetrahedra: the weight row is one 16 B load (same fma order as the general loop)
-        const float4 w4 = *reinterpret_cast<const float4*>(weights + (int64_t)r * 4);
-        const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
+        for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
+        if (k1 == 4) {  // tetrahedra: the weight row is one 16 B load (same fma order as the general loop)
+          const float4 w4 = *reinterpret_cast<const float4*>(weights + (int64_t)r * 4);
+          const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(wj[j], vs[j * DIM + k], p[i][k]);
+            for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(wj[j], vs[j * DIM + k], p[i][k]);
+          }
+        } else {
+          for (int j = 0; j < k1; ++j) {
+            const float w = weights[(int64_t)r * k1 + j];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
+          }
         }
-      } else {
-        for (int j = 0; j < k1; ++j) {
-          const float w = weights[(int64_t)r * k1 + j];
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
-        }
+        best[i] = __builtin_inff();
       }
-      best[i] = __builtin_inff();
-    }
-    float ext = 0.f, vol = 1.f;
-#pragma unroll
-    for (int k = 0; k < DIM; ++k) {
-      float mn = p[0][k], mx = p[0][k];
-#pragma unroll
-      for (int i = 1; i < SPL; ++i) {
-        mn = __builtin_fminf(mn, p[i][k]);
-        mx = __builtin_fmaxf(mx, p[i][k]);
-      }
-      blo[k] = wave_min_f32(mn);
-      bhi[k] = wave_max_f32(mx);
-      ext = __builtin_fmaxf(ext, bhi[k] - blo[k]);
-      vol *= (bhi[k] - blo[k]);
-    }
+    };
     // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
     // pn . (x - org) <= po relative to the LOCAL origin org = vertex 0 (no cancellation for clouds far from the
     // coordinate origin).  A point within c of a sample lies within c of every such half-space; the test below
@@ -268,23 +314,65 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
 
-    // The chunk's own extent along every face normal (a 2(DIM+1)-plane polytope around its samples, tighter than
-    // the bounding box for skewed simplices and than the simplex's half-spaces for chunks in its interior): a
-    // point within c of a sample has pn.(x - org) within c of that sample's value.
+    // ---- region of the work item: bounding box of its samples and their extent along every face normal (a
+    // 2(DIM+1)-plane polytope around them, tighter than the box for skewed simplices and than the simplex's
+    // half-spaces for patches in its interior): a point within c of a sample has pn.(x - org) within c of that
+    // sample's value
     float slo[DIM + 1], shi[DIM + 1];
+    {
+      float mn[DIM], mx[DIM], dmn[DIM + 1], dmx[DIM + 1];
 #pragma unroll
-    for (int f = 0; f <= DIM; ++f) {
-      float mn = __builtin_inff(), mx = -__builtin_inff();
+      for (int k = 0; k < DIM; ++k) { mn[k] = __builtin_inff(); mx[k] = -__builtin_inff(); }
+#pragma unroll
+      for (int f = 0; f <= DIM; ++f) { dmn[f] = __builtin_inff(); dmx[f] = -__builtin_inff(); }
+      for (int sub = 0; sub < n_sub; ++sub) {  // (SUPER: the samples of the item's last chunk stay in registers)
+        q = q_first + sub;
+        make_samples();
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            mn[k] = __builtin_fminf(mn[k], p[i][k]);
+            mx[k] = __builtin_fmaxf(mx[k], p[i][k]);
+          }
+#pragma unroll
+          for (int f = 0; f <= DIM; ++f) {
+            float dd = -po[f];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], p[i][k] - org[k], dd);
+            dmn[f] = __builtin_fminf(dmn[f], dd);
+            dmx[f] = __builtin_fmaxf(dmx[f], dd);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        blo[k] = wave_min_f32(mn[k]);
+        bhi[k] = wave_max_f32(mx[k]);
+      }
+#pragma unroll
+      for (int f = 0; f <= DIM; ++f) {
+        slo[f] = wave_min_f32(dmn[f]);
+        shi[f] = wave_max_f32(dmx[f]);
+      }
+    }
+    float ext = 0.f, vol = 1.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      ext = __builtin_fmaxf(ext, bhi[k] - blo[k]);
+      vol *= (bhi[k] - blo[k]);
+    }
+    if (seeded) {
+      // minima found so far (the SUPER launch's query at half this cell size); a sample is settled when its
+      // minimum passed that launch's test (bit 31 marks it in the fused layout: masked off here)
+      const float c_prev = 0.5f * c_seed;
+      const float c_ok_prev = (0.999f * c_prev) * (0.999f * c_prev);
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
-        float dd = -po[f];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], p[i][k] - org[k], dd);
-        mn = __builtin_fminf(mn, dd);
-        mx = __builtin_fmaxf(mx, dd);
+        const uint32_t w = out_d2[s * (int64_t)sel.ld_out + row[i]];
+        best[i] = __uint_as_float(w & ~SETTLED_BIT);
+        open[i] = open[i] && !(best[i] <= c_ok_prev);
       }
-      slo[f] = wave_min_f32(mn);
-      shi[f] = wave_max_f32(mx);
     }
 
     PHASE(1);
@@ -350,16 +438,16 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       return over ? -1 : n_leaf;
     };
 
-    // ---- 1. density of the cloud inside the chunk box -> first cell size
+    // ---- 1. density of the cloud inside the region's box -> first cell size
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { qlo[k] = blo[k]; qhi[k] = bhi[k]; }
-    int n_leaves = gather();
+    int n_leaves = seeded ? 0 : gather();
     PHASE(2);
     bool give_up = n_leaves < 0;
     if (give_up) ++g_gather0;
-    float c = ext;
-    int n0 = 0;  // points of the cloud inside the chunk box
-    if (!give_up) {
+    float c = seeded ? c_seed : ext;
+    int n0 = 0;  // points of the cloud inside the box
+    if (!give_up && !seeded) {
       // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
       const int n_cand0 = n_leaves * LEAF;
       for (int ib = 0; ib < n_cand0; ib += 64 * UNR) {
@@ -385,13 +473,151 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       }
     }
     if (!(c > 0.f) || !(c < 3.0e38f)) c = 1.f;
+    if (seeded) n0 = 1 << 27;  // (unknown: let the dense limit decide about the exhaustive evaluation)
     PHASE(3);
 
     // ---- 2-4. stage, query, verify; double c while samples stay open
 #ifdef FLOODER_PHASE_TIMERS
     unsigned long long d_info = 0, d_tb = 0, d_flush = 0, d_wait = 0;  // diagnostics of the last attempt
 #endif
-    for (int attempt = 0; attempt < max_tries && !give_up; ++attempt) {
+    // ---- results of the current chunk; tiles of 64 samples that are still open go to the exact tree sweep.
+    // seed_mode (SUPER launch, chunk with open samples): the minima are parked in the (S, R) buffer for the deferred
+    // per-chunk pass instead (every tile is written, nothing is flagged).
+    auto finalize = [&](bool seed_mode) {
+    if (acc.face_bits) {
+      // fused face maxima: every settled sample raises the running maximum of each face it lies on (one integer
+      // atomic per face present in the chunk: interior chunks touch one face); the (S, R) buffer is only
+      // written for the tiles the finish has to look at (bit 31 = already settled)
+      uint32_t mb[SPL], um = 0u;
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        const bool settled = (q * CHUNK + i * 64 + lane < n_live) && !open[i];
+        mb[i] = settled ? acc.memb[row[i]] : 0u;
+        um |= mb[i];
+      }
+      um = wave_or_u32(um);
+      while (um) {  // (wave-uniform)
+        const int f = __builtin_ctz(um);
+        um &= um - 1u;
+        uint32_t v = 0u;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          const uint32_t b = ((mb[i] >> f) & 1u) ? __float_as_uint(best[i]) : 0u;
+          v = b > v ? b : v;
+        }
+        v = wave_max_u32(v);
+        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
+      }
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        if (seed_mode) {
+          if (q * CHUNK + i * 64 + lane < n_live)
+            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
+        } else if (__ballot(open[i]) != 0ull) {
+          if (acc.top) {
+            // probe: one greedy descent of the box tree for the tile's open samples (nearest child box at every
+            // level, one leaf evaluated) gives each of them a finite upper bound; the tile with the largest one
+            // becomes its simplex's "top" tile, which the finish settles first
+            float tlo[DIM], thi[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              tlo[k] = wave_min_f32(open[i] ? p[i][k] : __builtin_inff());
+              thi[k] = wave_max_f32(open[i] ? p[i][k] : -__builtin_inff());
+            }
+            int grp = 0;
+            for (int lvl = top; lvl >= 0; --lvl) {
+              const int idx = grp * FAN + lane;
+              const bool ok = idx < (int)lv.count[lvl];
+              float lo[DP], hi[DP];
+              const uint32_t nb_ = (uint32_t)((int)lv.off[lvl] + (ok ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+              load_row_at<DP>(nodes, nb_, lo);
+              load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
+              float lb = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
+                lb = __builtin_fmaf(gap, gap, lb);
+              }
+              lb = ok ? lb : __builtin_inff();
+              const float mn = wave_min_f32(lb);
+              grp = grp * FAN + __builtin_ctzll(__ballot(lb == mn));
+            }
+            const float* cp = pts + (int64_t)grp * LEAF * DP;
+            float bb = best[i];
+#pragma unroll
+            for (int h = 0; h < LEAF; h += 8) {
+              typename RowVec<DP>::type cc[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                float t0 = p[i][0] - cc[u][0];
+                float d2 = t0 * t0;
+                t0 = p[i][1] - cc[u][1];
+                d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = p[i][2] - cc[u][2];
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                bb = __builtin_fminf(bb, d2);
+              }
+            }
+            best[i] = bb;
+            const uint32_t key = wave_max_u32(open[i] ? __float_as_uint(bb) : 0u);
+            if (lane == 0 && key != 0u) {
+              const unsigned long long old =
+                  atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)(s * tiles64 + q * SPL + i));
+              if (old == 0ull) acc.top_list[atomicAdd(acc.top_count, 1)] = (int)s;
+            }
+          }
+          if (q * CHUNK + i * 64 + lane < n_live)
+            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
+          if (lane == 0) {
+            const int pos = atomicAdd(flag_count, 1);
+            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+          }
+          ++n_flagged;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
+        if (!seed_mode && __ballot(open[i]) != 0ull) {
+          if (lane == 0) {
+            const int pos = atomicAdd(flag_count, 1);
+            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+          }
+          ++n_flagged;
+        }
+      }
+    }
+    };
+    // SUPER: a chunk is done after its one query; with open samples left it is parked and deferred (next cell size 2c)
+    auto finalize_sub = [&](bool any_open_lane, float c_now) {
+      const bool any = __ballot(any_open_lane) != 0ull;
+      finalize(any);
+      if (any) defer(q, 1, 2.f * c_now);
+    };
+    bool sc_done = false;
+    // SUPER: the stage is built once for the whole run of chunks; anything that does not work out is deferred
+    auto defer_all_fresh = [&]() {
+      for (int sub = 0; sub < n_sub; ++sub) defer(q_first + sub, 0, 0.f);
+    };
+    if constexpr (SUPER) {
+      // will the neighbourhood fit the stage?  points in the box x growth of the box by c on every side x the share
+      // the slab filter keeps (about half): a run that is predicted not to fit is not gathered at all
+      float grow = 0.5f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const float e = bhi[k] - blo[k];
+        grow *= e > 0.f ? __builtin_fminf((e + 2.f * c) / e, 8.f) : 8.f;
+      }
+      // (an empty box gives no density: the cell size would fall back to the extent of the whole run, far more than
+      // its chunks would try on their own - leave those to the per-chunk pass)
+      if (give_up || n0 == 0 || (float)n0 * grow > (float)dl.n0_limit) { defer_all_fresh(); continue; }
+    }
+    for (int attempt = seeded ? 1 : 0; attempt < (SUPER ? 1 : max_tries) && !give_up; ++attempt) {
       c = __builtin_fmaxf(c, ext / (float)(G - 3));
       const float inv_c = 1.f / c;
       int nc[DIM];
@@ -490,6 +716,9 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       const float c_ok = (0.999f * c) * (0.999f * c);
       // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
+      if constexpr (SUPER) {
+        if (n_keep > CAPW) break;  // the neighbourhood of the whole run does not fit the stage: chunk by chunk
+      }
       if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) { give_up = true; ++g_cap; break; }
       if (n_keep <= brute_max) {
         // ---- few kept points: every sample against every one of them, straight from the compacted list the
@@ -497,29 +726,50 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         // candidates).  Cheaper than the cell query's dependent LDS chains while the list is short.
         if (lane < 4) s_pts[n_keep + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
         wave_lds_sync();
-        for (int j = 0; j < n_keep; j += 4) {
-          float4 x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
-#pragma unroll
-          for (int i = 0; i < SPL; ++i) {
-            float bb = best[i];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              float t0 = p[i][0] - x[u].x;
-              float d2 = t0 * t0;
-              t0 = p[i][1] - x[u].y;
-              d2 = __builtin_fmaf(t0, t0, d2);
-              if constexpr (DIM == 3) {
-                t0 = p[i][2] - x[u].z;
+        auto brute_eval = [&]() {
+          for (int j = 0; j < n_keep; j += 4) {
+            float4 x[4];
+  #pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+  #pragma unroll
+            for (int i = 0; i < SPL; ++i) {
+              float bb = best[i];
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                float t0 = p[i][0] - x[u].x;
+                float d2 = t0 * t0;
+                t0 = p[i][1] - x[u].y;
                 d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = p[i][2] - x[u].z;
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                bb = __builtin_fminf(bb, d2);
               }
-              bb = __builtin_fminf(bb, d2);
+              best[i] = bb;
             }
-            best[i] = bb;
           }
+          if (stats) n_pairs += (unsigned long long)n_keep * SPL;
+        };
+        if constexpr (SUPER) {
+          for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
+            q = q_first + sub;
+            if (sub != n_sub - 1) make_samples();
+            brute_eval();
+            bool any_open = false;
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) {
+              open[i] = open[i] && !(best[i] <= c_ok);
+              any_open = any_open || open[i];
+            }
+            finalize_sub(any_open, c);
+          }
+          n_staged += (unsigned long long)n_keep;
+          sc_done = true;
+          wave_lds_sync();
+          break;
         }
-        if (stats) n_pairs += (unsigned long long)n_keep * SPL;
+        brute_eval();
         n_staged += (unsigned long long)n_keep;
         bool any_open = false;
 #pragma unroll
@@ -679,192 +929,107 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       if (attempt > 0) ++n_retries;
 
       PHASE(7);
-      // 3. query the open samples
-      bool any_open = false;
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) {
-        if (open[i]) {
-          int ck[DIM];
-          float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) {
-            const float tf = (p[i][k] - g0[k]) * inv_c;
-            const int t = (int)tf;
-            ck[k] = t < 1 ? 1 : (t > nc[k] - 2 ? nc[k] - 2 : t);
-            const float f = tf - (float)ck[k];  // position inside the (clamped) cell, in cells
-            const float lo_gap = __builtin_fmaxf(f, 0.f) * c * 0.999f;
-            const float hi_gap = __builtin_fmaxf(1.f - f, 0.f) * c * 0.999f;
-            gap2[k][0] = lo_gap * lo_gap;
-            gap2[k][1] = 0.f;
-            gap2[k][2] = hi_gap * hi_gap;
-          }
-          float b = best[i];
-          // rows of 3 cells along x, nearest first; a row is skipped when even its slab is no closer
-          // than the running minimum
-          constexpr int NROW = DIM == 3 ? 9 : 3;
-          constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-          constexpr int ORD2[3] = {0, -1, 1};
-          // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
-          const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
-          int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
-          if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
-#pragma unroll
-          for (int rw = 0; rw < NROW; ++rw) {
-            int base;
-            float lb;
-            if constexpr (DIM == 3) {
-              const int dy = ORD3[rw][0], dz = ORD3[rw][1];
-              base = base0 + dy * stride_y + dz * stride_z;
-              lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
-            } else {
-              const int dy = ORD2[rw];
-              base = base0 + dy * stride_y;
-              lb = gap2[1][dy + 1];
+      // 3. query the open samples of the current chunk
+      auto query_cells = [&]() -> bool {
+        bool any_open = false;
+  #pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          if (open[i]) {
+            int ck[DIM];
+            float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
+  #pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float tf = (p[i][k] - g0[k]) * inv_c;
+              const int t = (int)tf;
+              ck[k] = t < 1 ? 1 : (t > nc[k] - 2 ? nc[k] - 2 : t);
+              const float f = tf - (float)ck[k];  // position inside the (clamped) cell, in cells
+              const float lo_gap = __builtin_fmaxf(f, 0.f) * c * 0.999f;
+              const float hi_gap = __builtin_fmaxf(1.f - f, 0.f) * c * 0.999f;
+              gap2[k][0] = lo_gap * lo_gap;
+              gap2[k][1] = 0.f;
+              gap2[k][2] = hi_gap * hi_gap;
             }
-            if (!(lb < b)) continue;
-            // the row's outer cells are dropped too when their slab is no closer than the running minimum
-            const int first = (lb + gap2[0][0] < b) ? 0 : 1;
-            const int last = (lb + gap2[0][2] < b) ? 3 : 2;
-            const int bg = s_cell[base + first];
-            const int en = s_cell[base + last];
-            if (stats) n_pairs += (unsigned long long)(en - bg);
-            // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
-            // the list - a minimum over more real points is still a valid upper bound, and exact once verified
-            for (int j = bg; j < en; j += 4) {
-              float4 x[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                float t0 = p[i][0] - x[u].x;
-                float d2 = t0 * t0;
-                t0 = p[i][1] - x[u].y;
-                d2 = __builtin_fmaf(t0, t0, d2);
-                if constexpr (DIM == 3) {
-                  t0 = p[i][2] - x[u].z;
+            float b = best[i];
+            // rows of 3 cells along x, nearest first; a row is skipped when even its slab is no closer
+            // than the running minimum
+            constexpr int NROW = DIM == 3 ? 9 : 3;
+            constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+            constexpr int ORD2[3] = {0, -1, 1};
+            // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
+            const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
+            int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
+            if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
+  #pragma unroll
+            for (int rw = 0; rw < NROW; ++rw) {
+              int base;
+              float lb;
+              if constexpr (DIM == 3) {
+                const int dy = ORD3[rw][0], dz = ORD3[rw][1];
+                base = base0 + dy * stride_y + dz * stride_z;
+                lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
+              } else {
+                const int dy = ORD2[rw];
+                base = base0 + dy * stride_y;
+                lb = gap2[1][dy + 1];
+              }
+              if (!(lb < b)) continue;
+              // the row's outer cells are dropped too when their slab is no closer than the running minimum
+              const int first = (lb + gap2[0][0] < b) ? 0 : 1;
+              const int last = (lb + gap2[0][2] < b) ? 3 : 2;
+              const int bg = s_cell[base + first];
+              const int en = s_cell[base + last];
+              if (stats) n_pairs += (unsigned long long)(en - bg);
+              // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
+              // the list - a minimum over more real points is still a valid upper bound, and exact once verified
+              for (int j = bg; j < en; j += 4) {
+                float4 x[4];
+  #pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+  #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  float t0 = p[i][0] - x[u].x;
+                  float d2 = t0 * t0;
+                  t0 = p[i][1] - x[u].y;
                   d2 = __builtin_fmaf(t0, t0, d2);
+                  if constexpr (DIM == 3) {
+                    t0 = p[i][2] - x[u].z;
+                    d2 = __builtin_fmaf(t0, t0, d2);
+                  }
+                  b = __builtin_fminf(b, d2);
                 }
-                b = __builtin_fminf(b, d2);
               }
             }
+            best[i] = b;
+            open[i] = !(b <= c_ok);
           }
-          best[i] = b;
-          open[i] = !(b <= c_ok);
+          any_open = any_open || open[i];
         }
-        any_open = any_open || open[i];
+        return any_open;
+      };
+      if constexpr (SUPER) {
+        for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
+          q = q_first + sub;
+          if (sub != n_sub - 1) make_samples();
+          const bool ao = query_cells();
+          finalize_sub(ao, c);
+        }
+        sc_done = true;
+        wave_lds_sync();
+        break;
       }
+      const bool any_open = query_cells();
       PHASE(8);
       if (__ballot(any_open) == 0ull) break;
       if (attempt == max_tries - 1) ++g_tries;
       c *= 2.f;
     }
 
-    // ---- results; tiles of 64 samples that are still open go to the exact tree sweep
-    if (acc.face_bits) {
-      // fused face maxima: every settled sample raises the running maximum of each face it lies on (one integer
-      // atomic per face present in the chunk: interior chunks touch one face); the (S, R) buffer is only
-      // written for the tiles the finish has to look at (bit 31 = already settled)
-      uint32_t mb[SPL], um = 0u;
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) {
-        const bool settled = (q * CHUNK + i * 64 + lane < n_live) && !open[i];
-        mb[i] = settled ? acc.memb[row[i]] : 0u;
-        um |= mb[i];
-      }
-      um = wave_or_u32(um);
-      while (um) {  // (wave-uniform)
-        const int f = __builtin_ctz(um);
-        um &= um - 1u;
-        uint32_t v = 0u;
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-          const uint32_t b = ((mb[i] >> f) & 1u) ? __float_as_uint(best[i]) : 0u;
-          v = b > v ? b : v;
-        }
-        v = wave_max_u32(v);
-        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
-      }
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) {
-        if (__ballot(open[i]) != 0ull) {
-          if (acc.top) {
-            // probe: one greedy descent of the box tree for the tile's open samples (nearest child box at every
-            // level, one leaf evaluated) gives each of them a finite upper bound; the tile with the largest one
-            // becomes its simplex's "top" tile, which the finish settles first
-            float tlo[DIM], thi[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-              tlo[k] = wave_min_f32(open[i] ? p[i][k] : __builtin_inff());
-              thi[k] = wave_max_f32(open[i] ? p[i][k] : -__builtin_inff());
-            }
-            int grp = 0;
-            for (int lvl = top; lvl >= 0; --lvl) {
-              const int idx = grp * FAN + lane;
-              const bool ok = idx < (int)lv.count[lvl];
-              float lo[DP], hi[DP];
-              const uint32_t nb_ = (uint32_t)((int)lv.off[lvl] + (ok ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
-              load_row_at<DP>(nodes, nb_, lo);
-              load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
-              float lb = 0.f;
-#pragma unroll
-              for (int k = 0; k < DIM; ++k) {
-                const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
-                lb = __builtin_fmaf(gap, gap, lb);
-              }
-              lb = ok ? lb : __builtin_inff();
-              const float mn = wave_min_f32(lb);
-              grp = grp * FAN + __builtin_ctzll(__ballot(lb == mn));
-            }
-            const float* cp = pts + (int64_t)grp * LEAF * DP;
-            float bb = best[i];
-#pragma unroll
-            for (int h = 0; h < LEAF; h += 8) {
-              typename RowVec<DP>::type cc[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                float t0 = p[i][0] - cc[u][0];
-                float d2 = t0 * t0;
-                t0 = p[i][1] - cc[u][1];
-                d2 = __builtin_fmaf(t0, t0, d2);
-                if constexpr (DIM == 3) {
-                  t0 = p[i][2] - cc[u][2];
-                  d2 = __builtin_fmaf(t0, t0, d2);
-                }
-                bb = __builtin_fminf(bb, d2);
-              }
-            }
-            best[i] = bb;
-            const uint32_t key = wave_max_u32(open[i] ? __float_as_uint(bb) : 0u);
-            if (lane == 0 && key != 0u) {
-              const unsigned long long old =
-                  atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)(s * tiles64 + q * SPL + i));
-              if (old == 0ull) acc.top_list[atomicAdd(acc.top_count, 1)] = (int)s;
-            }
-          }
-          if (q * CHUNK + i * 64 + lane < n_live)
-            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
-          if (lane == 0) {
-            const int pos = atomicAdd(flag_count, 1);
-            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
-          }
-          ++n_flagged;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) {
-        if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
-        if (__ballot(open[i]) != 0ull) {
-          if (lane == 0) {
-            const int pos = atomicAdd(flag_count, 1);
-            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
-          }
-          ++n_flagged;
-        }
-      }
+    if constexpr (SUPER) {
+      if (!sc_done) defer_all_fresh();
+      PHASE(10);
+      continue;
     }
+    finalize(false);
     PHASE(10);
 #ifdef FLOODER_PHASE_TIMERS
     if (stats && lane == 0) {  // diagnostic build only: sixteen values per chunk
@@ -914,7 +1079,7 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 RowSel sel, FaceAcc acc, hipStream_t st) {
+                 RowSel sel, FaceAcc acc, DeferList dl, int32_t* queue2, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
@@ -923,8 +1088,20 @@ struct CellOp {
       int64_t want = n_chunks / 48;
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
-      hipLaunchKernelGGL((cell_sweep_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                         weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP, g_cell_tries, g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc);
+      const int brute_max = g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP;
+      if (dl.list) {
+        // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
+        hipLaunchKernelGGL((cell_sweep_kernel<DIM, true>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
+                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
+                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc, dl);
+        hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
+                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
+                           g_cell_exh_tries, queue2, out, flag_list, flag_count, stats, sel, acc, dl);
+      } else {
+        hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
+                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
+                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc, dl);
+      }
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
@@ -936,11 +1113,57 @@ struct CellOp {
 
 namespace {
 
+// Order-preserving split of 0 .. n-1 by weight[i] <= limit: one block, ballot scans (n is a few thousand).
+// Runs of four chunks pay in sparse volumetric clouds (most runs fit the stage); where fewer than half of the simplices
+// are sparse (weight <= sparse_limit) the whole sweep stays chunk by chunk: counts = {0, 0, 0}.
+__global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __restrict__ weight, int n, float limit,
+                                                               float sparse_limit, int32_t* __restrict__ light,
+                                                               int32_t* __restrict__ heavy, int32_t* __restrict__ counts) {
+  __shared__ int s_cnt[16];
+  __shared__ int s_sparse;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_sparse = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) mine += weight[i] <= sparse_limit ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0) atomicAdd(&s_sparse, mine);
+  __syncthreads();
+  if (2 * s_sparse < n) {
+    if (threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }
+    return;
+  }
+  int n_light = 0, n_heavy = 0;  // (block-uniform running totals)
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const bool in = i < n;
+    const bool is_light = in && weight[i] <= limit;
+    const unsigned long long m = __ballot(is_light);
+    if (lane == 0) s_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_cnt[w];
+      before += w < wv ? c : 0;
+      total += c;
+    }
+    const int rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (is_light) light[n_light + rank] = i;
+    else if (in) heavy[n_heavy + (threadIdx.x - rank)] = i;
+    const int valid = n - base < 1024 ? n - base : 1024;
+    n_light += total;
+    n_heavy += valid - total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
+}
+
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int ld_out, const int32_t* row_list, const int32_t* row_cnt, int list_stride,
-                     int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc, void* stream,
-                     const char* who) {
+                     int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc, DeferList dl,
+                     int32_t* queue2, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
       n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f) || ld_out < 1 ||
@@ -957,7 +1180,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel, acc,
-                              (hipStream_t)stream);
+                              dl, queue2, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -971,23 +1194,36 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           ld_out, row_list, row_cnt, list_stride, flag_list, flag_count, stats,
-                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, stream,
-                          "flooder_sweep_cell_f32: bad argument");
+                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr},
+                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+                          nullptr, stream, "flooder_sweep_cell_f32: bad argument");
 }
 
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* top, int32_t* top_list, int32_t* top_count, uint64_t* stats,
-                                 void* stream) {
+                                 uint64_t* top, int32_t* top_list, int32_t* top_count, int32_t* defer_list,
+                                 float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
+                                 int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
-  if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)))
+  if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)) ||
+      (defer_list && (!defer_c || !defer_ctl)) || (simplex_weight && (!defer_list || !light_list || !heavy_list)) ||
+      n_simplices > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_faces_f32: bad argument");
+  if (!simplex_weight) light_list = heavy_list = nullptr;
+  if (simplex_weight) {  // split the simplices (order kept) into the light and the heavy list
+    hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
+                       (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
+                       defer_ctl + 2);
+  }
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, R, nullptr, nullptr, 0, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count},
+                          DeferList{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
+                                    light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0},
+                          defer_list ? defer_ctl + 1 : nullptr,
                           stream, "flooder_sweep_cell_faces_f32: bad argument");
 }
 

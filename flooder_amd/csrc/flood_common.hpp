@@ -22,6 +22,9 @@ extern int g_cell_exh_sparse;
 extern int g_cell_brute_max;
 extern int g_finish_focus_pct;
 extern int g_cell_tries;
+extern int g_cell_super_weight;
+extern int g_cell_super_n0;
+extern int g_cell_super_sparse;
 extern int g_curve_bits;
 extern int g_cell_exh_tries;
 extern int g_finish_items_cap;

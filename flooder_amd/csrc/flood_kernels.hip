@@ -643,6 +643,18 @@ int flooder_set_option(const char* name, int value) {
     g_curve_bits = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_super_weight") == 0 && value >= 0) {
+    g_cell_super_weight = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_super_sparse") == 0 && value >= 0) {
+    g_cell_super_sparse = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_super_n0") == 0 && value >= 0) {
+    g_cell_super_n0 = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_tries") == 0 && value >= 1 && value <= 8) {
     g_cell_tries = value;
     return FLOODER_OK;

@@ -225,14 +225,24 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * top / top_list / top_count (all NULL, or n_simplices zeroed uint64 / n_simplices int32 / one zeroed int32): the
  * probe of the finish folded into the sweep - every flagged tile gets one greedy tree descent for its open samples
  * (finite upper bounds) while they are still in registers, and top[s] = (largest such bound << 32 | tile id).
+ * defer_list / defer_c / defer_ctl (all NULL, or n_simplices * ceil(R / 256) int32 / as many float32 / eight zeroed
+ * int32): two launches instead of one - first every run of four consecutive chunks (1024 samples) is gathered,
+ * filtered and staged ONCE and its chunks are queried against that stage; runs that do not fit the stage and chunks
+ * that keep open samples are appended to defer_list and worked off chunk by chunk by the second launch.
+ * simplex_weight (NULL or n_simplices floats of flooder_simplex_weight_f32) with light_list / heavy_list
+ * (n_simplices int32 scratch each): simplices heavier than option "cell_super_weight" (3000) skip the first launch -
+ * in a dense region no run of four chunks fits the stage - and are worked off chunk by chunk by the second.  When
+ * fewer than half of the simplices are sparse (weight <= option "cell_super_sparse", 600) the first launch gets no
+ * work at all and the second sweeps everything in plain order.
  * Followed by flooder_finish_faces_f32 (probed = 1 when top was passed here) and flooder_face_values_f32.
  */
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* top, int32_t* top_list, int32_t* top_count, uint64_t* stats,
-                                 void* stream);
+                                 uint64_t* top, int32_t* top_list, int32_t* top_count, int32_t* defer_list,
+                                 float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
+                                 int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not

@@ -4,6 +4,7 @@ import sys, torch, numpy as np
 sys.path.insert(0, '.')
 import flooder_amd as fa
 from flooder_amd import _native, core
+core.CELL_SUPER = False  # (the per-chunk records below assume one work item per chunk)
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 torch.manual_seed(42)
 dev = torch.device('cuda:0')

@@ -6,6 +6,7 @@ import flooder_amd as fa
 from flooder_amd import _native, core
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = _native.load()
+core.CELL_SUPER = False  # (the per-chunk records below assume one work item per chunk)
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
 pts = torch.randn(1_000_000, 3).to(dev)

@@ -37,7 +37,7 @@ try:
     d = json.load(open(sys.argv[1]))
     st = d["config"]["sweep_stats_rank0"] or {}
     print(sys.argv[2], "ms/step", d["ms_per_step"], "+-", d["ms_per_step_std"], {k: v["ms_per_step"] for k, v in d["kernels"].items()},
-          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds")})
+          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds", "deferred_chunks", "chunks_total")})
 except Exception as e:
     print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-600:])
 PY
@@ -81,6 +81,7 @@ PY
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/phase_timers_$wl.txt ;;
     sortbench) hipcc -O3 --offload-arch=gfx950 tools/sort_bench.hip -o /tmp/sort_bench > $OUT/sort_build.log 2>&1 && timeout 120 /tmp/sort_bench > $OUT/sort_bench.txt 2>&1; cat $OUT/sort_bench.txt ;;
+    cweights:*) timeout 300 python tools/check_weights.py ${s#cweights:} 2>&1 | grep -v amdgpu.ids ;;
     tfps) timeout 600 python tools/time_fps.py > $OUT/time_fps.txt 2>&1; cat $OUT/time_fps.txt ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
