@@ -38,7 +38,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .simplex_tree import HAS_GUDHI, SimplexTree, delaunay_simplices
+from .simplex_tree import HAS_GUDHI, SimplexTree, delaunay_cells, delaunay_simplices
 
 __all__ = ["flood_complex", "generate_landmarks", "generate_grid", "generate_uniform_weights",
            "SUPPORTED_DTYPES", "HAS_HIP_KERNELS"]
@@ -210,10 +210,9 @@ def _build_complex(landmarks: torch.Tensor, max_dimension: int):
                 buckets[len(simplex) - 1].append(tuple(simplex))
         simplices = [np.array(b, dtype=np.int64).reshape(-1, d + 1) for d, b in enumerate(buckets)]
         return stree, simplices
-    all_dims = delaunay_simplices(lm, None)
-    stree = SimplexTree.from_arrays(all_dims)
-    simplices = [all_dims[d] if d < len(all_dims) else np.zeros((0, d + 1), np.int64)
-                 for d in range(max_dimension + 1)]
+    # Qhull cells; the face tables up to max_dimension now, the higher ones when somebody asks for them
+    stree = SimplexTree.from_cells(delaunay_cells(lm), lm.shape[0], eager=max_dimension)
+    simplices = [stree.simplices_of_dimension(d) for d in range(max_dimension + 1)]
     return stree, simplices
 
 
@@ -229,6 +228,25 @@ def _ball_prep(simplex_vertices: torch.Tensor, d: int):
     radii = torch.amax((simplex_vertices - centers.unsqueeze(1)).norm(dim=2), dim=1) \
         * (1.42 if d > 1 else 1.01) + 1e-3
     return centers, radii
+
+
+_GRID_CACHE: Dict[tuple, tuple] = {}
+
+
+def _grid_tables(points_per_edge: int, dim: int, device, dtype):
+    """``generate_grid`` + face table + sample plan of one (points_per_edge, dimension): identical from call to
+    call, 2 - 3 ms of host work and a dozen small uploads each time - kept per device."""
+    key = (int(points_per_edge), int(dim), str(device), dtype, SAMPLE_UNITS)
+    hit = _GRID_CACHE.get(key)
+    if hit is None:
+        weights, vertex_idxs, face_idxs = generate_grid(points_per_edge, dim, device, dtype)
+        faces = _FaceTable(face_idxs, weights.shape[0], device)
+        plan = SamplePlan(weights, faces) if torch.device(device).type == "cuda" else None
+        v_np = [v.cpu().numpy() for v in vertex_idxs]
+        if len(_GRID_CACHE) >= 16:
+            _GRID_CACHE.clear()
+        hit = _GRID_CACHE[key] = (weights, vertex_idxs, face_idxs, faces, plan, v_np)
+    return hit
 
 
 class _FaceTable:
@@ -922,15 +940,20 @@ def flood_complex(
 
         kdtree = KDTree(np.asarray(points))
 
+    index = None
+    if on_gpu and method != "ball":
+        # the curve sort + box tree run on the GPU while the host triangulates the landmarks
+        pts32 = points.to(torch.float32)
+        index = shared_index if shared_index is not None else PointIndex(pts32)
     stree, simplices = _build_complex(landmarks, max_dimension)
     LAST_STATS.reset()
     LAST_STATS.n_points = points.shape[0]
 
-    # sort the cloud along its widest axis (core.py:140-144)
+    # widest axis of the cloud (core.py:140-144): sort key of the reference, work order of the simplices here
     if sort_axis is not None:
         axis = int(sort_axis)
     elif on_gpu:
-        box = cloud_box(points).cpu()
+        box = (index.box if index is not None else cloud_box(points)).cpu()
         axis = int(torch.argmax(box[8:8 + dim] - box[:dim]).item())
     else:
         axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
@@ -941,33 +964,42 @@ def flood_complex(
         if method == "ball":  # the reference's formulation: cloud sorted along the widest axis (core.py:140-144)
             pts_pad = _pad_rows(pts32[torch.argsort(pts32[:, axis])], dp)
             search = pts_pad[:, axis].contiguous()
-        else:
-            index = shared_index if shared_index is not None else PointIndex(pts32)
+    lm_np = landmarks.detach().to(torch.float32 if on_gpu else dtype).cpu().numpy()
 
-    results: List[Tuple[np.ndarray, np.ndarray]] = []  # (simplices (n,k), values (n,)) in update order
+    results: List[tuple] = []  # (simplices (n,k), values (n,)) or indexed cell-face assignments, in update order
     for d in range(max_dimension + 1):
         if num_rand is None and d < max_dimension:
             continue
-        d_simplices = torch.as_tensor(simplices[d], device=device)
-        num_simplices = len(d_simplices)
+        num_simplices = simplices[d].shape[0]
         if num_simplices == 0:
             continue
-        lm = lm32 if on_gpu else landmarks
-        simplex_vertices = lm[d_simplices]
-        centers, radii = _ball_prep(simplex_vertices, d)
-        splx_idx = torch.argsort(centers[:, axis])
-        simplex_vertices = simplex_vertices[splx_idx]
-        centers = centers[splx_idx]
-        radii = radii[splx_idx]
-        d_simplices = d_simplices[splx_idx]
+        plan = None
+        centers = radii = None
+        if on_gpu and method != "ball":
+            # the culled sweeps need no bounding balls; the simplices are queued along the widest axis (any order
+            # gives the same values), prepared on the host so that nothing here waits for the device
+            v_np = lm_np[simplices[d]]
+            order_np = np.argsort(v_np.mean(axis=1)[:, axis], kind="stable")
+            simp_h = simplices[d][order_np]
+            simplex_vertices = torch.as_tensor(np.ascontiguousarray(v_np[order_np]), device=device)
+        else:
+            d_simplices = torch.as_tensor(simplices[d], device=device)
+            lm = lm32 if on_gpu else landmarks
+            simplex_vertices = lm[d_simplices]
+            centers, radii = _ball_prep(simplex_vertices, d)
+            splx_idx = torch.argsort(centers[:, axis])
+            simplex_vertices = simplex_vertices[splx_idx]
+            centers = centers[splx_idx]
+            radii = radii[splx_idx]
+            order_np = splx_idx.cpu().numpy()
+            simp_h = simplices[d][order_np]
 
         if num_rand is None:
-            weights, vertex_idxs, face_idxs = generate_grid(points_per_edge, max_dimension, device,
-                                                            torch.float32 if on_gpu else dtype)
-            faces = _FaceTable(face_idxs, weights.shape[0], device)
+            weights, vertex_idxs, face_idxs, faces, plan, v_idx_np = _grid_tables(
+                points_per_edge, max_dimension, device, torch.float32 if on_gpu else dtype)
         else:
             weights = generate_uniform_weights(num_rand, d, device, torch.float32 if on_gpu else dtype)
-            vertex_idxs = face_idxs = None
+            vertex_idxs = face_idxs = v_idx_np = None
             faces = _FaceTable(None, weights.shape[0], device)
         LAST_STATS.top_simplices = num_simplices
         LAST_STATS.samples_per_simplex = weights.shape[0]
@@ -985,9 +1017,9 @@ def flood_complex(
                                                    radii if mine is None else radii[mine], weights, faces,
                                                    reduce_hook)
             elif method == "cell":
-                face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook)
+                face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook, plan=plan)
             else:
-                face_dev, _ = _sweep_dimension_bvh(index, sv, weights, faces, reduce_hook)
+                face_dev, _ = _sweep_dimension_bvh(index, sv, weights, faces, reduce_hook, plan=plan)
         else:
             samples = weights.unsqueeze(0) @ sv
             dist, _ = kdtree.query(np.asarray(samples))
@@ -1003,22 +1035,31 @@ def flood_complex(
             face_dev = full
         face_vals = face_dev.cpu().numpy().astype(np.float64)
 
-        simp_h = d_simplices.cpu().numpy()
         if num_rand is None:
+            # faces of the swept simplices.  When those are the top cells of the complex, the rows of the face tables
+            # are known from the enumeration of the faces (no search); else located by key.
+            top_cells = isinstance(stree, SimplexTree) and stree._cells is not None and stree._cells.shape[1] == d + 1
             col = 0
-            for v_idx in vertex_idxs:
-                v_idx = v_idx.cpu().numpy()
-                nf = v_idx.shape[0]
-                face_simplices = simp_h[:, v_idx].reshape(-1, v_idx.shape[1])
-                results.append((face_simplices, face_vals[:, col:col + nf].reshape(-1)))
+            for v_idx in v_idx_np:
+                nf, k = v_idx.shape
+                vals_k = face_vals[:, col:col + nf]
                 col += nf
+                if top_cells and stree.cell_face_index(k - 1) is not None:
+                    combos = list(itertools.combinations(range(d + 1), k))
+                    results.append(("cells", k - 1, order_np, [combos.index(tuple(int(x) for x in row)) for row in v_idx],
+                                    vals_k))
+                else:
+                    results.append((simp_h[:, v_idx].reshape(-1, k), vals_k.reshape(-1)))
         else:
             results.append((simp_h, face_vals[:, 0]))
 
     # hand-off (core.py:278-288)
     if isinstance(stree, SimplexTree):
-        for simp, vals in results:
-            stree.assign_filtration_bulk(simp, vals)
+        for item in results:
+            if isinstance(item[0], str):
+                stree.assign_cell_faces(item[1], item[2], item[3], item[4])
+            else:
+                stree.assign_filtration_bulk(item[0], item[1])
     else:  # pragma: no cover - gudhi tree
         for simp, vals in results:
             for s, v in zip(simp.tolist(), vals.tolist()):

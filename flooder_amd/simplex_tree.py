@@ -29,7 +29,7 @@ from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-__all__ = ["SimplexTree", "DelaunayComplex", "delaunay_simplices", "HAS_GUDHI"]
+__all__ = ["SimplexTree", "DelaunayComplex", "delaunay_simplices", "delaunay_cells", "faces_of_cells", "HAS_GUDHI"]
 
 try:  # pragma: no cover - gudhi is absent from the build image
     import gudhi as _gudhi  # type: ignore
@@ -66,18 +66,13 @@ def _unique_rows(rows: np.ndarray) -> np.ndarray:
     return rows[keep]
 
 
-def delaunay_simplices(points: np.ndarray, max_dimension: Optional[int] = None) -> List[np.ndarray]:
-    """All simplices of the Delaunay triangulation of ``points``, bucketed by dimension.
-
-    Returns ``out[d]`` = sorted unique ``(n_d, d+1)`` int64 array of ascending vertex
-    ids, for d = 0 .. min(max_dimension, ambient dim).  Mirrors what the reference
-    collects from ``stree.get_simplices()`` at ``core.py:135-138``.
-    """
+def delaunay_cells(points: np.ndarray) -> np.ndarray:
+    """Top-dimensional cells of the Delaunay triangulation of ``points``: unique rows of ascending vertex
+    ids, in lexicographic order (Qhull; what ``gudhi.DelaunayComplex`` triangulates with CGAL)."""
     from scipy.spatial import Delaunay
 
     points = np.ascontiguousarray(points, dtype=np.float64)
     n, dim = points.shape
-    top = dim if max_dimension is None else min(max_dimension, dim)
     if dim == 1:
         order = np.argsort(points[:, 0], kind="stable")
         cells = np.stack([order[:-1], order[1:]], axis=1) if n > 1 else np.zeros((0, 2), np.int64)
@@ -86,20 +81,52 @@ def delaunay_simplices(points: np.ndarray, max_dimension: Optional[int] = None) 
         cells = np.arange(n, dtype=np.int64)[None, :]
     else:
         cells = Delaunay(points).simplices
-    cells = np.sort(np.asarray(cells, dtype=np.int64), axis=1)
-    out: List[np.ndarray] = []
+    return _unique_rows(np.sort(np.asarray(cells, dtype=np.int64), axis=1))
+
+
+def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
+                   want_index: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """The d-dimensional faces of ``cells`` (rows of ascending vertex ids): ``(table, index)`` with ``table`` the
+    sorted unique ``(n_d, d+1)`` rows and ``index[c, j]`` the row of ``table`` holding face j of cell c, faces
+    numbered like ``itertools.combinations(range(width), d + 1)`` (``index`` is None when the packed keys would not
+    fit 62 bits; vertices: every one of the ``n_points`` input points is a vertex of the complex, as in gudhi)."""
     width = cells.shape[1]
-    for d in range(top + 1):
-        if d + 1 > width:
-            out.append(np.zeros((0, d + 1), dtype=np.int64))
-            continue
-        combos = list(itertools.combinations(range(width), d + 1))
-        faces = np.concatenate([cells[:, c] for c in combos], axis=0)
-        out.append(_unique_rows(faces))
-    if out and out[0].shape[0] < n:
-        # every input point is a vertex of the complex (gudhi inserts all of them)
-        out[0] = np.arange(n, dtype=np.int64)[:, None]
-    return out
+    if d + 1 > width or cells.shape[0] == 0:
+        return np.zeros((0, d + 1), dtype=np.int64), None
+    if d + 1 == width:
+        return cells, np.arange(cells.shape[0], dtype=np.int64)[:, None]
+    combos = list(itertools.combinations(range(width), d + 1))
+    if d == 0 and n_points > 0:
+        table = np.arange(n_points, dtype=np.int64)[:, None]
+        return table, cells.copy()            # (face j of a cell = its j-th vertex = row id)
+    base = int(cells.max()) + 1
+    k = d + 1
+    if want_index and base ** k < 2 ** 62:
+        mult = base ** np.arange(k - 1, -1, -1, dtype=np.int64)
+        keys = np.stack([cells[:, c] @ mult for c in combos], axis=1)          # (n_cells, n_combos)
+        uk, inv = np.unique(keys.reshape(-1), return_inverse=True)
+        table = np.empty((uk.shape[0], k), dtype=np.int64)
+        rest = uk
+        for j in range(k - 1, -1, -1):
+            table[:, j] = rest % base
+            rest = rest // base
+        return table, inv.reshape(keys.shape).astype(np.int64)
+    faces = np.concatenate([cells[:, c] for c in combos], axis=0)
+    return _unique_rows(faces), None
+
+
+def delaunay_simplices(points: np.ndarray, max_dimension: Optional[int] = None) -> List[np.ndarray]:
+    """All simplices of the Delaunay triangulation of ``points``, bucketed by dimension.
+
+    Returns ``out[d]`` = sorted unique ``(n_d, d+1)`` int64 array of ascending vertex
+    ids, for d = 0 .. min(max_dimension, ambient dim).  Mirrors what the reference
+    collects from ``stree.get_simplices()`` at ``core.py:135-138``.
+    """
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    n, dim = points.shape
+    top = dim if max_dimension is None else min(max_dimension, dim)
+    cells = delaunay_cells(points)
+    return [faces_of_cells(cells, d, n)[0] for d in range(top + 1)]
 
 
 class SimplexTree:
@@ -110,6 +137,56 @@ class SimplexTree:
         self._vals: Dict[int, np.ndarray] = {}
         self._pending: Dict[int, Dict[Tuple[int, ...], float]] = {}
         self._persistence = None
+        # complexes built from top-dimensional cells (``from_cells``): face tables are enumerated on first use
+        self._cells: Optional[np.ndarray] = None
+        self._n_points = 0
+        self._lazy: set = set()                       # dimensions not enumerated yet
+        self._cell_faces: Dict[int, Optional[np.ndarray]] = {}   # d -> (n_cells, n_combos) rows of table d
+        self._monotone = False                        # make_filtration_non_decreasing has run: late tables inherit
+
+    @classmethod
+    def from_cells(cls, cells: np.ndarray, n_points: int, eager: Optional[int] = None) -> "SimplexTree":
+        """Complex spanned by top-dimensional ``cells`` (unique rows of ascending vertex ids) over ``n_points``
+        vertices, filtration values NaN (what ``gudhi.DelaunayComplex(...).create_simplex_tree()`` returns).  Face
+        tables of dimension <= ``eager`` (default: all) are enumerated now, the others when first touched - the
+        6-D Delaunay complex of 2000 points has 15 million simplices, of which a ``max_dimension=2`` run needs
+        1.4 million."""
+        st = cls()
+        cells = np.asarray(cells, dtype=np.int64)
+        st._cells = cells
+        st._n_points = int(n_points)
+        top = cells.shape[1] - 1
+        st._lazy = set(range(top + 1))
+        for d in range(top + 1 if eager is None else min(eager, top) + 1):
+            st._materialise(d)
+        return st
+
+    def _materialise(self, d: int) -> None:
+        if d not in self._lazy:
+            return
+        self._lazy.discard(d)
+        # (the cell -> face rows cost an argsort of all faces: kept only for the tables enumerated up front, which
+        # are the ones the sweep assigns values to)
+        table, index = faces_of_cells(self._cells, d, self._n_points, want_index=not self._monotone)
+        self._cell_faces[d] = index
+        if table.shape[0]:
+            self._rows[d] = table
+            self._vals[d] = np.full(table.shape[0], np.nan, dtype=np.float64)
+            if self._monotone and d > 0:     # the monotone pass has run already: a late table takes its faces' maxima
+                self._materialise(d - 1)
+                self._raise_dimension(d)
+
+    def _materialise_all(self) -> None:
+        for d in sorted(self._lazy):
+            self._materialise(d)
+
+    def cell_face_index(self, d: int) -> Optional[np.ndarray]:
+        """``index[c, j]`` = row of the dimension-d table holding face j (``itertools.combinations`` order of the
+        kept vertex positions) of top cell c; None for complexes not built from cells."""
+        if self._cells is None:
+            return None
+        self._materialise(d)
+        return self._cell_faces.get(d)
 
     # ------------------------------------------------------------------ bulk API
     @classmethod
@@ -127,14 +204,17 @@ class SimplexTree:
 
     def simplices_of_dimension(self, d: int) -> np.ndarray:
         self._flush()
+        self._materialise(d)
         return self._rows.get(d, np.zeros((0, d + 1), dtype=np.int64))
 
     def filtrations_of_dimension(self, d: int) -> np.ndarray:
         self._flush()
+        self._materialise(d)
         return self._vals.get(d, np.zeros((0,), dtype=np.float64))
 
     def _locate(self, d: int, query: np.ndarray) -> np.ndarray:
         """Index of each (sorted-ascending) query row in the dimension-d table, -1 if absent."""
+        self._materialise(d)
         table = self._rows.get(d)
         query = np.asarray(query, dtype=np.int64).reshape(-1, d + 1)
         if table is None or table.shape[0] == 0 or query.shape[0] == 0:
@@ -184,6 +264,7 @@ class SimplexTree:
     def _flush(self) -> None:
         if not self._pending:
             return
+        self._materialise_all()   # (explicit inserts: the complex is no longer the span of its cells)
         for d, items in self._pending.items():
             if not items:
                 continue
@@ -205,6 +286,18 @@ class SimplexTree:
         if d in self._pending and key in self._pending[d]:
             return True
         return bool(self._locate(d, np.array([key]))[0] >= 0) if d >= 0 else False
+
+    def assign_cell_faces(self, d: int, cell_rows: np.ndarray, face_cols: Sequence[int], values: np.ndarray) -> bool:
+        """``values[i, j]`` -> face ``face_cols[j]`` (numbering of ``cell_face_index``) of top cell ``cell_rows[i]``,
+        through the index kept from the enumeration of the faces instead of a search per row.  Later rows win on
+        duplicates, as in ``assign_filtration_bulk``.  False (nothing done) when no such index exists."""
+        index = self.cell_face_index(d)
+        if index is None or d not in self._vals:
+            return False
+        rows = index[np.asarray(cell_rows)][:, list(face_cols)]
+        self._vals[d][rows.reshape(-1)] = np.asarray(values, dtype=np.float64).reshape(-1)
+        self._persistence = None
+        return True
 
     def insert(self, simplex: Iterable[int], filtration: float = 0.0) -> bool:
         """Insert a simplex and all its faces (gudhi semantics: existing simplices keep
@@ -252,6 +345,7 @@ class SimplexTree:
 
     def num_simplices(self) -> int:
         self._flush()
+        self._materialise_all()
         return int(sum(r.shape[0] for r in self._rows.values()))
 
     def num_vertices(self) -> int:
@@ -260,6 +354,8 @@ class SimplexTree:
 
     def dimension(self) -> int:
         self._flush()
+        if self._lazy:
+            return max(max(self._lazy), max([d for d, r in self._rows.items() if r.shape[0]], default=-1))
         dims = [d for d, r in self._rows.items() if r.shape[0]]
         return max(dims) if dims else -1
 
@@ -267,6 +363,7 @@ class SimplexTree:
         """Yield ``(vertex list, filtration)`` in the depth-first order of a simplex tree:
         lexicographic, a simplex directly before the simplices it prefixes."""
         self._flush()
+        self._materialise_all()
         dims = sorted(d for d, r in self._rows.items() if r.shape[0])
         if not dims:
             return
@@ -293,6 +390,7 @@ class SimplexTree:
         """``{simplex tuple: filtration}`` of the whole complex (what ``dict(stree.get_simplices())`` gives,
         reference core.py:285-288) without a Python-level generator per simplex."""
         self._flush()
+        self._materialise_all()
         out: Dict[Tuple[int, ...], float] = {}
         for d in sorted(self._rows):
             rows = self._rows[d]
@@ -303,6 +401,7 @@ class SimplexTree:
     def get_filtration(self) -> Iterator[Tuple[List[int], float]]:
         """Simplices sorted by (filtration, dimension, lexicographic), gudhi's filtration order."""
         self._flush()
+        self._materialise_all()
         items = []
         for d, rows in self._rows.items():
             for row, v in zip(rows.tolist(), self._vals[d].tolist()):
@@ -328,35 +427,58 @@ class SimplexTree:
             if i >= 0:
                 yield row, float(self._vals[d][i])
 
+    def _facet_rows(self, d: int) -> Optional[np.ndarray]:
+        """``out[i, j]`` = row of table d-1 holding the facet of simplex i of table d that omits its j-th vertex,
+        read off the cell -> face indices of the two tables (every face lies in some cell); None without them."""
+        if self._cells is None or self._cell_faces.get(d) is None or self._cell_faces.get(d - 1) is None or d == 0:
+            return None
+        width = self._cells.shape[1]
+        hi_c = list(itertools.combinations(range(width), d + 1))
+        lo_c = {c: i for i, c in enumerate(itertools.combinations(range(width), d))}
+        idx_hi, idx_lo = self._cell_faces[d], self._cell_faces[d - 1]
+        out = np.empty((self._rows[d].shape[0], d + 1), dtype=np.int64)
+        for j, cmb in enumerate(hi_c):
+            for m in range(d + 1):
+                out[idx_hi[:, j], m] = idx_lo[:, lo_c[cmb[:m] + cmb[m + 1:]]]
+        return out
+
+    def _raise_dimension(self, d: int) -> bool:
+        """One step of the monotone pass: dimension-d values raised to the maxima of their facets."""
+        rows = self._rows.get(d)
+        if d == 0 or rows is None or rows.shape[0] == 0 or (d - 1) not in self._rows:
+            return False
+        vals = self._vals[d]
+        lower = self._vals[d - 1]
+        face_max = np.full(rows.shape[0], -np.inf)
+        facets = self._facet_rows(d)
+        for j in range(d + 1):
+            if facets is not None:
+                idx = facets[:, j]
+            else:
+                face = np.delete(rows, j, axis=1)
+                idx = self._locate(d - 1, face)
+            fv = np.where(idx >= 0, lower[np.maximum(idx, 0)], -np.inf)
+            fv = np.where(np.isnan(fv), -np.inf, fv)
+            face_max = np.maximum(face_max, fv)
+        own_nan = np.isnan(vals)
+        raised = np.where(own_nan, face_max, np.maximum(vals, face_max))
+        raised = np.where(np.isneginf(raised), vals, raised)
+        diff = ~((raised == vals) | (np.isnan(raised) & np.isnan(vals)))
+        if diff.any():
+            self._vals[d] = raised
+            return True
+        return False
+
     def make_filtration_non_decreasing(self) -> bool:
         """Raise every simplex to at least the value of each of its faces, dimension by
         dimension (gudhi ``Simplex_tree::make_filtration_non_decreasing``).  A NaN face value
-        does not propagate; a NaN own value is replaced by the maximum over its faces."""
+        does not propagate; a NaN own value is replaced by the maximum over its faces.
+        Face tables that have not been enumerated yet take part when they are (``from_cells``)."""
         self._flush()
         changed = False
-        dims = sorted(self._rows)
-        for d in dims:
-            if d == 0 or (d - 1) not in self._rows:
-                continue
-            rows = self._rows[d]
-            if rows.shape[0] == 0:
-                continue
-            vals = self._vals[d]
-            lower = self._vals[d - 1]
-            face_max = np.full(rows.shape[0], -np.inf)
-            for j in range(d + 1):
-                face = np.delete(rows, j, axis=1)
-                idx = self._locate(d - 1, face)
-                fv = np.where(idx >= 0, lower[np.maximum(idx, 0)], -np.inf)
-                fv = np.where(np.isnan(fv), -np.inf, fv)
-                face_max = np.maximum(face_max, fv)
-            own_nan = np.isnan(vals)
-            raised = np.where(own_nan, face_max, np.maximum(vals, face_max))
-            raised = np.where(np.isneginf(raised), vals, raised)
-            diff = ~((raised == vals) | (np.isnan(raised) & np.isnan(vals)))
-            if diff.any():
-                changed = True
-                self._vals[d] = raised
+        for d in sorted(self._rows):
+            changed = self._raise_dimension(d) or changed
+        self._monotone = True
         if changed:
             self._persistence = None
         return changed
@@ -367,6 +489,7 @@ class SimplexTree:
         from .persistence import persistence_pairs
 
         self._flush()
+        self._materialise_all()
         self._persistence = persistence_pairs(self, min_persistence=min_persistence,
                                               persistence_dim_max=persistence_dim_max)
 
@@ -405,4 +528,4 @@ class DelaunayComplex:
         self._points = np.asarray(points, dtype=np.float64)
 
     def create_simplex_tree(self, *_, **__) -> SimplexTree:
-        return SimplexTree.from_arrays(delaunay_simplices(self._points))
+        return SimplexTree.from_cells(delaunay_cells(self._points), self._points.shape[0])

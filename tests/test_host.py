@@ -200,3 +200,47 @@ def test_sample_order_gives_compact_chunks():
         assert sorted(o.tolist()) == list(range(w.shape[0]))
         if w.shape[0] <= 64:
             assert o.tolist() == list(range(w.shape[0]))
+
+
+def test_lazy_tree_from_cells_equals_eager_tree():
+    """SimplexTree.from_cells (face tables enumerated on first use, cell -> face row index) against from_arrays:
+    same complex, same values after bulk assignment + monotone pass, whatever is enumerated late."""
+    import itertools
+    from flooder_amd.simplex_tree import SimplexTree, delaunay_cells, delaunay_simplices, faces_of_cells
+    rng = np.random.default_rng(3)
+    for dim, n in ((2, 60), (3, 80), (4, 40)):
+        P = rng.normal(size=(n, dim))
+        cells = delaunay_cells(P)
+        tables = delaunay_simplices(P)
+        eager = SimplexTree.from_arrays(tables)
+        lazy = SimplexTree.from_cells(cells, n, eager=1)
+        assert lazy.dimension() == dim
+        # index: face j of cell c
+        for d in range(dim + 1):
+            table, index = faces_of_cells(cells, d, n)
+            assert np.array_equal(table, tables[d])
+            combos = list(itertools.combinations(range(dim + 1), d + 1))
+            for j, cmb in enumerate(combos):
+                assert np.array_equal(table[index[:, j]], cells[:, list(cmb)])
+        # assign values to edges and vertices only, then monotone: higher tables inherit (some enumerated late)
+        e = tables[1]
+        ev = rng.random(e.shape[0])
+        for st in (eager, lazy):
+            st.assign_filtration_bulk(tables[0], np.zeros(n))
+            st.assign_filtration_bulk(e, ev)
+            st.make_filtration_non_decreasing()
+        assert lazy._lazy                      # dimensions >= 2 still not enumerated
+        for d in range(dim + 1):
+            assert np.array_equal(lazy.simplices_of_dimension(d), eager.simplices_of_dimension(d))
+            assert np.allclose(lazy.filtrations_of_dimension(d), eager.filtrations_of_dimension(d), equal_nan=True)
+        assert lazy.to_dict() == eager.to_dict()
+        assert lazy.num_simplices() == eager.num_simplices()
+        # indexed assignment == located assignment
+        a = SimplexTree.from_cells(cells, n)
+        b = SimplexTree.from_cells(cells, n)
+        vals = rng.random((cells.shape[0], dim + 1))
+        combos = list(itertools.combinations(range(dim + 1), dim))      # facets
+        assert a.assign_cell_faces(dim - 1, np.arange(cells.shape[0]), list(range(dim + 1)), vals)
+        for j, cmb in enumerate(combos):
+            b.assign_filtration_bulk(cells[:, list(cmb)], vals[:, j])
+        assert np.array_equal(np.isnan(a.filtrations_of_dimension(dim - 1)), np.isnan(b.filtrations_of_dimension(dim - 1)))
