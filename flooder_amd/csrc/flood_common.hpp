@@ -21,6 +21,7 @@ extern int g_bvh_refine_pct;
 extern int g_cell_exh_sparse;
 extern int g_cell_brute_max;
 extern int g_finish_focus_pct;
+extern int g_finish_refresh;
 extern int g_cell_tries;
 extern int g_cell_super_weight;
 extern int g_cell_super_n0;

@@ -26,20 +26,23 @@ using namespace flooder;
 namespace {
 
 constexpr float SAFE = 0.99999f;
-constexpr int REFRESH = 4;  // leaf evaluations between two reloads of the face maxima
 constexpr int SHORT_LIST = 1024;
+constexpr int TOP_NODES = 1024;  // nodes of the two top tree levels kept in LDS (32 KB in 3D)
 
 template <int DIM>
 __global__ __launch_bounds__(256) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_count,
-    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int items_cap, int refine_pct, float focus_frac, int32_t* __restrict__ queue,
+    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int items_cap, int refine_pct, float focus_frac, int refresh_every, int32_t* __restrict__ queue,
     uint32_t* __restrict__ d2, FaceAcc acc, unsigned long long* __restrict__ top,
     int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
+  // the two top levels of the box tree (993 nodes for a million points) live in LDS, shared by the block's waves:
+  // every search starts there, and a focus round restarts there - only the leaf groups are fetched from L2
+  __shared__ float s_top[TOP_NODES * 2 * DP];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int tiles = (R + 63) >> 6;
@@ -58,7 +61,27 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   const int64_t n_items = n_base * subs;
   const int per_sub = 64 / subs;
   const int topl = lv.n_levels - 1;
+  // stage levels topl (first) and topl - 1 (behind it) when they fit
+  const int top_cnt = (int)lv.count[topl];
+  const int sub_cnt = topl >= 2 ? (int)lv.count[topl - 1] : 0;    // (level 0 = leaves: fetched per group)
+  const int staged_sub = (sub_cnt > 0 && top_cnt + sub_cnt <= TOP_NODES) ? sub_cnt : 0;
+  const int stage_min_lvl = topl >= 1 ? (staged_sub ? topl - 1 : topl) : MAXL;  // levels >= this are read from LDS
+  if (topl >= 1) {
+    const float* src_top = nodes + lv.off[topl] * 2 * DP;
+    for (int i = threadIdx.x; i < top_cnt * 2 * DP; i += 256) s_top[i] = src_top[i];
+    if (staged_sub) {
+      const float* src_sub = nodes + lv.off[topl - 1] * 2 * DP;
+      for (int i = threadIdx.x; i < staged_sub * 2 * DP; i += 256) s_top[top_cnt * 2 * DP + i] = src_sub[i];
+    }
+    __syncthreads();
+  }
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, n_dropped = 0, n_live0 = 0, n_rounds = 0;
+#ifdef FLOODER_PHASE_TIMERS
+  unsigned long long tf[6] = {0, 0, 0, 0, 0, 0}, tf_prev = __builtin_amdgcn_s_memtime();
+#define FIN_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tf[i] += t_ - tf_prev; tf_prev = t_; } while (0)
+#else
+#define FIN_PHASE(i) do {} while (0)
+#endif
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
   const bool static_deal = n_items <= (int64_t)gridDim.x * 4;
@@ -75,6 +98,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       g = (int64_t)wave_uniform(g32);
       if (g >= n_items) break;
     }
+    FIN_PHASE(5);  // (queue pop, bookkeeping)
     const int sub = (int)(g % subs);
     g /= subs;
     int64_t s;
@@ -157,9 +181,15 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       for (int k = 0; k < DIM; ++k) { c_lo[k] = __builtin_inff(); c_hi[k] = -__builtin_inff(); }
       if (idx < lv.count[lvl]) {
         float lo[DP], hi[DP];
-        const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
-        load_row<DP>(nb, lo);
-        load_row<DP>(nb + DP, hi);
+        if (lvl >= stage_min_lvl) {
+          const float* nb = s_top + ((lvl == topl ? 0 : top_cnt) + (int)idx) * 2 * DP;
+#pragma unroll
+          for (int k = 0; k < DP; ++k) { lo[k] = nb[k]; hi[k] = nb[DP + k]; }
+        } else {
+          const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
+          load_row<DP>(nb, lo);
+          load_row<DP>(nb + DP, hi);
+        }
         lb = 0.f;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
@@ -248,6 +278,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       };
       rebound();
       ++n_rounds;
+      FIN_PHASE(0);  // item setup / round setup (loads, face maxima, live set, boxes)
       int lvl = topl;
       float lb0 = child_bounds(topl, 0);
       int64_t grp0 = 0;
@@ -299,6 +330,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
               if (!(cand && need)) lb0 = __builtin_inff();
             }
           }
+          FIN_PHASE(1);  // node expansion (+ refine at the leaf level)
           continue;
         }
         // ---- leaf level: nearest unvisited leaf of the current group
@@ -323,9 +355,11 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
           const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[k], p[k] - bhi[k]), 0.f);
           lbp = __builtin_fmaf(gap, gap, lbp);
         }
-        if (__ballot(focus && (lbp * SAFE < best)) == 0ull) continue;
+        if (__ballot(focus && (lbp * SAFE < best)) == 0ull) { FIN_PHASE(2); continue; }
+        FIN_PHASE(2);  // leaf selection + test
         eval_leaf(c);
-        if (++since >= REFRESH) {
+        FIN_PHASE(3);  // leaf evaluation
+        if (++since >= refresh_every) {
           since = 0;
           refresh();  // other waves may have raised the face maxima meanwhile: focus samples may drop out
           focus = focus && live;
@@ -333,6 +367,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         } else {
           Mf = wave_max_f32(focus ? best : -1.f);
         }
+        FIN_PHASE(4);  // bounds / live set upkeep
         if (!(Mf >= 0.f)) break;
       }
       // ---- deliver the round: focus samples that stayed live to its end are exact (a focus sample that dropped out
@@ -349,6 +384,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       }
       done = done || focus;
       refresh();
+      FIN_PHASE(4);
       if (!(M >= 0.f)) break;
     }
   }
@@ -361,6 +397,10 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       atomicAdd(&stats[5], n_live0);
     }
     atomicAdd(&stats[6], n_rounds);
+#ifdef FLOODER_PHASE_TIMERS
+    if (mode == 2)
+      for (int i = 0; i < 6; ++i) atomicAdd(&stats[40 + i], tf[i]);  // diagnostic build only (tools/bvh_phase.py)
+#endif
   }
 }
 
@@ -381,7 +421,7 @@ struct FinishOp {
     // the cell sweep's when `probed`, else pass 0 here)
     for (int mode = probed ? 1 : 0; mode < 3; ++mode) {
       hipLaunchKernelGGL((finish_faces_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, k1,
-                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, ctl + mode, d2, acc, top,
+                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, g_finish_refresh, ctl + mode, d2, acc, top,
                          top_list, ctl + 3, stats);
     }
     return check_launch("finish_faces");

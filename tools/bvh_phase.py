@@ -23,8 +23,10 @@ for _ in range(2):
     stats.zero_()
     core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
 torch.cuda.synchronize()
-t = stats[49:53].cpu().numpy().astype(float)
+t = stats[49:55].cpu().numpy().astype(float)
 ev, te, nd = stats[9:12].cpu().tolist()
-print(which, "leaf evals", ev, "leaf tests", te, "node expansions", nd)
-for n, v, cnt in zip(["setup", "node expansion", "leaf select+test (incl. skipped)", "leaf evaluation"], t, [1, nd, te, ev]):
+rounds = int(stats[15])
+print(which, "rest pass of the finish: leaf evals", ev, "leaf tests", te, "node expansions", nd, "focus rounds", rounds, "(counts: all passes)")
+for n, v, cnt in zip(["item / round setup", "node expansion (+refine)", "leaf select + test", "leaf evaluation", "bounds / live upkeep + delivery", "queue pop"],
+                     t, [rounds, nd, te, ev, ev, 1]):
     print(f"{n:34s} {v / t.sum() * 100:6.2f} %   {v / max(cnt, 1):9.0f} cycles per event")

@@ -74,6 +74,12 @@ PY
             timeout 300 python tools/wave_ends.py $wl ${W:-1} > $OUT/wave_ends_${wl}_${W:-1}.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             tail -2 $OUT/wave_ends_${wl}_${W:-1}.txt ;;
+    fphase:*) wl=${s#fphase:}
+            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            timeout 300 python tools/bvh_phase.py $wl 2>&1 | grep -v amdgpu.ids > $OUT/fin_phase_$wl.txt
+            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            cat $OUT/fin_phase_$wl.txt ;;
     ptimers:*) wl=${s#ptimers:}
             cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
