@@ -109,6 +109,7 @@ def parse_args():
                          "(experiment: reference candidate count, descending), weight (core.simplex_order)")
     ap.add_argument("--unfused", action="store_true", help="sweep -> finish -> face_max over the full (S, R) buffer")
     ap.add_argument("--units", default=None, help="cut sizes of the sample bisection, e.g. 1024/256/64/16")
+    ap.add_argument("--no-slots", action="store_true", help="one face-maximum word per (simplex, face) instead of per distinct face")
     ap.add_argument("--no-super", action="store_true", help="cell sweep chunk by chunk (no shared stage per run of four)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
@@ -258,6 +259,11 @@ def main():
     del cnt0
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
     plan = core.SamplePlan(weights, faces)
+    # one running maximum per DISTINCT face of the complex, as flood_complex uses on one GPU (shards keep (S, F))
+    slots = None
+    if args.method == "cell" and mine is None and hook is None and not args.unfused and not args.no_slots:
+        rows = stree._locate(d, np.sort(simp.cpu().numpy(), axis=1))      # rows of the top table, in sweep order
+        slots = core.shared_face_slots(stree, d, rows, [v.cpu().numpy() for v in vertex_idxs], dev)
 
     def build_index(timer=None):
         with core._span(timer, "index"):
@@ -276,7 +282,8 @@ def main():
         st = stats if with_stats else None
         if args.method == "cell":
             stats.zero_()
-            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=st, plan=plan)
+            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=st, plan=plan,
+                                                face_slots=None if slots is None else slots[:2])
         elif args.method == "bvh":
             stats.zero_()
             out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer,
@@ -322,6 +329,8 @@ def main():
 
     out = step(None, with_stats=True)  # untimed: work counters for the report
     torch.cuda.synchronize()
+    if slots is not None:
+        out = out[slots[0].long()]     # (n_slots,) values per distinct face -> (S, F) for the parity check below
 
     # ------------------------------------------------------------------ per-kernel numbers (rank 0's share)
     k_ms = {k: v / args.steps for k, v in timer.totals_ms().items()}   # HIP events on the launch stream
@@ -353,7 +362,8 @@ def main():
                 "fallback_nodes_expanded": sh[11], "fallback_max_tests_one_tile": sh[12],
                 "finish_tiles_dropped_on_arrival": sh[13], "finish_samples_live_on_arrival": sh[14],
                 "finish_focus_rounds": sh[15],
-                "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks}
+                "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks,
+                "shared_face_slots": slots is not None}
     else:
         per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)
     done_evals = sum(v["pairs"] for v in per_kernel.values())

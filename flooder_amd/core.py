@@ -500,6 +500,29 @@ class PointIndex:
                           "flooder_bvh_build_f32")
 
 
+def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.ndarray], device):
+    """Slots of the fused face maxima with ONE word per distinct face of the complex: for the top cells of a
+    ``SimplexTree.from_cells`` complex (in the order ``order_np`` of the sweep) and the face numbering of
+    ``generate_grid`` (``v_idx_np[k]``: vertex positions of the codimension-k faces).  Returns
+    ``(slot (S, F) int32 tensor, n_slots, offsets)`` with ``offsets[k]`` = first slot of the faces of codimension k
+    (slot - offsets[k] = row of the dimension d-k table), or None when the tree has no cell -> face index."""
+    if not isinstance(stree, SimplexTree) or stree._cells is None or stree._cells.shape[1] != d + 1:
+        return None
+    cols, offsets, total = [], [], 0
+    for v_idx in v_idx_np:
+        nf, k = v_idx.shape
+        index = stree.cell_face_index(k - 1)
+        if index is None:
+            return None
+        combos = list(itertools.combinations(range(d + 1), k))
+        pick = [combos.index(tuple(int(x) for x in row)) for row in v_idx]
+        cols.append(index[order_np][:, pick] + total)
+        offsets.append(total)
+        total += stree.simplices_of_dimension(k - 1).shape[0]
+    slot = np.ascontiguousarray(np.concatenate(cols, axis=1).astype(np.int32))
+    return torch.as_tensor(slot, device=device), total, offsets
+
+
 def simplex_order(index: "PointIndex", verts: torch.Tensor) -> torch.Tensor:
     """Work order of the simplices for the culled sweeps: descending estimated number of cloud points inside the
     simplex's bounding box (``flooder_simplex_weight_f32``).  Work per simplex is heavy-tailed - a tetrahedron in
@@ -701,13 +724,15 @@ CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spac
 # that cannot raise a face maximum.  False: sweep -> finish -> flooder_face_max_f32 over the full (S, R) buffer.
 FUSED_FACES = True
 CELL_PROBE = True    # the finish's probe (one greedy tree descent per flagged tile) runs inside the cell sweep
+SHARED_FACE_SLOTS = True   # one running maximum per distinct face of the complex (top-dimensional grid sweeps)
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                           reduce_hook: Optional[Callable[[torch.Tensor], None]],
                           want_dist: bool = False, timer: Optional[_KernelTimer] = None,
-                          stats: Optional[torch.Tensor] = None, plan: Optional[SamplePlan] = None):
+                          stats: Optional[torch.Tensor] = None, plan: Optional[SamplePlan] = None,
+                          face_slots: Optional[Tuple[torch.Tensor, int]] = None):
     """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree sweep of the unverified tiles
     -> [reduce_hook] -> face max.  No host synchronisation.
 
@@ -721,6 +746,11 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     evaluated, leaves tested, nodes expanded, most tests by one tile}, [13] fine rows swept after pruning,
     [14] fine rows in total (both 0 when pruning is off); on the fused path [13] = tiles the last finish pass
     dropped on arrival, [14] = samples still live on arrival in that pass.
+
+    ``face_slots`` = (slot (S, F) int32, n_slots), fused path only: face f of simplex s accumulates into word
+    ``slot[s, f]`` and the result is the (n_slots,) vector of per-slot values instead of the (S, F) matrix -
+    one slot per DISTINCT face of the complex lets the simplices sharing a triangle / edge / vertex share its
+    running maximum (``shared_face_slots``).
     """
     lib = _native.load()
     dev = index.pts.device
@@ -744,8 +774,9 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # scratch that only the flagged tiles touch.
         F = faces.n_faces
         tiles = (R + 63) // 64
+        slot_t, n_slots = face_slots if face_slots is not None else (None, S * F)
         ctl = torch.zeros(24, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish ([7]: top count), [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices, lists on
-        face_bits = torch.zeros((S, F), dtype=torch.int32, device=dev)
+        face_bits = torch.zeros(n_slots, dtype=torch.int32, device=dev)
         top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
         d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
@@ -763,8 +794,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
-                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(flags), ctl[1:].data_ptr(),
-                _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
+                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags),
+                ctl[1:].data_ptr(), _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
                 ctl[7:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
                 _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(sub(0, 9)), st),
@@ -775,12 +806,12 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[4:].data_ptr(),
                 _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
                 _native.ptr(plan.memb_all), F,
-                _native.ptr(face_bits), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
+                _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
-        out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
+        out_face = torch.empty(n_slots if face_slots is not None else (S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
-            _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), S * F, _native.ptr(out_face), st),
+            _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), n_slots, _native.ptr(out_face), st),
                           "flooder_face_values_f32")
         return out_face, None
 
@@ -1017,7 +1048,12 @@ def flood_complex(
                                                    radii if mine is None else radii[mine], weights, faces,
                                                    reduce_hook)
             elif method == "cell":
-                face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook, plan=plan)
+                slots = None
+                if (SHARED_FACE_SLOTS and FUSED_FACES and num_rand is None and mine is None and reduce_hook is None
+                        and faces.n_faces <= 32):
+                    slots = shared_face_slots(stree, d, order_np, v_idx_np, device)
+                face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook, plan=plan,
+                                                    face_slots=None if slots is None else slots[:2])
             else:
                 face_dev, _ = _sweep_dimension_bvh(index, sv, weights, faces, reduce_hook, plan=plan)
         else:
@@ -1035,7 +1071,13 @@ def flood_complex(
             face_dev = full
         face_vals = face_dev.cpu().numpy().astype(np.float64)
 
-        if num_rand is None:
+        if on_gpu and method == "cell" and slots is not None:
+            # one value per distinct face: straight into the tables
+            for v_idx, off in zip(v_idx_np, slots[2]):
+                k = v_idx.shape[1]
+                n_rows = stree.simplices_of_dimension(k - 1).shape[0]
+                results.append(("table", k - 1, face_vals[off:off + n_rows]))
+        elif num_rand is None:
             # faces of the swept simplices.  When those are the top cells of the complex, the rows of the face tables
             # are known from the enumeration of the faces (no search); else located by key.
             top_cells = isinstance(stree, SimplexTree) and stree._cells is not None and stree._cells.shape[1] == d + 1
@@ -1056,7 +1098,10 @@ def flood_complex(
     # hand-off (core.py:278-288)
     if isinstance(stree, SimplexTree):
         for item in results:
-            if isinstance(item[0], str):
+            if isinstance(item[0], str) and item[0] == "table":
+                stree._vals[item[1]][:] = item[2]
+                stree._persistence = None
+            elif isinstance(item[0], str):
                 stree.assign_cell_faces(item[1], item[2], item[3], item[4])
             else:
                 stree.assign_filtration_bulk(item[0], item[1])

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
   const int64_t n_heavy_items = (use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
   const int64_t n_items = SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
                                 : (use_lists ? n_heavy_items + (int64_t)dl.count[0] : n_simplices * chunks);
+  if (n_items == 0) return;  // (nothing for this launch: no need for 3072 waves to pop an empty queue)
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
 #ifdef FLOODER_PHASE_TIMERS
   unsigned long long t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
           v = b > v ? b : v;
         }
         v = wave_max_u32(v);
-        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
+        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
       }
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
@@ -1089,6 +1090,8 @@ struct CellOp {
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       const int brute_max = g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP;
+      // (a short queue - a rank's share of a multi-GPU run - is balanced better chunk by chunk than in runs of four)
+      if (dl.list && n_chunks < (int64_t)g_cell_super_min_chunks) dl = DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
       if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, true>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
@@ -1194,7 +1197,7 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           ld_out, row_list, row_cnt, list_stride, flag_list, flag_count, stats,
-                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr},
+                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
                           DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                           nullptr, stream, "flooder_sweep_cell_f32: bad argument");
 }
@@ -1202,8 +1205,9 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
-                                 int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* top, int32_t* top_list, int32_t* top_count, int32_t* defer_list,
+                                 int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
+                                 int32_t* flag_count, uint64_t* top, int32_t* top_list, int32_t* top_count,
+                                 int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
@@ -1220,7 +1224,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, R, nullptr, nullptr, 0, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
-                                  top_count},
+                                  top_count, face_slot},
                           DeferList{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
                                     light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0},
                           defer_list ? defer_ctl + 1 : nullptr,

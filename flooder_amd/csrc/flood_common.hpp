@@ -26,6 +26,7 @@ extern int g_cell_tries;
 extern int g_cell_super_weight;
 extern int g_cell_super_n0;
 extern int g_cell_super_sparse;
+extern int g_cell_super_min_chunks;
 extern int g_curve_bits;
 extern int g_cell_exh_tries;
 extern int g_finish_items_cap;
@@ -157,6 +158,14 @@ struct FaceAcc {
   unsigned long long* top;
   int32_t* top_list;
   int32_t* top_count;
+  // slot of (simplex s, face f) in face_bits: slot[s * n_faces + f], or s * n_faces + f when null.  A triangle, an
+  // edge or a vertex is a face of several simplices and its samples have bit-identical coordinates from each of them
+  // (the zero weights contribute exact zeros): with one slot per DISTINCT face the first simplex that settles a face
+  // lets every other one drop that face's samples in the finish.
+  const int32_t* slot;
+  __device__ __forceinline__ int64_t slot_of(int64_t s, int f) const {
+    return slot ? (int64_t)slot[s * (int64_t)n_faces + f] : s * (int64_t)n_faces + f;
+  }
 };
 
 // Which sample rows of a simplex a sweep works on: all R rows of the weight table (list == nullptr), or

@@ -132,17 +132,21 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
     const bool settled = !exists || (seed & SETTLED_BIT) != 0u;  // settled by the cell sweep: delivered already
     float best = __uint_as_float(seed & ~SETTLED_BIT);
     const uint32_t mb = settled ? 0u : acc.memb[r];
-    const uint32_t* fbase = acc.face_bits + s * (int64_t)acc.n_faces;
+    // this lane's face slot (lane f < n_faces holds the slot of face f of the simplex)
+    const int64_t my_slot = lane < acc.n_faces ? acc.slot_of(s, lane) : 0;
 
     // ---- live set: unsettled samples whose upper bound still exceeds the running maximum of one of their faces
     bool live, done = settled || mb == 0u;  // done: settled exactly and delivered (or nothing to deliver)
     float M, tlo[DIM], thi[DIM];
+    uint32_t fb_seen = 0u;  // lane f: the last value read of face f's running maximum (a lower bound of the current one)
     auto refresh = [&]() {
-      const uint32_t fb = lane < acc.n_faces
-                              ? __hip_atomic_load(fbase + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+      // only the faces some not yet settled sample of the tile lies on are (re)loaded: usually one to three
+      uint32_t um = wave_or_u32(done ? 0u : mb);
+      const uint32_t fb = (lane < acc.n_faces && ((um >> lane) & 1u))
+                              ? __hip_atomic_load(acc.face_bits + my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                               : 0xffffffffu;
+      if (fb != 0xffffffffu) fb_seen = fb;
       uint32_t thr = 0xffffffffu;
-      uint32_t um = wave_or_u32(mb);
       while (um) {  // (wave-uniform)
         const int f = __builtin_ctz(um);
         um &= um - 1u;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       eval_leaf(grp);
       if (exists && !settled) d2[s * (int64_t)R + r] = __float_as_uint(best);
       // upper bound of the tile among the samples that still matter
-      const uint32_t fb = lane < acc.n_faces ? fbase[lane] : 0xffffffffu;
+      const uint32_t fb = lane < acc.n_faces ? acc.face_bits[my_slot] : 0xffffffffu;
       uint32_t thr = 0xffffffffu, um = wave_or_u32(mb);
       while (um) {
         const int f = __builtin_ctz(um);
@@ -379,7 +383,9 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
           const int f = __builtin_ctz(um);
           um &= um - 1u;
           const uint32_t v = wave_max_u32(((mbm >> f) & 1u) ? __float_as_uint(best) : 0u);
-          if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[s * (int64_t)acc.n_faces + f], v);
+          // (no atomic for a value that cannot raise the maximum: most deliveries of a shared face are such)
+          const uint32_t seen = (uint32_t)__builtin_amdgcn_readlane((int)fb_seen, f);
+          if (lane == 0 && v > seen) atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
         }
       }
       done = done || focus;
@@ -436,14 +442,15 @@ int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, co
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                              const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
                              uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
-                             const uint32_t* memb, int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream) {
+                             const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
+                             uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !flag_list || !flag_count || !ctl || !top || !top_list || !d2_scratch ||
       !memb || !face_bits || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 1 || n_faces < 1 || n_faces > 32)
     return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<FinishOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, flag_list,
-                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces, nullptr, nullptr, nullptr},
+                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces, nullptr, nullptr, nullptr, face_slot},
                                 reinterpret_cast<unsigned long long*>(top), top_list, probed,
                                 reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
 }

@@ -651,6 +651,10 @@ int flooder_set_option(const char* name, int value) {
     g_cell_super_weight = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_super_min_chunks") == 0 && value >= 0) {
+    g_cell_super_min_chunks = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_super_sparse") == 0 && value >= 0) {
     g_cell_super_sparse = value;
     return FLOODER_OK;

@@ -220,7 +220,9 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * Cell sweep fused with the per-face maxima (core.py:251-276 folded into the sweep): as flooder_sweep_cell_f32 over
  * all R rows, but every sample whose nearest neighbour is settled raises face_bits[s * n_faces + f] (integer
  * atomic max on the d2 bits; zeroed by the caller) for each face f whose bit is set in memb[r] (n_faces <= 32;
- * random mode: one face, every memb word = 1).  The (S, R) buffer becomes scratch: only the tiles appended to
+ * random mode: one face, every memb word = 1).  face_slot (NULL, or n_simplices x n_faces int32): the word of
+ * face_bits that face f of simplex s uses, face_slot[s * n_faces + f], so that a triangle / edge / vertex shared by
+ * several simplices (its samples are bit-identical from each) has ONE running maximum.  The (S, R) buffer becomes scratch: only the tiles appended to
  * flag_list are written (bit 31 of a word = that sample is already settled), the other cells stay undefined.
  * top / top_list / top_count (all NULL, or n_simplices zeroed uint64 / n_simplices int32 / one zeroed int32): the
  * probe of the finish folded into the sweep - every flagged tile gets one greedy tree descent for its open samples
@@ -239,8 +241,9 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
-                                 int n_faces, uint32_t* face_bits, int32_t* flag_list, int32_t* flag_count,
-                                 uint64_t* top, int32_t* top_list, int32_t* top_count, int32_t* defer_list,
+                                 int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
+                                 int32_t* flag_count, uint64_t* top, int32_t* top_list, int32_t* top_count,
+                                 int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream);
 
@@ -260,7 +263,8 @@ int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, co
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                              const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
                              uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
-                             const uint32_t* memb, int n_faces, uint32_t* face_bits, uint64_t* stats, void* stream);
+                             const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
+                             uint64_t* stats, void* stream);
 
 /* out_face[i] = sqrt(float(face_bits[i])), i < n: the filtration values (core.py:257, 272: distances, not squares). */
 int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_face, void* stream);
