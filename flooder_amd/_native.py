@@ -61,6 +61,10 @@ SIGNATURES = {
                                        c_int, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
+    "flooder_gather_rows_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "flooder_sweep_bvh_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                      c_void_p, c_void_p, c_void_p]),
+    "flooder_face_max_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_fps_bucket_count": (c_int64, [c_int64]),
     "flooder_fps_indexed_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -677,6 +677,43 @@ class SamplePlan:
             self.cface_rows = torch.as_tensor(np.concatenate(cf_rows).astype(np.int32), device=dev)
 
 
+def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: torch.Tensor, weights: torch.Tensor,
+                         faces: _FaceTable, reduce_hook: Optional[Callable[[torch.Tensor], None]],
+                         want_dist: bool = False, timer: Optional[_KernelTimer] = None):
+    """float64 inputs (the reference instantiates its kernels with DTYPE = fp64, triton_kernels.py:226-229): tree
+    sweep in double over the float32 box tree of the cloud -> [reduce_hook on the (S, R) int64 bit patterns] ->
+    face maxima + sqrt in double.  Returns (S, F) float64."""
+    lib = _native.load()
+    dev = index.pts.device
+    st = _native.current_stream_ptr(dev)
+    S, k1, _ = verts.shape
+    R = weights.shape[0]
+    verts = verts.to(torch.float64).contiguous()
+    order = torch.as_tensor(sample_order(weights), device=dev)
+    w_perm = weights.to(torch.float64)[order].contiguous()
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(R, device=dev)
+    rows_perm = inv[faces.rows.long()].to(torch.int32).contiguous()
+    d2 = torch.empty((S, R), dtype=torch.int64, device=dev)
+    queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    with _span(timer, "sweep"):
+        _native.check(lib.flooder_sweep_bvh_f64(_native.ptr(pts64_sorted), index.n, index.dim, _native.ptr(index.nodes),
+                                                _native.ptr(verts), _native.ptr(w_perm), k1, R, S, _native.ptr(queue),
+                                                _native.ptr(d2), st), "flooder_sweep_bvh_f64")
+    if reduce_hook is not None:
+        with _span(timer, "reduce"):
+            reduce_hook(d2)
+    out_face = torch.empty((S, faces.n_faces), dtype=torch.float64, device=dev)
+    out_dist = torch.empty((S, R), dtype=torch.float64, device=dev) if want_dist else None
+    with _span(timer, "face_max"):
+        _native.check(lib.flooder_face_max_f64(_native.ptr(d2), S, R, _native.ptr(faces.ptr), _native.ptr(rows_perm),
+                                               faces.n_faces, _native.ptr(out_face), _native.ptr(out_dist), st),
+                      "flooder_face_max_f64")
+    if out_dist is not None:
+        out_dist = out_dist[:, inv]
+    return out_face, out_dist
+
+
 def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                          reduce_hook: Optional[Callable[[torch.Tensor], None]],
                          want_dist: bool = False, timer: Optional[_KernelTimer] = None,
@@ -954,8 +991,10 @@ def flood_complex(
     if dtype not in SUPPORTED_DTYPES:
         raise TypeError(f"dtype ({dtype}) not supported")
     if dtype is torch.float64:
-        warnings.warn("float64 inputs: the HIP kernels compute in float32 (inputs are rounded once); "
-                      "the CPU path keeps float64", RuntimeWarning, stacklevel=2)
+        # (the reference warns about float64 as well, core.py:118-123: its kernels then run in double, as here)
+        warnings.warn("float64 inputs: the device sweep runs its float64 kernel (tree sweep in double, several "
+                      "times slower than the float32 path); pass float32 tensors for speed", RuntimeWarning,
+                      stacklevel=2)
     if device.type not in ("cuda", "cpu"):
         raise RuntimeError("Device not supported.")
     dim = points.shape[1]
@@ -972,10 +1011,19 @@ def flood_complex(
         kdtree = KDTree(np.asarray(points))
 
     index = None
+    use_f64 = on_gpu and dtype is torch.float64 and method != "ball"
+    pts64_sorted = None
     if on_gpu and method != "ball":
         # the curve sort + box tree run on the GPU while the host triangulates the landmarks
         pts32 = points.to(torch.float32)
         index = shared_index if shared_index is not None else PointIndex(pts32)
+        if use_f64:  # the float64 rows in the order of the (float32) index
+            lib_ = _native.load()
+            pts64_sorted = torch.empty((index.pts.shape[0], index.dp), dtype=torch.float64, device=device)
+            _native.check(lib_.flooder_gather_rows_f64(_native.ptr(points.contiguous()), index.n, dim, dim,
+                                                       _native.ptr(index.order32), _native.ptr(pts64_sorted),
+                                                       index.pts.shape[0], _native.current_stream_ptr(device)),
+                          "flooder_gather_rows_f64")
     stree, simplices = _build_complex(landmarks, max_dimension)
     LAST_STATS.reset()
     LAST_STATS.n_points = points.shape[0]
@@ -995,7 +1043,7 @@ def flood_complex(
         if method == "ball":  # the reference's formulation: cloud sorted along the widest axis (core.py:140-144)
             pts_pad = _pad_rows(pts32[torch.argsort(pts32[:, axis])], dp)
             search = pts_pad[:, axis].contiguous()
-    lm_np = landmarks.detach().to(torch.float32 if on_gpu else dtype).cpu().numpy()
+    lm_np = landmarks.detach().to(torch.float64 if use_f64 else (torch.float32 if on_gpu else dtype)).cpu().numpy()
 
     results: List[tuple] = []  # (simplices (n,k), values (n,)) or indexed cell-face assignments, in update order
     for d in range(max_dimension + 1):
@@ -1025,11 +1073,14 @@ def flood_complex(
             order_np = splx_idx.cpu().numpy()
             simp_h = simplices[d][order_np]
 
+        w_dtype = torch.float64 if use_f64 else (torch.float32 if on_gpu else dtype)
         if num_rand is None:
             weights, vertex_idxs, face_idxs, faces, plan, v_idx_np = _grid_tables(
-                points_per_edge, max_dimension, device, torch.float32 if on_gpu else dtype)
+                points_per_edge, max_dimension, device, w_dtype)
+            if use_f64:
+                plan = None
         else:
-            weights = generate_uniform_weights(num_rand, d, device, torch.float32 if on_gpu else dtype)
+            weights = generate_uniform_weights(num_rand, d, device, w_dtype)
             vertex_idxs = face_idxs = v_idx_np = None
             faces = _FaceTable(None, weights.shape[0], device)
         LAST_STATS.top_simplices = num_simplices
@@ -1047,6 +1098,9 @@ def flood_complex(
                                                    centers if mine is None else centers[mine],
                                                    radii if mine is None else radii[mine], weights, faces,
                                                    reduce_hook)
+            elif use_f64:
+                slots = None
+                face_dev, _ = _sweep_dimension_f64(index, pts64_sorted, sv, weights, faces, reduce_hook)
             elif method == "cell":
                 slots = None
                 if (SHARED_FACE_SLOTS and FUSED_FACES and num_rand is None and mine is None and reduce_hook is None

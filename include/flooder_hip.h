@@ -313,6 +313,24 @@ int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms,
                     int64_t* out_idx, float* work_min, uint64_t* work_best, void* stream);
 
 /*
+ * ---- float64 sweep -------------------------------------------------------------------------------------------------
+ * The reference's kernels are instantiated with DTYPE = fp64 for float64 inputs (triton_kernels.py:226-229).  Here:
+ * the box tree of the float32-rounded cloud (flooder_bvh_build_f32) with the float64 rows gathered in the same order;
+ * boxes are widened by one float32 ulp per side inside the kernel and every bound and distance is evaluated in double.
+ *   flooder_gather_rows_f64: as flooder_gather_rows_f32 for double rows (padding rows +inf, padding columns 0);
+ *   flooder_sweep_bvh_f64:   out_d2[s, r] = bit pattern of the double min over all points of |p(s, r) - x|^2
+ *                            (non-negative doubles order like unsigned 64-bit integers); queue: one zeroed int32;
+ *   flooder_face_max_f64:    face maxima + sqrt in double (layout as flooder_face_max_f32).
+ */
+int flooder_gather_rows_f64(const double* pts, int64_t n_pts, int dim, int ld, const int32_t* order, double* out,
+                            int64_t n_pad, void* stream);
+int flooder_sweep_bvh_f64(const double* pts_sorted, int64_t n_pts, int dim, const float* nodes, const double* verts,
+                          const double* weights, int k1, int R, int64_t n_simplices, int32_t* queue,
+                          uint64_t* out_d2, void* stream);
+int flooder_face_max_f64(const uint64_t* d2, int64_t n_simplices, int R, const int32_t* face_ptr,
+                         const int32_t* face_rows, int n_faces, double* out_face, double* out_dist, void* stream);
+
+/*
  * Bucketed exact farthest-point sampling (dim <= 3) over the curve-sorted copy of the cloud that the sweeps use.
  * Replaces fpsample.bucket_fps_kdline_sampling (flooder/core.py:337-343: exact FPS accelerated by kd-tree buckets):
  * buckets of 64 or 256 consecutive sorted rows carry a bounding box and their largest running minimum; a new

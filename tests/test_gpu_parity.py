@@ -187,12 +187,42 @@ def test_workspace_grouping_is_invisible(dev, monkeypatch):
     assert a == b
 
 
-def test_float64_input_gpu(dev):
-    z, kw, keys = load_e2e("torus3d_grid")
+@pytest.mark.parametrize("name", ["torus3d_grid", "eight2d_rand", "gauss6d_maxdim2", "cheese3d_grid"])
+def test_float64_input_gpu(dev, name):
+    """float64 tensors run the float64 device kernels (the reference instantiates its Triton kernels with
+    DTYPE = fp64): values match the reference's float64 CPU result to double precision, not just to float32."""
+    z, kw, keys = load_e2e(name)
+    torch.manual_seed(int(z["weight_seed"]))
     with pytest.warns(RuntimeWarning):
         fc = fa.flood_complex(torch.as_tensor(z["points"], device=dev).double(),
                               torch.as_tensor(z["landmarks"], device=dev).double(), **kw)
-    assert_close_filtration(dict_values(fc, keys), z["filtration_f64"], z["points"], "f64 input")
+    got, ref = dict_values(fc, keys), z["filtration_f64"]
+    if kw.get("num_rand"):
+        # random weights go through a float32 log on the HOST (core.py:425): its last bit depends on the host's
+        # vector unit, so the float64 golden of another machine is only float32-accurate here - the reference CPU
+        # algorithm (kd-tree, float64) is re-run on this host with the same seed instead
+        assert np.abs(got - ref).max() < 1e-6
+        torch.manual_seed(int(z["weight_seed"]))
+        with pytest.warns(RuntimeWarning):
+            cpu = fa.flood_complex(torch.as_tensor(z["points"]).double(), torch.as_tensor(z["landmarks"]).double(), **kw)
+        ref = dict_values(cpu, keys)
+    assert set(keys) == set(fc)
+    scale = float(np.abs(z["points"]).max())
+    assert np.abs(got - ref).max() <= 1e-12 * scale + 1e-11 * np.abs(ref).max(), np.abs(got - ref).max()
+
+
+def test_float32_and_float64_device_results_agree(dev):
+    """The reference's precision test (tests/test_flooder.py:214-246): float32 and float64 runs within 3e-6."""
+    pts = fo.noisy_torus(20_000, seed=42)
+    lms = pts[fo.exact_fps(pts, 300, 0)]
+    for kw in (dict(points_per_edge=20), dict(points_per_edge=None, num_rand=512)):
+        torch.manual_seed(42)
+        a = fa.flood_complex(torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev), **kw)
+        torch.manual_seed(42)
+        with pytest.warns(RuntimeWarning):
+            b = fa.flood_complex(torch.as_tensor(pts, device=dev).double(), torch.as_tensor(lms, device=dev).double(), **kw)
+        assert set(a) == set(b)
+        assert max(abs(a[k] - b[k]) for k in a) < 3e-6
 
 
 def test_shard_min_reduce_equals_unsharded(dev):
