@@ -41,22 +41,28 @@ for k, ns in avg_ns.items():
 json.dump(out, open(f"profiles/{name}_pmc.json", "w"), indent=1)
 traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
 sha = kernel_source_sha()
-for kern, method, span in (("cell_sweep_kernel<3>", "cell", "sweep"), ("finish_faces_kernel<3>", "cell", "fallback"),
-                           ("sweep_bvh_kernel<3, 2, 1>", "bvh", "sweep"), ("sweep_kernel<3, true>", "ball", "sweep")):
-    if kern in out and "FETCH_SIZE_mean_per_launch" in out[kern]:
-        f, w = out[kern]["FETCH_SIZE_mean_per_launch"], out[kern].get("WRITE_SIZE_mean_per_launch", 0.0)
-        per_step = 2 if span == "fallback" else 1      # the finish runs two passes (launches) per step
-        ent = {"kernel": kern, "fetch_size_kb": f, "write_size_kb": w, "fetch_correction": 2.0,
-               "launches_per_step": per_step,
-               "bytes_per_launch": int((2.0 * f + w) * 1024) * per_step, "source": f"profiles/{name}_pmc.json",
-               "kernel_src_sha": sha}
-        us = out[kern].get("avg_duration_us_kernel_trace")
-        valu = out[kern].get("SQ_INSTS_VALU_mean_per_launch")
-        if us and valu:
-            ent["issue_util"] = round(valu * 2.0 / (1024 * us * 1e-6 * 2.4e9), 4)
-            ent["valu_wave_instructions"] = valu
-            ent["issue_util_note"] = "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz)"
-        traffic[f"{tag}:{method}:{span}"] = ent
+# span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
+SPANS = (("cell", "sweep", ("cell_sweep_kernel<3, true>", "cell_sweep_kernel<3, false>"), 1),
+         ("cell", "fallback", ("finish_faces_kernel<3>",), 2),     # two passes (launches) per step
+         ("bvh", "sweep", ("sweep_bvh_kernel<3, 2, 1>",), 1), ("ball", "sweep", ("sweep_kernel<3, true>",), 1))
+for method, span, kerns, per_step in SPANS:
+    have = [k for k in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
+    if not have:
+        continue
+    f = sum(out[k]["FETCH_SIZE_mean_per_launch"] for k in have) * per_step
+    w = sum(out[k].get("WRITE_SIZE_mean_per_launch", 0.0) for k in have) * per_step
+    ent = {"kernels": have, "launches_per_step": per_step * len(have), "fetch_size_kb": round(f, 1),
+           "write_size_kb": round(w, 1), "fetch_correction": 2.0, "bytes_per_launch": int((2.0 * f + w) * 1024),
+           "bytes_note": "HBM bytes per step of this span: sum over its launches of 2 x FETCH_SIZE + WRITE_SIZE",
+           "source": f"profiles/{name}_pmc.json", "kernel_src_sha": sha}
+    us = sum(out[k].get("avg_duration_us_kernel_trace", 0.0) for k in have) * per_step
+    valu = sum(out[k].get("SQ_INSTS_VALU_mean_per_launch", 0.0) for k in have) * per_step
+    if us and valu:
+        ent["issue_util"] = round(valu * 2.0 / (1024 * us * 1e-6 * 2.4e9), 4)
+        ent["valu_wave_instructions"] = valu
+        ent["duration_us_kernel_trace"] = round(us, 1)
+        ent["issue_util_note"] = "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x duration x 2.4 GHz)"
+    traffic[f"{tag}:{method}:{span}"] = ent
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 bench = f"{src}/bench_trace.json"
 if os.path.exists(bench):
