@@ -592,89 +592,31 @@ def _sample_order_bisect(w: np.ndarray) -> np.ndarray:
     return np.concatenate(out)
 
 
-# Max-only pruning (flooder_prune_rows_f32) is OFF by default: at cfg 2 it cuts the samples swept to 27 %
-# (23 % coarse + 4.6 % of the fine rows) but the survivors are scattered, the cell sweep's per-chunk staging
-# cost then dominates, and the step gets slower (6.4 ms vs 3.7 ms; profiles/r1_prune_experiment.json).
-PRUNE_DEFAULT = False
-PRUNE_MIN_ROWS = 1024     # sample tables smaller than this are swept whole
-PRUNE_STRIDE = 8          # every 8th sample (in the sample order of the weights) is swept first ("coarse" rows)
-PRUNE_FACE_STRIDE = 3     # ... and every 3rd sample of each lower-dimensional face, and every vertex
-PRUNE_KNN = 6
-PRUNE_MAX_COARSE = 1536
-
-
 class SamplePlan:
-    """Device-resident sample weights in sweep order plus the face table remapped to that order
-    (built once per dimension pass; independent of the simplices).
+    """Device-resident sample weights in sweep order (``sample_order``) plus the face table remapped to that order
+    and, per row, the bit mask of the faces it lies on (the fused face maxima); built once per dimension pass,
+    independent of the simplices."""
 
-    With ``prune=True`` (and enough rows) the order is: coarse rows first - a uniform subset that is swept
-    exactly - then the fine rows; ``knn`` (fine row -> nearby coarse rows in weight space), ``memb`` (row ->
-    bit mask of the faces it lies on) and the per-face coarse-row lists feed ``flooder_prune_rows_f32``."""
-
-    def __init__(self, weights: torch.Tensor, faces: _FaceTable, prune: Optional[bool] = None):
-        prune = PRUNE_DEFAULT if prune is None else prune
+    def __init__(self, weights: torch.Tensor, faces: _FaceTable):
         dev = weights.device
         self.R, self.k1 = weights.shape
         R = self.R
-        w_h = weights.detach().cpu().numpy().astype(np.float64)
-        morton = sample_order(weights)                    # positions -> original rows, spatially coherent
+        perm = sample_order(weights)                      # positions -> original rows, spatially coherent
         f_ptr = faces.ptr.cpu().numpy().astype(np.int64)
         f_rows = faces.rows.cpu().numpy().astype(np.int64)
         n_faces = faces.n_faces
-        self.prune = bool(prune) and R >= PRUNE_MIN_ROWS and n_faces <= 32 and self.k1 >= 2
-        if self.prune:
-            rank = np.empty(R, dtype=np.int64)
-            rank[morton] = np.arange(R)
-            coarse = np.zeros(R, dtype=bool)
-            coarse[morton[::PRUNE_STRIDE]] = True
-            for f in range(n_faces):
-                rows = f_rows[f_ptr[f]:f_ptr[f + 1]]
-                if len(rows) < R:                          # a proper face: denser coarse subset along it
-                    rows = rows[np.argsort(rank[rows])]
-                    coarse[rows[::PRUNE_FACE_STRIDE]] = True
-                    coarse[rows[-1]] = True
-            self.prune = int(coarse.sum()) <= PRUNE_MAX_COARSE and int(coarse.sum()) < R
-        if self.prune:
-            c_rows = morton[coarse[morton]]                # coarse rows, Morton order
-            f_rows_fine = morton[~coarse[morton]]          # fine rows, Morton order
-            perm = np.concatenate([c_rows, f_rows_fine])
-            self.Rc = int(len(c_rows))
-        else:
-            perm = morton
-            self.Rc = R
         inv = np.empty(R, dtype=np.int64)
         inv[perm] = np.arange(R)
         self.inv = torch.as_tensor(inv, device=dev)
         self.w_perm = weights.to(torch.float32)[torch.as_tensor(perm, device=dev)].contiguous()
         self.rows_perm = self.inv[faces.rows.long()].to(torch.int32).contiguous()
         self.faces = faces
-        # row (in sweep order) -> bit mask of the faces it lies on: the fused face maxima of the cell sweep
         self.memb_all = None
         if n_faces <= 32:
             memb_all = np.zeros(R, dtype=np.uint32)
             for f in range(n_faces):
                 memb_all[inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]] |= np.uint32(1 << f)
             self.memb_all = torch.as_tensor(memb_all.view(np.int32), device=dev)
-        if self.prune:
-            from scipy.spatial import cKDTree
-
-            Rc = self.Rc
-            wc = w_h[perm[:Rc]]
-            K = min(PRUNE_KNN, Rc)
-            _, nn = cKDTree(wc).query(w_h[perm[Rc:]], k=K)
-            self.K = K
-            self.knn = torch.as_tensor(np.ascontiguousarray(nn.reshape(R - Rc, K)).astype(np.int32), device=dev)
-            memb = np.zeros(R, dtype=np.uint32)
-            cf_ptr, cf_rows = [0], []
-            for f in range(n_faces):
-                pos = inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]
-                memb[pos] |= np.uint32(1 << f)
-                cpos = pos[pos < Rc]
-                cf_rows.append(cpos)
-                cf_ptr.append(cf_ptr[-1] + len(cpos))
-            self.memb = torch.as_tensor(memb.view(np.int32), device=dev)
-            self.cface_ptr = torch.as_tensor(np.array(cf_ptr, dtype=np.int32), device=dev)
-            self.cface_rows = torch.as_tensor(np.concatenate(cf_rows).astype(np.int32), device=dev)
 
 
 def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: torch.Tensor, weights: torch.Tensor,
@@ -770,19 +712,18 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                           want_dist: bool = False, timer: Optional[_KernelTimer] = None,
                           stats: Optional[torch.Tensor] = None, plan: Optional[SamplePlan] = None,
                           face_slots: Optional[Tuple[torch.Tensor, int]] = None):
-    """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree sweep of the unverified tiles
-    -> [reduce_hook] -> face max.  No host synchronisation.
+    """Cell sweep (dim 2 / 3): wave-local LDS cell-grid sweep -> exact tree finish of the unverified tiles
+    -> [reduce_hook] -> face maxima.  No host synchronisation.
 
-    When the plan allows pruning (and neither the per-sample minima are wanted nor a cross-shard reduction
-    of them is pending) the sweep runs in two rounds: the coarse rows exactly, then - after
-    ``flooder_prune_rows_f32`` - only the fine rows that can still raise a face maximum.  Rows that are
-    dropped keep a zero in the d2 buffer; the per-face maxima are unchanged.
+    Default (only the face maxima are wanted): the fused path - ``flooder_sweep_cell_faces_f32``,
+    ``flooder_finish_faces_f32``, ``flooder_face_values_f32``.  With ``want_dist`` or a ``reduce_hook`` (the
+    per-sample minima are needed): ``flooder_sweep_cell_f32`` -> ``flooder_sweep_bvh_items_f32`` over the full
+    (S, R) buffer -> ``flooder_face_max_f32``.
 
     ``stats`` (optional, 16 zeroed int64): [0:9] cell sweep {pairs, points staged, tiles flagged,
-    re-staging rounds, 4 give-up reasons, exhaustive rounds}, [9:13] finishing tree sweep {leaves
-    evaluated, leaves tested, nodes expanded, most tests by one tile}, [13] fine rows swept after pruning,
-    [14] fine rows in total (both 0 when pruning is off); on the fused path [13] = tiles the last finish pass
-    dropped on arrival, [14] = samples still live on arrival in that pass.
+    re-staging rounds, 4 give-up reasons, exhaustive rounds}, [9:13] finish {leaves evaluated, leaves tested,
+    nodes expanded, -}, fused path: [13] tiles the last finish pass dropped on arrival, [14] samples still live
+    on arrival in that pass, [15] focus rounds.
 
     ``face_slots`` = (slot (S, F) int32, n_slots), fused path only: face f of simplex s accumulates into word
     ``slot[s, f]`` and the result is the (n_slots,) vector of per-slot values instead of the (S, F) matrix -
@@ -797,7 +738,6 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     verts = verts.to(torch.float32).contiguous()
     plan = plan if plan is not None else SamplePlan(weights, faces)
     w_perm, rows_perm = plan.w_perm, plan.rows_perm
-    prune = plan.prune and not want_dist and reduce_hook is None
 
     def sub(a, b):
         return None if stats is None else stats[a:b]
@@ -805,7 +745,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     if S == 0:
         return (torch.empty((0, faces.n_faces), dtype=torch.float32, device=dev),
                 torch.empty((0, R), dtype=torch.float32, device=dev) if want_dist else None)
-    if FUSED_FACES and not prune and not want_dist and reduce_hook is None and plan.memb_all is not None:
+    if FUSED_FACES and not want_dist and reduce_hook is None and plan.memb_all is not None:
         # ---- only the per-face maxima are wanted: fused path.  The cell sweep delivers every settled sample to
         # face_bits (integer atomic max), the finish drops what cannot raise a face maximum, the (S, R) buffer is
         # scratch that only the flagged tiles touch.
@@ -852,44 +792,19 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                           "flooder_face_values_f32")
         return out_face, None
 
-    ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # work-queue heads + flag counters
-
-    def sweep_rows(n_rows, row_list, row_cnt, stride, c0, label):
-        """cell sweep + exact finish of rows [0, n_rows) or of the listed rows; ctl[c0:c0+3] scratch"""
-        slots = stride if row_list is not None else n_rows
-        flags = torch.empty(S * ((slots + 63) // 64), dtype=torch.int32, device=dev)
-        with _span(timer, "sweep" + label):
-            _native.check(lib.flooder_sweep_cell_f32(
-                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, n_rows, S, float(CELL_ALPHA), ctl[c0:].data_ptr(), _native.ptr(d2), R,
-                _native.ptr(row_list), _native.ptr(row_cnt), stride, _native.ptr(flags),
-                ctl[c0 + 1:].data_ptr(), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
-        with _span(timer, "fallback" + label):
-            _native.check(lib.flooder_sweep_bvh_items_f32(
-                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, n_rows, S, _native.ptr(flags), ctl[c0 + 1:].data_ptr(),
-                ctl[c0 + 2:].data_ptr(), _native.ptr(d2), R, _native.ptr(row_list), _native.ptr(row_cnt), stride,
-                0, None, None, _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
-
-    if not prune:
-        d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
-        sweep_rows(R, None, None, 0, 0, "")
-    else:
-        Rc, Rf = plan.Rc, R - plan.Rc
-        d2 = torch.zeros((S, R), dtype=torch.int32, device=dev)  # dropped rows stay 0: they never win a max
-        sweep_rows(Rc, None, None, 0, 0, "_coarse")
-        row_list = torch.empty((S, Rf), dtype=torch.int32, device=dev)
-        row_cnt = torch.empty(S, dtype=torch.int32, device=dev)
-        with _span(timer, "prune"):
-            _native.check(lib.flooder_prune_rows_f32(
-                _native.ptr(d2), R, index.dim, _native.ptr(verts), _native.ptr(w_perm), k1, R, Rc,
-                _native.ptr(plan.knn), plan.K, _native.ptr(plan.memb), _native.ptr(plan.cface_ptr),
-                _native.ptr(plan.cface_rows), faces.n_faces, S, _native.ptr(row_list), _native.ptr(row_cnt), Rf, st),
-                "flooder_prune_rows_f32")
-        sweep_rows(R, row_list, row_cnt, Rf, 3, "")
-        if stats is not None:
-            stats[13] = row_cnt.sum()
-            stats[14] = S * Rf
+    ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # work-queue heads + flag counter
+    d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
+    flags = torch.empty(S * ((R + 63) // 64), dtype=torch.int32, device=dev)
+    with _span(timer, "sweep"):
+        _native.check(lib.flooder_sweep_cell_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2), _native.ptr(flags),
+            ctl[1:].data_ptr(), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
+    with _span(timer, "fallback"):
+        _native.check(lib.flooder_sweep_bvh_items_f32(
+            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+            _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[2:].data_ptr(),
+            _native.ptr(d2), 0, None, None, _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
 
     if reduce_hook is not None:
         with _span(timer, "reduce"):

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     int64_t n_simplices, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     unsigned long long* __restrict__ stats, const int32_t* __restrict__ item_list,
     const int32_t* __restrict__ n_list, int seed, int subs_max, int budget, int refine_pct,
-    int32_t* __restrict__ list2, int32_t* __restrict__ count2, RowSel sel) {
+    int32_t* __restrict__ list2, int32_t* __restrict__ count2) {
   // budget > 0 (work-list mode): a wave abandons a tile after `budget` box tests, stores the minima it has
   // (valid upper bounds) and appends the tile to list2; a second pass finishes those tiles split over
   // many more waves.  Bounds the tail caused by tiles near the medial axis of the cloud.
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   __shared__ float s_stage[LB > 1 ? 4 : 1][LB > 1 ? LB * LEAF : 1][DP];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
+  const int n_slots = R;  // sample slots per simplex
   const int tiles = (n_slots + 64 * KSV - 1) / (64 * KSV);
   // few flagged tiles: split each over up to subs_max waves (short tail); many: keep lanes distinct
   int subs = 1;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     const unsigned long long tests_before = n_leaf_test + n_node_test;
     const int64_t s = g / tiles;
     const int tile = (int)(g - s * tiles);
-    const int n_live = sel.list ? sel.cnt[s] : R;
+    const int n_live = R;
     if (tile * 64 * KSV >= n_live) continue;
 
     // ---- this lane's KSV samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188)
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
     for (int i = 0; i < KSV; ++i) {
       int slot = tile * 64 * KSV + i * 64 + slane;
       if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
-      const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
+      const int r = slot;
       row[i] = r;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
       }
       // seed: start from the minima already in out_d2 (upper bounds found by an earlier pass)
-      best[i] = seed ? __uint_as_float(out_d2[s * (int64_t)sel.ld_out + r]) : __builtin_inff();
+      best[i] = seed ? __uint_as_float(out_d2[s * (int64_t)R + r]) : __builtin_inff();
     }
     // ---- bounding box of the tile (wave-uniform)
     float tlo[DIM], thi[DIM];
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 #pragma unroll
     for (int i = 0; i < KSV; ++i) {
       if (tile * 64 * KSV + i * 64 + slane < n_live && lane < per_sub)
-        out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
+        out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]);
     }
     if (abandoned && sub == 0 && lane == 0) {  // (budgeted passes run with subs = 1)
       const int pos = atomicAdd(count2, 1);
@@ -689,8 +689,7 @@ struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
                  unsigned long long* stats, const int32_t* item_list, const int32_t* n_list, int seed,
-                 int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, RowSel sel,
-                 hipStream_t st) {
+                 int force_ks, int subs_max, int budget, int32_t* list2, int32_t* count2, hipStream_t st) {
     const int grid = g_bvh_grid;  // persistent blocks; 4 independent waves each
     int ks = force_ks ? force_ks : g_bvh_ks;
     if (ks == 0) ks = R <= 64 ? 1 : 2;  // (measured at cfg 2: 1: 10.7 ms, 2: 10.1, 4: 10.3, 8: 12.1)
@@ -700,7 +699,7 @@ struct SweepBvhOp {
     const bool batch = item_list != nullptr && ks == 1 && g_bvh_leaf_batch > 1;
 #define FLOODER_LAUNCH_BVH(KS_, LB_)                                                                              \
   hipLaunchKernelGGL((sweep_bvh_kernel<DIM, KS_, LB_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, \
-                     k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, refine_pct, list2, count2, sel)
+                     k1, R, ns, queue, out, stats, item_list, n_list, seed, subs_max, budget, refine_pct, list2, count2)
     if (batch) FLOODER_LAUNCH_BVH(1, 4);
     else if (ks == 1) FLOODER_LAUNCH_BVH(1, 1);
     else if (ks == 2) FLOODER_LAUNCH_BVH(2, 1);
@@ -772,27 +771,24 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), nullptr, nullptr, 0, 0, 1,
-                                  0, nullptr, nullptr, RowSel{nullptr, nullptr, 0, R}, (hipStream_t)stream);
+                                  0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                 const float* verts, const float* weights, int k1, int R,
                                 int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
-                                int32_t* queue, uint32_t* out_d2, int ld_out, const int32_t* row_list,
-                                const int32_t* row_cnt, int list_stride, int budget, int32_t* list2,
+                                int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
                                 int32_t* count2, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !item_list || !n_items ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || budget < 0 || ld_out < 1 ||
-      (budget > 0 && (!list2 || !count2)) || (row_list && (!row_cnt || list_stride < 1)))
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || budget < 0 || (budget > 0 && (!list2 || !count2)))
     return fail(FLOODER_E_ARG, "flooder_sweep_bvh_items_f32: bad argument");
-  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
   const Levels lv = make_levels(n_pts);
   // a budgeted pass keeps 64 distinct samples per wave; the unbudgeted pass may split tiles
   const int subs = budget > 0 ? 1 : g_bvh_subs;
   return dispatch_dim<SweepBvhOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, queue,
                                   out_d2, reinterpret_cast<unsigned long long*>(stats), item_list, n_items, 1,
-                                  1, subs, budget, list2, count2, sel, (hipStream_t)stream);
+                                  1, subs, budget, list2, count2, (hipStream_t)stream);
 }
 
 int flooder_selftest(const float* in64, float* out128, void* stream) {

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats, RowSel sel, FaceAcc acc, DeferList dl) {
+    unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl) {
   constexpr int DP = padded_dim(DIM);
   constexpr int GS = SUPER ? 4 : 1;  // chunks per work item
   constexpr int G = CellCfg<DIM>::G;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     return (int)((atomicAdd(&s_cell32[i >> 1], 1u << sh) >> sh) & 0xffffu);
   };
   const int top = lv.n_levels - 1;
-  const int n_slots = sel.list ? sel.stride : R;  // sample slots per simplex
+  const int n_slots = R;  // sample slots per simplex
   const int chunks = (n_slots + CHUNK - 1) / CHUNK;
   const int tiles64 = (n_slots + 63) >> 6;
   const int supers = (chunks + GS - 1) / GS;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     }
     const int q_first = q;
     const float* vs = verts + s * (int64_t)k1 * DIM;
-    const int n_live = sel.list ? sel.cnt[s] : R;  // live slots of this simplex (wave-uniform)
+    const int n_live = R;  // live slots of this simplex
     if (q * CHUNK >= n_live) continue;
     auto defer = [&](int qq, int seeded_flag, float c_next) {
       if (lane == 0) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
         int slot = q * CHUNK + i * 64 + lane;
         open[i] = slot < n_live;
         if (slot >= n_live) slot = n_live - 1;  // duplicate of the last live sample, never stored
-        const int r = sel.list ? sel.list[s * (int64_t)sel.stride + slot] : slot;
+        const int r = slot;
         row[i] = r;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       const float c_ok_prev = (0.999f * c_prev) * (0.999f * c_prev);
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
-        const uint32_t w = out_d2[s * (int64_t)sel.ld_out + row[i]];
+        const uint32_t w = out_d2[s * (int64_t)R + row[i]];
         best[i] = __uint_as_float(w & ~SETTLED_BIT);
         open[i] = open[i] && !(best[i] <= c_ok_prev);
       }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
       for (int i = 0; i < SPL; ++i) {
         if (seed_mode) {
           if (q * CHUNK + i * 64 + lane < n_live)
-            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
+            out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
         } else if (__ballot(open[i]) != 0ull) {
           if (acc.top) {
             // probe: one greedy descent of the box tree for the tile's open samples (nearest child box at every
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
             }
           }
           if (q * CHUNK + i * 64 + lane < n_live)
-            out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
+            out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
           if (lane == 0) {
             const int pos = atomicAdd(flag_count, 1);
             flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void cell_sweep_kernel(
     } else {
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
-        if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)sel.ld_out + row[i]] = __float_as_uint(best[i]);
+        if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]);
         if (!seed_mode && __ballot(open[i]) != 0ull) {
           if (lane == 0) {
             const int pos = atomicAdd(flag_count, 1);
@@ -1080,12 +1080,12 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 RowSel sel, FaceAcc acc, DeferList dl, int32_t* queue2, hipStream_t st) {
+                 FaceAcc acc, DeferList dl, int32_t* queue2, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
-      const int64_t n_chunks = ns * (((sel.list ? sel.stride : R) + CHUNK - 1) / CHUNK);
+      const int64_t n_chunks = ns * ((R + CHUNK - 1) / CHUNK);
       int64_t want = n_chunks / 48;
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
@@ -1096,14 +1096,14 @@ struct CellOp {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, true>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc, dl);
+                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, acc, dl);
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue2, out, flag_list, flag_count, stats, sel, acc, dl);
+                           g_cell_exh_tries, queue2, out, flag_list, flag_count, stats, acc, dl);
       } else {
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, sel, acc, dl);
+                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, acc, dl);
       }
       return check_launch("cell_sweep");
     } else {
@@ -1164,17 +1164,14 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
 
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
-                     uint32_t* out_d2, int ld_out, const int32_t* row_list, const int32_t* row_cnt, int list_stride,
-                     int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc, DeferList dl,
-                     int32_t* queue2, void* stream, const char* who) {
+                     uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
+                     DeferList dl, int32_t* queue2, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
-      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f) || ld_out < 1 ||
-      (row_list && (!row_cnt || list_stride < 1)))
+      n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
     return fail(FLOODER_E_ARG, who);
-  const RowSel sel{row_list, row_cnt, list_stride, ld_out};
   if (dim != 2 && dim != 3) return fail(FLOODER_E_ARG, "cell sweep: only dim 2 and 3");
-  if (n_simplices * (int64_t)(((row_list ? list_stride : R) + 63) / 64) > 0x7fffffffLL)
+  if (n_simplices * (int64_t)((R + 63) / 64) > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "cell sweep: too many (simplex, tile) pairs");
   const Levels lv = make_levels(n_pts);
   // the kernel addresses rows and node boxes with 32-bit byte offsets
@@ -1182,7 +1179,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
       total_nodes(lv) * (int64_t)(2 * padded_dim(dim) * sizeof(float)) >= (1LL << 32))
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
-                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), sel, acc,
+                              out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), acc,
                               dl, queue2, (hipStream_t)stream);
 }
 
@@ -1192,14 +1189,12 @@ extern "C" {
 
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                           float alpha, int32_t* queue, uint32_t* out_d2, int ld_out,
-                           const int32_t* row_list, const int32_t* row_cnt, int list_stride,
-                           int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream) {
+                           float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
+                           uint64_t* stats, void* stream) {
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
-                          ld_out, row_list, row_cnt, list_stride, flag_list, flag_count, stats,
-                          FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
-                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                          nullptr, stream, "flooder_sweep_cell_f32: bad argument");
+                          flag_list, flag_count, stats, FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
+                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, stream,
+                          "flooder_sweep_cell_f32: bad argument");
 }
 
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
@@ -1222,7 +1217,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                        defer_ctl + 2);
   }
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
-                          d2_scratch, R, nullptr, nullptr, 0, flag_list, flag_count, stats,
+                          d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot},
                           DeferList{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,

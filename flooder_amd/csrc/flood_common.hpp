@@ -168,16 +168,6 @@ struct FaceAcc {
   }
 };
 
-// Which sample rows of a simplex a sweep works on: all R rows of the weight table (list == nullptr), or
-// the first cnt[s] entries of the simplex's segment list[s*stride .. ) (rows that survived pruning).
-// ld_out = row stride of the d2 output buffer.
-struct RowSel {
-  const int32_t* list;
-  const int32_t* cnt;
-  int stride;
-  int ld_out;
-};
-
 template <template <int> class F, typename... Args>
 int dispatch_dim(int dim, Args&&... args) {
   switch (dim) {

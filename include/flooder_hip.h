@@ -193,8 +193,7 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
 int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                 const float* verts, const float* weights, int k1, int R,
                                 int64_t n_simplices, const int32_t* item_list, const int32_t* n_items,
-                                int32_t* queue, uint32_t* out_d2, int ld_out, const int32_t* row_list,
-                                const int32_t* row_cnt, int list_stride, int budget, int32_t* list2,
+                                int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
                                 int32_t* count2, uint64_t* stats, void* stream);
 
 /*
@@ -212,9 +211,8 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                           float alpha, int32_t* queue, uint32_t* out_d2, int ld_out,
-                           const int32_t* row_list, const int32_t* row_cnt, int list_stride,
-                           int32_t* flag_list, int32_t* flag_count, uint64_t* stats, void* stream);
+                           float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
+                           uint64_t* stats, void* stream);
 
 /*
  * Cell sweep fused with the per-face maxima (core.py:251-276 folded into the sweep): as flooder_sweep_cell_f32 over
@@ -275,25 +273,6 @@ int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_fac
  * as the work order (the order of the simplices never changes a value). */
 int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
                                int64_t n_simplices, float* weight, void* stream);
-
-/*
- * Row selection (both sweeps above): row_list == NULL sweeps all R rows of `weights` and writes
- * out_d2[s * ld_out + r]; otherwise simplex s sweeps only rows row_list[s * list_stride + i], i < row_cnt[s]
- * (work items and flag ids are then counted in slots of the list: ceil(list_stride / 64) tiles per simplex).
- *
- * flooder_prune_rows_f32 builds such a list.  The filtration value of a face is a MAXIMUM over samples of a
- * 1-Lipschitz function, so after an exact sweep of the first Rc ("coarse") rows - out_d2[s, 0:Rc] - a fine
- * row r >= Rc whose upper bound  min_k( d(q_k) + |p_r - p_qk| ), q_k = knn[(r-Rc)*K + k] (coarse rows near r),
- * does not exceed  min over the faces containing r (bit mask memb[r]) of the face's maximum over its coarse
- * rows (CSR cface_ptr / cface_rows)  cannot change any face maximum and is dropped.  Replaces nothing in the
- * reference (which evaluates every sample, core.py:188-226); the per-face maxima (core.py:251-276) are
- * unchanged.  row_list: n_simplices * list_stride int32 (list_stride >= R - Rc), row_cnt: n_simplices int32.
- */
-int flooder_prune_rows_f32(const uint32_t* d2, int ld_d2, int dim, const float* verts, const float* weights,
-                           int k1, int R, int Rc, const int32_t* knn, int K, const uint32_t* memb,
-                           const int32_t* cface_ptr, const int32_t* cface_rows, int n_faces,
-                           int64_t n_simplices, int32_t* row_list, int32_t* row_cnt, int list_stride,
-                           void* stream);
 
 /* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
 int flooder_selftest(const float* in64, float* out128, void* stream);

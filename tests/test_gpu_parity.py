@@ -340,24 +340,6 @@ def test_fuzz_methods_agree(dev):
         assert_close_filtration(dict_values(res["cell"], keys), dict_values(ref, keys), pts, f"case {case}")
 
 
-def test_max_only_pruning_keeps_every_face_maximum(dev, monkeypatch):
-    """Experimental two-round sweep (coarse rows, then only the rows that can still raise a face maximum):
-    the per-face values must not change by a single bit."""
-    pts = fo.noisy_torus(80_000, seed=5)
-    lms = pts[fo.exact_fps(pts, 200, 0)]
-    tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
-    a = fa.flood_complex(tp, tl, points_per_edge=20)
-    monkeypatch.setattr(core, "PRUNE_DEFAULT", True)
-    b = fa.flood_complex(tp, tl, points_per_edge=20)
-    assert a == b
-    torch.manual_seed(3)
-    c = fa.flood_complex(tp, tl, points_per_edge=None, num_rand=1500)
-    monkeypatch.setattr(core, "PRUNE_DEFAULT", False)
-    torch.manual_seed(3)
-    d = fa.flood_complex(tp, tl, points_per_edge=None, num_rand=1500)
-    assert c == d
-
-
 def test_full_size_properties_1m_gaussian(dev):
     """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
     vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""
