@@ -102,7 +102,8 @@ struct DeferList {
 // whose neighbourhood does not fit the stage, and chunks that keep open samples (they would need a larger cell
 // size, i.e. a new stage), are appended to a deferred list that a SUPER = false launch works off chunk by chunk.
 template <int DIM, bool SUPER>
-__global__ __launch_bounds__(256) void cell_sweep_kernel(
+__global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
+   
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
