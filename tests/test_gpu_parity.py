@@ -501,3 +501,39 @@ def test_simplex_weight_orders_dense_simplices_first(dev):
     true = np.array([((pts >= lo[i]) & (pts <= hi[i])).all(axis=1).sum() for i in range(V.shape[0])])
     top = set(np.argsort(-true)[: len(true) // 10].tolist())
     assert len(top & set(order[: len(true) // 5].tolist())) >= 0.8 * len(top)
+
+
+@pytest.mark.parametrize("cloud", ["gauss3d", "eight2d", "torus"])
+def test_runs_of_four_chunks_equal_chunk_by_chunk(dev, cloud, monkeypatch):
+    """The two-launch cell sweep (runs of four chunks against one shared stage, then the deferred chunks) forced on
+    for small inputs - every simplex 'sparse', no minimum queue length, several stage-fit limits - against the
+    chunk-by-chunk sweep: identical dictionaries."""
+    lib = _native.load()
+    if cloud == "gauss3d":
+        pts = np.random.default_rng(11).normal(size=(150_000, 3)).astype(np.float32)
+        n_l = 120
+    elif cloud == "eight2d":
+        pts = fa.generate_figure_eight_points_2d(120_000, noise_std=0.02, seed=3).numpy().astype(np.float32)
+        n_l = 150
+    else:
+        pts = fo.noisy_torus(200_000, seed=13)
+        n_l = 150
+    tp = torch.as_tensor(pts, device=dev)
+    tl = fa.generate_landmarks(tp, n_l, start_idx=0)
+    for kw in (dict(points_per_edge=30), dict(points_per_edge=None, num_rand=3000)):
+        monkeypatch.setattr(core, "CELL_SUPER", False)
+        torch.manual_seed(5)
+        ref = fa.flood_complex(tp, tl, method="cell", **kw)
+        monkeypatch.setattr(core, "CELL_SUPER", True)
+        for weight, n0 in ((10 ** 9, 480), (2000, 480), (10 ** 9, 100)):
+            try:
+                for name, val in ((b"cell_super_min_chunks", 0), (b"cell_super_sparse", 10 ** 9),
+                                  (b"cell_super_weight", weight), (b"cell_super_n0", n0)):
+                    assert lib.flooder_set_option(name, val) == 0
+                torch.manual_seed(5)
+                got = fa.flood_complex(tp, tl, method="cell", **kw)
+            finally:
+                for name, val in ((b"cell_super_min_chunks", 49152), (b"cell_super_sparse", 600),
+                                  (b"cell_super_weight", 2000), (b"cell_super_n0", 480)):
+                    lib.flooder_set_option(name, val)
+            assert got == ref, (cloud, kw, weight, n0)

@@ -80,10 +80,10 @@ PY
             timeout 300 python tools/bvh_phase.py $wl 2>&1 | grep -v amdgpu.ids > $OUT/fin_phase_$wl.txt
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/fin_phase_$wl.txt ;;
-    ptimers:*) wl=${s#ptimers:}
+    ptimers:*) IFS=: read -r _ wl md <<< "$s"
             cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
-            timeout 300 python tools/phase_timers.py $wl > $OUT/phase_timers_$wl.txt 2>&1
+            timeout 300 python tools/phase_timers.py $wl ${md:-} > $OUT/phase_timers_$wl.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
             cat $OUT/phase_timers_$wl.txt ;;
     sortbench) hipcc -O3 --offload-arch=gfx950 tools/sort_bench.hip -o /tmp/sort_bench > $OUT/sort_build.log 2>&1 && timeout 120 /tmp/sort_bench > $OUT/sort_bench.txt 2>&1; cat $OUT/sort_bench.txt ;;

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import flooder_amd as fa
 from flooder_amd import _native, core
 lib = _native.load()
-core.CELL_SUPER = False  # (the per-chunk records below assume one work item per chunk)
+core.CELL_SUPER = len(sys.argv) > 2 and sys.argv[2] == 'super'  # (per-chunk records assume one work item per chunk; the phase sums do not)
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
