@@ -34,12 +34,13 @@ namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
-// bits per axis of the curve codes: option "curve_bits" (default 12: 36-bit keys in 3D, five radix passes; a finer
-// curve than the 4096^3 grid does not make the 16-point leaves measurably tighter), at most floor(63 / dim) and 21
+// bits per axis of the curve codes: option "curve_bits"; default 10 in 3D and 16 in 2D - keys of at most 32 bits are
+// written and sorted as uint32 (a finer curve than the 1024^3 grid does not make the 16-point leaves measurably
+// tighter) -, 12 in higher dimensions; at most floor(63 / dim) and 21
 inline int curve_bits_per_axis(int dim) {
   int cap = 63 / dim;
   if (cap > 21) cap = 21;
-  int b = g_curve_bits > 0 ? g_curve_bits : 12;
+  int b = g_curve_bits > 0 ? g_curve_bits : (dim == 3 ? 10 : (dim == 2 ? 16 : 12));
   if (dim == 1) b = cap;          // (one axis: the code is the coordinate; keep its full resolution)
   return b < cap ? b : cap;
 }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict
 template <int DIM>
 __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
                                                      const float* __restrict__ dbox, int64_t* __restrict__ codes,
-                                                     int curve, int BITS) {
+                                                     int curve, int BITS, int narrow) {
   // curve 0: Morton (Z-order) codes; 1: Hilbert codes (Skilling's axes-to-transpose transform, then the same
   // bit interleave) - consecutive codes are neighbours in space, so 16 consecutive points make tighter leaves.
   // BITS per axis (flooder_curve_key_bits(dim) / dim): the radix sort of the codes costs one pass per 8 key bits
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ p
 #pragma unroll
         for (int k = 0; k < DIM; ++k) code |= (uint64_t)((q[k] >> b) & 1u) << (b * DIM + k);
     }
-    codes[j] = (int64_t)code;
+    if (narrow) reinterpret_cast<uint32_t*>(codes)[j] = (uint32_t)code;  // (keys of <= 32 bits: n uint32 words)
+    else codes[j] = (int64_t)code;
   }
 }
 
@@ -651,7 +653,7 @@ struct MortonOp {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes, g_curve,
-                       curve_bits_per_axis(DIM));
+                       curve_bits_per_axis(DIM), curve_bits_per_axis(DIM) * DIM <= 32 ? 1 : 0);
     return check_launch("morton");
   }
 };

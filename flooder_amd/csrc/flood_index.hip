@@ -76,11 +76,17 @@ int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_
   if (!codes || !codes_sorted || !order || !tmp || n_pts < 0 || n_pts > 0xfffffffeLL || key_bits < 1 || key_bits > 64)
     return fail(FLOODER_E_ARG, "flooder_index_sort: bad argument");
   size_t bytes = (size_t)tmp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, reinterpret_cast<const uint64_t*>(codes),
-                                           reinterpret_cast<uint64_t*>(codes_sorted),
-                                           rocprim::counting_iterator<uint32_t>(0u),
-                                           reinterpret_cast<uint32_t*>(order), (size_t)n_pts, 0u,
-                                           (unsigned)key_bits, (hipStream_t)stream);
+  hipError_t e;
+  if (key_bits <= 32)  // narrow keys: flooder_morton_f32 wrote n uint32 words
+    e = rocprim::radix_sort_pairs(tmp, bytes, reinterpret_cast<const uint32_t*>(codes),
+                                  reinterpret_cast<uint32_t*>(codes_sorted), rocprim::counting_iterator<uint32_t>(0u),
+                                  reinterpret_cast<uint32_t*>(order), (size_t)n_pts, 0u, (unsigned)key_bits,
+                                  (hipStream_t)stream);
+  else
+    e = rocprim::radix_sort_pairs(tmp, bytes, reinterpret_cast<const uint64_t*>(codes),
+                                  reinterpret_cast<uint64_t*>(codes_sorted), rocprim::counting_iterator<uint32_t>(0u),
+                                  reinterpret_cast<uint32_t*>(order), (size_t)n_pts, 0u, (unsigned)key_bits,
+                                  (hipStream_t)stream);
   if (e != hipSuccess) return fail(FLOODER_E_LAUNCH, hipGetErrorString(e));
   return check_launch("index_sort");
 }
