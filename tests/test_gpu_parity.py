@@ -537,3 +537,29 @@ def test_runs_of_four_chunks_equal_chunk_by_chunk(dev, cloud, monkeypatch):
                                   (b"cell_super_weight", 2000), (b"cell_super_n0", 480)):
                     lib.flooder_set_option(name, val)
             assert got == ref, (cloud, kw, weight, n0)
+
+
+def test_index_sort_is_a_stable_sort(dev):
+    """flooder_index_sort (radix sort over the used key bits; uint32 words for keys of at most 32 bits) against torch's
+    stable sort: identical permutations, duplicates included."""
+    lib = _native.load()
+    g = torch.Generator().manual_seed(9)
+    for n, bits in ((1, 30), (63, 30), (5000, 8), (100_000, 30), (1_000_003, 30), (300_000, 17), (200_000, 36),
+                    (4_000_000, 30)):
+        keys = torch.randint(0, 1 << bits, (n,), generator=g, dtype=torch.int64)
+        if n > 1000:
+            keys[: n // 3] = keys[n // 3: 2 * (n // 3)]                     # plenty of duplicates
+        want = torch.sort(keys, stable=True).indices.numpy()
+        buf = torch.zeros(n, dtype=torch.int64, device=dev)
+        if bits <= 32:
+            buf.view(torch.int32)[:n] = keys.to(torch.int32).to(dev)       # narrow keys: n uint32 words
+        else:
+            buf.copy_(keys)
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        nb = int(lib.flooder_index_sort_bytes(n))
+        tmp = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _native.check(lib.flooder_index_sort(_native.ptr(buf), n, bits, _native.ptr(out), _native.ptr(order),
+                                             _native.ptr(tmp), nb, 0), "flooder_index_sort")
+        torch.cuda.synchronize()
+        assert np.array_equal(order.cpu().numpy().astype(np.int64), want), (n, bits)
