@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   // few items: split each tile over several waves (short tail, tight boxes); many: 64 distinct samples per wave
   int subs = 1;
   const int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
-  if (mode != 0) {
+  if (mode == 2) {
     subs = subs_max;
     while (subs > 1 && n_base * subs > items_cap) subs >>= 1;
     if (subs_max > 1 && n_base * 64 <= (int64_t)gridDim.x * 4) subs = 64;
@@ -109,7 +109,6 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
     } else {
       item = flag_list[g];
       s = item / tiles;
-      if (mode == 2 && n_list > SHORT_LIST && top[s] != 0ull && (int)(uint32_t)(top[s] & 0xffffffffull) == item) continue;
     }
     const int tile = item - (int)(s * tiles);
     const int slane = sub * per_sub + (lane & (per_sub - 1));  // sample slot of this lane inside the tile
@@ -169,6 +168,15 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         tlo[k] = wave_min_f32(settled ? __builtin_inff() : p[k]);
         thi[k] = wave_max_f32(settled ? -__builtin_inff() : p[k]);
       }
+    }
+    int pick = -1;
+    if (mode == 1 && M >= 0.f) {
+      // top pass: only the sample with the largest bound of the simplex's top tile is settled here - one point query
+      // per simplex gives every face maximum a value close to its final one; the other samples of the tile are
+      // handled by the last pass like those of any tile (most of them drop against that value)
+      pick = __builtin_ctzll(__ballot(live && best == M));
+      done = done || lane != pick;
+      refresh();
     }
     if (sub == 0) n_live0 += __popcll(__ballot(live && mine));
     if (!(M >= 0.f)) {  // nothing to do for this tile
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       FIN_PHASE(4);
       if (!(M >= 0.f)) break;
     }
+    if (mode == 1 && lane == pick && exists) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
   }
   if (stats && lane == 0 && (n_node_test | n_leaf_test | n_dropped) != 0ull) {
     atomicAdd(&stats[0], n_leaf_eval);
