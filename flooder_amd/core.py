@@ -296,6 +296,7 @@ class SweepStats:
         self.slab_points = 0         # ball tests
         self.groups = 0
         self.deferred_chunks = 0     # chunks the run-of-four launch handed to the per-chunk launch
+        self.hard_entries = (0, 0, 0)  # tiles the finish searched with several waves (top pass, rest, rest again)
 
 
 LAST_STATS = SweepStats()
@@ -704,6 +705,7 @@ CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spac
 FUSED_FACES = True
 CELL_PROBE = True    # the finish's probe (one greedy tree descent per flagged tile) runs inside the cell sweep
 SHARED_FACE_SLOTS = True   # one running maximum per distinct face of the complex (top-dimensional grid sweeps)
+FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does not fit is finished by one wave)
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 
 
@@ -752,12 +754,16 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         F = faces.n_faces
         tiles = (R + 63) // 64
         slot_t, n_slots = face_slots if face_slots is not None else (None, S * F)
-        ctl = torch.zeros(24, dtype=torch.int32, device=dev)       # [0] sweep queue, [1] flag count, [4:12] finish ([7]: top count), [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices, lists on
+        # [0] sweep queue, [1] flag count, [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices,
+        # lists on; [24:40] finish (queue heads, [27] top count, [31:34] hard entries); [40:] histogram of the flagged
+        # tiles' bounds and the cursors of the finish's counting sort
+        ctl = torch.zeros(40 + 8192, dtype=torch.int32, device=dev)
+        hard = torch.empty(2 * (2 * FINISH_HARD_CAP + (FINISH_HARD_CAP + 1) // 2), dtype=torch.int64, device=dev)
         face_bits = torch.zeros(n_slots, dtype=torch.int32, device=dev)
         top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
         d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
-        flags = torch.empty(S * tiles, dtype=torch.int32, device=dev)
+        flags = torch.empty((3, S * tiles), dtype=torch.int32, device=dev)  # flagged tiles, their bounds, ordered
         chunks = (R + 255) // 256
         defer_list = torch.empty(S * chunks, dtype=torch.int32, device=dev) if CELL_SUPER else None
         defer_c = torch.empty(S * chunks, dtype=torch.float32, device=dev) if CELL_SUPER else None
@@ -771,21 +777,25 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
-                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags),
-                ctl[1:].data_ptr(), _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
-                ctl[7:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
+                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
+                ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
+                ctl[40:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
+                ctl[27:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
                 _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(sub(0, 9)), st),
                 "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[4:].data_ptr(),
+                _native.ptr(w_perm), k1, R, S, _native.ptr(flags[0]), ctl[1:].data_ptr(),
+                _native.ptr(flags[1]) if CELL_PROBE else None, ctl[40:].data_ptr() if CELL_PROBE else None,
+                _native.ptr(flags[2]) if CELL_PROBE else None, ctl[24:].data_ptr(),
                 _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
-                _native.ptr(plan.memb_all), F,
-                _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
+                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(hard),
+                FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
+            LAST_STATS.hard_entries = tuple(int(v) for v in ctl[31:34].tolist())
         out_face = torch.empty(n_slots if face_slots is not None else (S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
             _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), n_slots, _native.ptr(out_face), st),

@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           if (q * CHUNK + i * 64 + lane < n_live)
             out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
         } else if (__ballot(open[i]) != 0ull) {
+          uint32_t tile_key = 0u;
           if (acc.top) {
             // probe: one greedy descent of the box tree for the tile's open samples (nearest child box at every
             // level, one leaf evaluated) gives each of them a finite upper bound; the tile with the largest one
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             }
             best[i] = bb;
             const uint32_t key = wave_max_u32(open[i] ? __float_as_uint(bb) : 0u);
+            tile_key = key;
             if (lane == 0 && key != 0u) {
               const unsigned long long old =
                   atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)(s * tiles64 + q * SPL + i));
@@ -577,6 +579,10 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           if (lane == 0) {
             const int pos = atomicAdd(flag_count, 1);
             flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+            if (acc.flag_key) {
+              acc.flag_key[pos] = tile_key;
+              atomicAdd(&acc.flag_hist[tile_key >> 19], 1);
+            }
           }
           ++n_flagged;
         }
@@ -1202,14 +1208,14 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
-                                 int32_t* flag_count, uint64_t* top, int32_t* top_list, int32_t* top_count,
-                                 int32_t* defer_list,
+                                 int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
+                                 int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)) ||
       (defer_list && (!defer_c || !defer_ctl)) || (simplex_weight && (!defer_list || !light_list || !heavy_list)) ||
-      n_simplices > 0x7fffffffLL)
+      (flag_key && (!flag_hist || !top)) || n_simplices > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_faces_f32: bad argument");
   if (!simplex_weight) light_list = heavy_list = nullptr;
   if (simplex_weight) {  // split the simplices (order kept) into the light and the heavy list
@@ -1220,7 +1226,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
-                                  top_count, face_slot},
+                                  top_count, face_slot, flag_key, flag_hist},
                           DeferList{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
                                     light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0},
                           defer_list ? defer_ctl + 1 : nullptr,

@@ -30,6 +30,9 @@ extern int g_cell_super_min_chunks;
 extern int g_curve_bits;
 extern int g_cell_exh_tries;
 extern int g_finish_items_cap;
+extern int g_finish_budget;  // leaves per round before a tile of the finish counts as hard (0: off)
+extern int g_finish_parts;   // waves per hard entry
+extern int g_finish_order;   // 1: the finish works the flagged tiles off by descending probe bound
 extern int g_fps_switch;
 extern int g_fps_rpl;
 extern int g_curve;
@@ -163,6 +166,10 @@ struct FaceAcc {
   // (the zero weights contribute exact zeros): with one slot per DISTINCT face the first simplex that settles a face
   // lets every other one drop that face's samples in the finish.
   const int32_t* slot;
+  // cell sweep -> finish: the probe's bound of every flagged tile (parallel to the flag list) and a histogram of the
+  // bounds' top 12 bits: the finish starts the tiles with the largest bounds - the longest searches - first
+  uint32_t* flag_key = nullptr;
+  int32_t* flag_hist = nullptr;
   __device__ __forceinline__ int64_t slot_of(int64_t s, int f) const {
     return slot ? (int64_t)slot[s * (int64_t)n_faces + f] : s * (int64_t)n_faces + f;
   }

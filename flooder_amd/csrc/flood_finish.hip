@@ -29,14 +29,38 @@ constexpr float SAFE = 0.99999f;
 constexpr int SHORT_LIST = 1024;
 constexpr int TOP_NODES = 1024;  // nodes of the two top tree levels kept in LDS (32 KB in 3D)
 
+// Hard tiles.  A sample near the medial axis of the cloud is almost equidistant to thousands of leaves, and a tile of
+// such samples keeps ONE wave busy for milliseconds while the rest of the chip idles at the end of the pass (and on
+// a shard of the simplices nothing else is left to hide it).  A round that evaluates more than `budget` leaves is
+// therefore abandoned: the bounds reached so far go back to the scratch matrix and the tile, with the lanes of the
+// round's focus samples, is appended to a hard list.  The next launch (mode 3) searches every hard entry with
+// `parts` waves, wave j descending only into the level-1 nodes j, j + parts, ... (an interleaved 1/parts of the
+// sorted cloud); each takes the minimum into the scratch matrix, and the wave that finishes last - a counter per
+// entry - reads the exact values, delivers them and goes on with the tile's remaining samples as mode 2 would.
+struct HardLists {
+  const unsigned long long* ent_in;   // item | sub << 32 | subs << 40 | stop_after_join << 48
+  const unsigned long long* mask_in;  // lanes of the focus samples
+  int32_t* join_in;                   // waves done per entry (zeroed by the producer)
+  const int32_t* cnt_in;
+  unsigned long long* ent_out;
+  unsigned long long* mask_out;
+  int32_t* join_out;
+  int32_t* cnt_out;
+  int cap;     // entries per list
+  int budget;  // leaves per round before a round counts as hard (0: never)
+  int parts;
+};
+
 template <int DIM>
-__global__ __launch_bounds__(256) void finish_faces_kernel(
+__global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_count,
-    int mode /* 0 probe, 1 top tiles, 2 rest */, int subs_max, int items_cap, int refine_pct, float focus_frac, int refresh_every, int32_t* __restrict__ queue,
+    int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_sorted,
+    const int32_t* __restrict__ flag_count,
+    int mode /* 0 probe, 1 top tiles, 2 rest, 3 hard entries */, int subs_max, int items_cap, int refine_pct, float focus_frac, int refresh_every, int32_t* __restrict__ queue,
     uint32_t* __restrict__ d2, FaceAcc acc, unsigned long long* __restrict__ top,
-    int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, unsigned long long* __restrict__ stats) {
+    int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, HardLists hl,
+    unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
@@ -49,7 +73,11 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   const int n_list = flag_count[0];
   // few items: split each tile over several waves (short tail, tight boxes); many: 64 distinct samples per wave
   int subs = 1;
-  const int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
+  int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
+  if (mode == 3) {
+    n_base = hl.cnt_in[0];
+    if (n_base > hl.cap) n_base = hl.cap;  // (entries that did not fit were finished by their producer)
+  }
   if (mode == 2) {
     subs = subs_max;
     while (subs > 1 && n_base * subs > items_cap) subs >>= 1;
@@ -57,10 +85,11 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   }
   if (n_base == 0) return;
   // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
-  if (mode != 2 && n_list <= SHORT_LIST) return;
-  const int64_t n_items = n_base * subs;
-  const int per_sub = 64 / subs;
+  if (mode < 2 && n_list <= SHORT_LIST) return;
+  const int64_t n_items = n_base * (mode == 3 ? hl.parts : subs);
   const int topl = lv.n_levels - 1;
+  // (the split of a hard entry is by level-1 node: a tree without that level has no hard entries)
+  const bool budgeted = hl.budget > 0 && hl.ent_out != nullptr && topl >= 1;
   // stage levels topl (first) and topl - 1 (behind it) when they fit
   const int top_cnt = (int)lv.count[topl];
   const int sub_cnt = topl >= 2 ? (int)lv.count[topl - 1] : 0;    // (level 0 = leaves: fetched per group)
@@ -84,9 +113,30 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
 #endif
 
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
+#ifdef FLOODER_WAVE_END_FIN
+  const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_longest = 0, t_item = 0;  // longest single item of this wave (10 ns ticks)
+  unsigned long long c_longest = 0, c_item[4] = {0, 0, 0, 0};  // its rounds, leaf evaluations, expansions, leaf tests
+  long long g_prev = -1;
+  unsigned long long m_prev = 0;
+#endif
   const bool static_deal = n_items <= (int64_t)gridDim.x * 4;
   bool dealt = false;
   for (;;) {
+#ifdef FLOODER_WAVE_END_FIN
+    if (t_item) {
+      const unsigned long long d = __builtin_amdgcn_s_memrealtime() - t_item;
+      if (mode == 2 && stats && lane == 0 && g_prev >= 0 && g_prev < 200000) {
+        stats[40000 + 2 * g_prev] = d | ((n_rounds - c_item[0]) << 32) | ((n_leaf_eval - c_item[1]) << 44);
+        stats[40000 + 2 * g_prev + 1] = m_prev;
+      }
+      if (d > t_longest) {
+        t_longest = d;
+        c_longest = ((n_rounds - c_item[0]) << 48) | ((n_leaf_eval - c_item[1]) << 32) | ((n_node_test - c_item[2]) << 16) |
+                    ((n_leaf_test - c_item[3]) & 0xffffull);
+      }
+    }
+#endif
     int64_t g;
     if (static_deal) {
       if (dealt || wave_id >= n_items) break;
@@ -99,15 +149,39 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       if (g >= n_items) break;
     }
     FIN_PHASE(5);  // (queue pop, bookkeeping)
-    const int sub = (int)(g % subs);
-    g /= subs;
+#ifdef FLOODER_WAVE_END_FIN
+    t_item = __builtin_amdgcn_s_memrealtime();
+    g_prev = g;
+    m_prev = 0;
+    c_item[0] = n_rounds; c_item[1] = n_leaf_eval; c_item[2] = n_node_test; c_item[3] = n_leaf_test;
+#endif
+    int sub, subs_i = subs, part = -1;
+    int64_t ent_idx = -1;
+    bool stop_after = false;
+    unsigned long long fmask = 0ull;
     int64_t s;
     int item;  // global tile id: simplex * tiles + tile
-    if (mode == 1) {
+    if (mode == 3) {
+      ent_idx = g / hl.parts;
+      part = (int)(g % hl.parts);
+      const unsigned long long ent = hl.ent_in[ent_idx];
+      item = (int)(uint32_t)(ent & 0xffffffffull);
+      sub = (int)((ent >> 32) & 0xffull);
+      subs_i = (int)((ent >> 40) & 0xffull);
+      stop_after = ((ent >> 48) & 1ull) != 0ull;
+      fmask = hl.mask_in[ent_idx];
+      s = item / tiles;
+    } else {
+      sub = (int)(g % subs);
+      g /= subs;
+    }
+    const int per_sub = 64 / subs_i;
+    if (mode == 3) {
+    } else if (mode == 1) {
       s = top_list[g];
       item = (int)(uint32_t)(top[s] & 0xffffffffull);
     } else {
-      item = flag_list[g];
+      item = (n_list > SHORT_LIST && flag_sorted ? flag_sorted : flag_list)[g];
       s = item / tiles;
     }
     const int tile = item - (int)(s * tiles);
@@ -169,6 +243,9 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         thi[k] = wave_max_f32(settled ? -__builtin_inff() : p[k]);
       }
     }
+#ifdef FLOODER_WAVE_END_FIN
+    m_prev = (unsigned long long)__float_as_uint(M >= 0.f ? M : 0.f) | ((unsigned long long)__popcll(__ballot(live)) << 32);
+#endif
     int pick = -1;
     if (mode == 1 && M >= 0.f) {
       // top pass: only the sample with the largest bound of the simplex's top tile is settled here - one point query
@@ -179,7 +256,9 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
       refresh();
     }
     if (sub == 0) n_live0 += __popcll(__ballot(live && mine));
-    if (!(M >= 0.f)) {  // nothing to do for this tile
+    // nothing to do for this tile (mode 3: then no wave on the entry has, now or later - liveness only ever goes
+    // away - and that the entry is never counted off loses nothing)
+    if (!(M >= 0.f)) {
       if (sub == 0) ++n_dropped;
       continue;
     }
@@ -210,6 +289,8 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
           const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
           lb = __builtin_fmaf(gap, gap, lb);
         }
+        // one wave of several on a hard entry: only its share of the level-1 nodes
+        if (part >= 0 && lvl == 1 && (int)(idx % hl.parts) != part) lb = __builtin_inff();
       }
       return lb;
     };
@@ -277,8 +358,13 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
     // them alone - a few nearby points instead of a 64-sample tile - while every leaf it evaluates still tightens
     // the bounds of all lanes.  The settled values are delivered, face_bits rises, and most of the remaining
     // samples drop out without a search of their own; whatever is still live forms the next round.
+    bool joined = mode == 3;  // the first round of a hard entry: shared with the other waves on it
+    bool aborted = false;
+    bool on_budget = budgeted;
     for (;;) {
-      bool focus = live && best >= focus_frac * M;
+      // (a sample another wave on the entry sees as not live is below its faces' maxima: whatever bound is
+      // delivered for it changes nothing, so the waves need not agree on the live set)
+      bool focus = joined ? (live && ((fmask >> lane) & 1ull) != 0ull) : (live && best >= focus_frac * M);
       float Mf;
       auto rebound = [&]() {
         Mf = wave_max_f32(focus ? best : -1.f);
@@ -299,8 +385,9 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         s_lb[wv][topl][lane] = lb0;
         if (lane == 0) s_grp[wv][topl] = 0;
       }
-      int since = 0;
+      int since = 0, evals = 0;
       for (;;) {
+        if (joined && !(Mf >= 0.f)) break;
         if (lvl > 0) {
           const float lbv = s_lb[wv][lvl][lane];
           const float mn = wave_min_f32(lbv);
@@ -371,6 +458,25 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         FIN_PHASE(2);  // leaf selection + test
         eval_leaf(c);
         FIN_PHASE(3);  // leaf evaluation
+        if (on_budget && !joined && ++evals > hl.budget) {
+          // a hard round: hand the tile to the next launch (unless its list is full: then carry on alone)
+          const unsigned long long fm = __ballot(focus && mine);
+          int h = 0;
+          if (lane == 0) h = atomicAdd(hl.cnt_out, 1);
+          h = wave_uniform(h);
+          if (h < hl.cap) {
+            if (mine && !settled) d2[s * (int64_t)R + r] = __float_as_uint(best);  // bounds reached so far
+            if (lane == 0) {
+              hl.ent_out[h] = (unsigned long long)(uint32_t)item | ((unsigned long long)sub << 32) |
+                              ((unsigned long long)subs_i << 40) | (mode == 1 ? (1ull << 48) : 0ull);
+              hl.mask_out[h] = fm;
+              hl.join_out[h] = 0;
+            }
+            aborted = true;
+            break;
+          }
+          on_budget = false;
+        }
         if (++since >= refresh_every) {
           since = 0;
           refresh();  // other waves may have raised the face maxima meanwhile: focus samples may drop out
@@ -381,6 +487,23 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         }
         FIN_PHASE(4);  // bounds / live set upkeep
         if (!(Mf >= 0.f)) break;
+      }
+      if (aborted) break;
+      if (joined) {
+        // ---- a hard entry: minimum over the waves on it, the last one to arrive goes on
+        const bool fl = mine && !settled && ((fmask >> lane) & 1ull) != 0ull;
+        if (fl) atomicMin(&d2[s * (int64_t)R + r], __float_as_uint(best));
+        __threadfence();
+        int old = 0;
+        if (lane == 0) old = atomicAdd(&hl.join_in[ent_idx], 1);
+        old = wave_uniform(old);
+        if (old != hl.parts - 1) break;
+        __threadfence();
+        if (fl) best = __uint_as_float(__hip_atomic_load(&d2[s * (int64_t)R + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        focus = fl;
+        joined = false;
+        part = -1;
+        if (fl) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
       }
       // ---- deliver the round: focus samples that stayed live to its end are exact (a focus sample that dropped out
       // on the way is below the running maximum of each of its faces: its atomic changes nothing)
@@ -397,12 +520,22 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
         }
       }
       done = done || focus;
+      if (stop_after) break;  // (an entry of the top pass: one sample)
       refresh();
       FIN_PHASE(4);
       if (!(M >= 0.f)) break;
     }
-    if (mode == 1 && lane == pick && exists) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
+    if (mode == 1 && !aborted && lane == pick && exists) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
   }
+#ifdef FLOODER_WAVE_END_FIN
+  // diagnostic build (tools/wave_ends.py finish): per-wave start, end and longest item of the last pass
+  if (stats && mode == 2 && lane == 0 && wave_id < 4096) {
+    stats[64 + 16384 + 3 * wave_id] = t_wave0;
+    stats[64 + 16384 + 3 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+    stats[64 + 16384 + 3 * wave_id + 2] = t_longest;
+    stats[64 + 16384 + 3 * 4096 + wave_id] = c_longest;
+  }
+#endif
   if (stats && lane == 0 && (n_node_test | n_leaf_test | n_dropped) != 0ull) {
     atomicAdd(&stats[0], n_leaf_eval);
     atomicAdd(&stats[1], n_leaf_test);
@@ -419,6 +552,51 @@ __global__ __launch_bounds__(256) void finish_faces_kernel(
   }
 }
 
+// Counting sort of the flagged tiles by the top 12 bits of their probe bound, largest first (sweep: keys and the
+// histogram; here: every block scans the histogram for itself, then scatters its share of the list).  The bound
+// predicts the length of a tile's search well (rank correlation 0.8 on the torus of cfg 3); with the long searches
+// started first the last pass ends when the work does, not when the last long tile that happened to be queued
+// late does (cfg 3: -27 % of the pass, cfg 5: -29 %, simulated from measured tile times).
+constexpr int KEY_BUCKETS = 4096;
+__global__ __launch_bounds__(256) void order_flags_kernel(const int32_t* __restrict__ flag_list,
+                                                          const uint32_t* __restrict__ flag_key,
+                                                          const int32_t* __restrict__ flag_count,
+                                                          const int32_t* __restrict__ hist,
+                                                          int32_t* __restrict__ cursor,
+                                                          int32_t* __restrict__ flag_sorted) {
+  __shared__ int s_base[KEY_BUCKETS];
+  __shared__ int s_part[256];
+  const int n = flag_count[0];
+  if (n <= SHORT_LIST) return;
+  // descending exclusive scan: thread t owns buckets [4095 - 16 t - 15, 4095 - 16 t]
+  constexpr int PER = KEY_BUCKETS / 256;
+  int own[PER], sum = 0;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    own[u] = hist[KEY_BUCKETS - 1 - (threadIdx.x * PER + u)];
+    sum += own[u];
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_part[threadIdx.x] - sum;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    s_base[KEY_BUCKETS - 1 - (threadIdx.x * PER + u)] = run;
+    run += own[u];
+  }
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int b = (int)(flag_key[i] >> 19);
+    flag_sorted[s_base[b] + atomicAdd(&cursor[b], 1)] = flag_list[i];
+  }
+}
+
 __global__ void face_values_kernel(const uint32_t* __restrict__ bits, int64_t n, float* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -428,17 +606,61 @@ __global__ void face_values_kernel(const uint32_t* __restrict__ bits, int64_t n,
 template <int DIM>
 struct FinishOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
-                 int k1, int R, int64_t ns, const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                 int k1, int R, int64_t ns, const int32_t* flag_list, const int32_t* flag_count,
+                 const uint32_t* flag_key, int32_t* flag_hist, int32_t* flag_sorted, int32_t* ctl,
                  uint32_t* d2, FaceAcc acc, unsigned long long* top, int32_t* top_list, int probed,
-                 unsigned long long* stats, hipStream_t st) {
+                 unsigned long long* hard, int hard_cap, unsigned long long* stats, hipStream_t st) {
     const int grid = g_bvh_grid;
     // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile (filled by the probe -
-    // the cell sweep's when `probed`, else pass 0 here)
-    for (int mode = probed ? 1 : 0; mode < 3; ++mode) {
+    // the cell sweep's when `probed`, else pass 0 here); ctl[4..6]: queue heads of the hard-entry launches,
+    // ctl[7..9]: lengths of the hard lists
+    const bool hard_on = hard != nullptr && hard_cap > 0 && g_finish_budget > 0;
+    const bool ordered = flag_key != nullptr && flag_hist != nullptr && flag_sorted != nullptr && g_finish_order != 0;
+    if (ordered)
+      hipLaunchKernelGGL(order_flags_kernel, dim3(256), dim3(256), 0, st, flag_list, flag_key, flag_count, flag_hist,
+                         flag_hist + KEY_BUCKETS, flag_sorted);
+    const int64_t words = (int64_t)hard_cap * 2 + (hard_cap + 1) / 2;  // entries, masks (u64), counters (i32)
+    auto list = [&](int which, bool in, int32_t* cnt, HardLists& hl) {
+      unsigned long long* base = hard + which * words;
+      if (in) {
+        hl.ent_in = base;
+        hl.mask_in = base + hard_cap;
+        hl.join_in = reinterpret_cast<int32_t*>(base + 2 * (int64_t)hard_cap);
+        hl.cnt_in = cnt;
+      } else {
+        hl.ent_out = base;
+        hl.mask_out = base + hard_cap;
+        hl.join_out = reinterpret_cast<int32_t*>(base + 2 * (int64_t)hard_cap);
+        hl.cnt_out = cnt;
+      }
+    };
+    auto launch = [&](int mode, int32_t* queue, const HardLists& hl) {
       hipLaunchKernelGGL((finish_faces_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, k1,
-                         R, ns, flag_list, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, g_finish_refresh, ctl + mode, d2, acc, top,
-                         top_list, ctl + 3, stats);
+                         R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct,
+                         (float)g_finish_focus_pct * 0.01f, g_finish_refresh, queue, d2, acc, top, top_list, ctl + 3,
+                         hl, stats);
+    };
+    const HardLists none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hard_cap, 0,
+                         g_finish_parts};
+    if (!probed) launch(0, ctl + 0, none);
+    if (!hard_on) {
+      launch(1, ctl + 1, none);
+      launch(2, ctl + 2, none);
+      return check_launch("finish_faces");
     }
+    HardLists a = none, b = none, c = none, d = none, e = none;
+    a.budget = c.budget = d.budget = g_finish_budget;
+    list(0, false, ctl + 7, a);  // top pass: hard entries -> list 0
+    launch(1, ctl + 1, a);
+    list(0, true, ctl + 7, b);   // ... searched by several waves each
+    launch(3, ctl + 4, b);
+    list(1, false, ctl + 8, c);  // the other samples: hard entries -> list 1
+    launch(2, ctl + 2, c);
+    list(1, true, ctl + 8, d);   // ... searched; what is hard among the rest of their tiles -> list 0 again
+    list(0, false, ctl + 9, d);
+    launch(3, ctl + 5, d);
+    list(0, true, ctl + 9, e);   // ... searched, their tiles finished whatever it takes
+    launch(3, ctl + 6, e);
     return check_launch("finish_faces");
   }
 };
@@ -449,18 +671,21 @@ extern "C" {
 
 int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                             const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                             const int32_t* flag_list, const int32_t* flag_count, const uint32_t* flag_key,
+                             int32_t* flag_hist, int32_t* flag_sorted, int32_t* ctl,
                              uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
                              const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
-                             uint64_t* stats, void* stream) {
+                             uint64_t* hard_scratch, int hard_cap, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !flag_list || !flag_count || !ctl || !top || !top_list || !d2_scratch ||
-      !memb || !face_bits || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 1 || n_faces < 1 || n_faces > 32)
+      !memb || !face_bits || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 1 || n_faces < 1 || n_faces > 32 ||
+      hard_cap < 0)
     return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<FinishOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, flag_list,
-                                flag_count, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces, nullptr, nullptr, nullptr, face_slot},
+                                flag_count, flag_key, flag_hist, flag_sorted, ctl, d2_scratch, FaceAcc{memb, face_bits, n_faces, nullptr, nullptr, nullptr, face_slot},
                                 reinterpret_cast<unsigned long long*>(top), top_list, probed,
+                                reinterpret_cast<unsigned long long*>(hard_scratch), hard_cap,
                                 reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
 }
 

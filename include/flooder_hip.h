@@ -61,8 +61,8 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32; "curve_bits": bits per axis;
  *   "cell_brute_max": kept points up to which a chunk is evaluated straight from the compacted list (160);
  *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
- *                     evaluation (3); "finish_focus_pct", "finish_items_cap": focus rounds and tile splitting of
- *                     flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
+ *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_parts", "finish_order":
+ *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
@@ -236,14 +236,17 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * in a dense region no run of four chunks fits the stage - and are worked off chunk by chunk by the second.  When
  * fewer than half of the simplices are sparse (weight <= option "cell_super_sparse", 600) the first launch gets no
  * work at all and the second sweeps everything in plain order.
+ * flag_key / flag_hist (both NULL, or as many uint32 as flag_list holds / 8192 zeroed int32; need top): the probe's
+ * bound of every flagged tile, parallel to flag_list, and a histogram of the bounds' top 12 bits - with them the
+ * finish works the tiles off longest search first.
  * Followed by flooder_finish_faces_f32 (probed = 1 when top was passed here) and flooder_face_values_f32.
  */
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
                                  int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
-                                 int32_t* flag_count, uint64_t* top, int32_t* top_list, int32_t* top_count,
-                                 int32_t* defer_list,
+                                 int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
+                                 int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream);
 
@@ -253,18 +256,27 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Three passes: a probe (one
  * greedy descent per tile: finite upper bounds, and per simplex the tile with the largest one), the top tile of
  * every simplex, then all other tiles.  Face values equal the exhaustive result bit for bit.
- *   ctl: 8 zeroed int32 (queue heads; ctl[3] = number of entries of top_list, which the cell sweep's probe may
- *   already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64 (zeroed unless
- *   probed); top_list: n_simplices int32;
+ *   ctl: 16 zeroed int32 (queue heads and list lengths; ctl[3] = number of entries of top_list, which the cell
+ *   sweep's probe may already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64
+ *   (zeroed unless probed); top_list: n_simplices int32;
+ *   flag_key / flag_hist / flag_sorted: all NULL, or what flooder_sweep_cell_faces_f32 filled plus scratch of the
+ *   size of flag_list - a counting sort by descending bound puts the long searches first in the last pass's queue
+ *   (option "finish_order" 0 turns it off);
+ *   hard_scratch / hard_cap: NULL / 0, or 2 * (2 * hard_cap + (hard_cap + 1) / 2) uint64 of scratch - a round that
+ *   evaluates more than option "finish_budget" (512) leaves is abandoned and its tile goes on a list of at most
+ *   hard_cap entries; the next launch searches every entry with option "finish_parts" (16) waves, each over an
+ *   interleaved share of the level-1 nodes of the box tree, and the last one to arrive delivers (five launches
+ *   instead of two; without scratch, or with the budget 0, one wave works every tile off alone);
  *   stats: NULL or 7 zeroed uint64 {leaves evaluated, leaves tested, nodes expanded, -, tiles dropped on arrival in
  *   the last pass, samples live on arrival in the last pass, -}.
  */
 int flooder_finish_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                              const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                             const int32_t* flag_list, const int32_t* flag_count, int32_t* ctl,
+                             const int32_t* flag_list, const int32_t* flag_count, const uint32_t* flag_key,
+                             int32_t* flag_hist, int32_t* flag_sorted, int32_t* ctl,
                              uint64_t* top, int32_t* top_list, int probed, uint32_t* d2_scratch,
                              const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
-                             uint64_t* stats, void* stream);
+                             uint64_t* hard_scratch, int hard_cap, uint64_t* stats, void* stream);
 
 /* out_face[i] = sqrt(float(face_bits[i])), i < n: the filtration values (core.py:257, 272: distances, not squares). */
 int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_face, void* stream);

@@ -20,6 +20,7 @@ for s in $STEPS; do
             python tools/summarize_profiles.py ${s#prof:} r2_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
             mkdir -p $OUT/profiles && cp profiles/r2_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
+    emul:*) bash tools/emulate_scaling.sh ${s#emul:} > $OUT/emulate_${s#emul:}.txt 2>&1; cat $OUT/emulate_${s#emul:}.txt ;;
     timers) cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
             timeout 300 python tools/phase_timers.py > $OUT/phase_timers.txt 2>&1
