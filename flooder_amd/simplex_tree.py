@@ -25,6 +25,7 @@ dimension, monotonise) are vectorised instead of one Python call per simplex.
 from __future__ import annotations
 
 import itertools
+import math
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -38,6 +39,9 @@ try:  # pragma: no cover - gudhi is absent from the build image
 except Exception:  # pragma: no cover
     _gudhi = None
     HAS_GUDHI = False
+
+
+INDEX_MAX_FACES = 8_000_000  # cell -> face row indices are kept for tables enumerated from at most this many faces
 
 
 def _lex_sort_rows(rows: np.ndarray) -> np.ndarray:
@@ -111,6 +115,14 @@ def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
             table[:, j] = rest % base
             rest = rest // base
         return table, inv.reshape(keys.shape).astype(np.int64)
+    if base ** k < 2 ** 62:  # packed keys, one combination at a time (no (n_cells x n_combos, k) intermediate)
+        mult = base ** np.arange(k - 1, -1, -1, dtype=np.int64)
+        rest = np.unique(np.concatenate([cells[:, c] @ mult for c in combos]))
+        table = np.empty((rest.shape[0], k), dtype=np.int64)
+        for j in range(k - 1, -1, -1):
+            table[:, j] = rest % base
+            rest = rest // base
+        return table, None
     faces = np.concatenate([cells[:, c] for c in combos], axis=0)
     return _unique_rows(faces), None
 
@@ -167,7 +179,11 @@ class SimplexTree:
         self._lazy.discard(d)
         # (the cell -> face rows cost an argsort of all faces: kept only for the tables enumerated up front, which
         # are the ones the sweep assigns values to)
-        table, index = faces_of_cells(self._cells, d, self._n_points, want_index=not self._monotone)
+        # (... and only while the argsort is small: the 6-D complex of 2000 points has 35 triangles in each of
+        # 1.5 million cells - there the monotone pass and the hand-off locate rows by key instead)
+        n_faces_all = self._cells.shape[0] * math.comb(self._cells.shape[1], d + 1)
+        table, index = faces_of_cells(self._cells, d, self._n_points,
+                                      want_index=not self._monotone and n_faces_all <= INDEX_MAX_FACES)
         self._cell_faces[d] = index
         if table.shape[0]:
             self._rows[d] = table

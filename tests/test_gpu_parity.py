@@ -539,6 +539,56 @@ def test_runs_of_four_chunks_equal_chunk_by_chunk(dev, cloud, monkeypatch):
             assert got == ref, (cloud, kw, weight, n0)
 
 
+@pytest.mark.parametrize("cloud", ["torus", "eight2d"])
+def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
+    """The finish's schedule - flagged tiles by descending probe bound, rounds over the leaf budget searched by several
+    waves over interleaved shares of the tree (joined by the last one to arrive) - must not change a single bit of the
+    face values: plain order / one wave per tile against tiny budgets, 4 / 16 / 64 waves per entry and a hard list
+    too short for its entries (those are finished by their producer)."""
+    lib = _native.load()
+    if cloud == "torus":
+        pts = torch.as_tensor(fo.noisy_torus(300_000, seed=13), device=dev)
+        d = 3
+    else:
+        pts = fa.generate_figure_eight_points_2d(200_000, noise_std=0.02, seed=3).to(dev)
+        d = 2
+    lms = fa.generate_landmarks(pts, 200, start_idx=0)
+    _, simplices = core._build_complex(lms, d)
+    verts = lms[torch.as_tensor(simplices[d], device=dev)].contiguous()
+    weights, _, fi = core.generate_grid(30, d, dev, torch.float32)
+    faces = core._FaceTable(fi, weights.shape[0], dev)
+    index = core.PointIndex(pts)
+    stats = torch.zeros(16, dtype=torch.int64, device=dev)
+
+    def run(order, budget, parts, cap):
+        monkeypatch.setattr(core, "FINISH_HARD_CAP", cap)
+        try:
+            for name, val in ((b"finish_order", order), (b"finish_budget", budget), (b"finish_parts", parts)):
+                assert lib.flooder_set_option(name, val) == 0
+            stats.zero_()
+            out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
+            torch.cuda.synchronize()
+            return out.cpu().numpy(), core.LAST_STATS.hard_entries
+        finally:
+            for name, val in ((b"finish_order", 1), (b"finish_budget", 512), (b"finish_parts", 16)):
+                lib.flooder_set_option(name, val)
+
+    ref, hard = run(0, 0, 16, 32768)
+    assert hard == (0, 0, 0)
+    unfused_before = core.FUSED_FACES
+    monkeypatch.setattr(core, "FUSED_FACES", False)
+    plain, _ = core._sweep_dimension_cell(index, verts, weights, faces, None)
+    monkeypatch.setattr(core, "FUSED_FACES", unfused_before)
+    np.testing.assert_array_equal(ref, plain.cpu().numpy())
+    seen = 0
+    for order, budget, parts, cap in ((1, 0, 16, 32768), (1, 4, 16, 32768), (0, 1, 4, 32768), (1, 16, 64, 32768),
+                                      (1, 2, 16, 8), (1, 64, 1, 32768)):
+        got, hard = run(order, budget, parts, cap)
+        np.testing.assert_array_equal(got, ref, err_msg=str((cloud, order, budget, parts, cap)))
+        seen += hard[1]
+    assert seen > 0, "no round ever exceeded the budget: the hard-entry launches were not exercised"
+
+
 def test_index_sort_is_a_stable_sort(dev):
     """flooder_index_sort (radix sort over the used key bits; uint32 words for keys of at most 32 bits) against torch's
     stable sort: identical permutations, duplicates included."""

@@ -89,7 +89,7 @@ PY
             cat $OUT/phase_timers_$wl.txt ;;
     sortbench) hipcc -O3 --offload-arch=gfx950 tools/sort_bench.hip -o /tmp/sort_bench > $OUT/sort_build.log 2>&1 && timeout 120 /tmp/sort_bench > $OUT/sort_bench.txt 2>&1; cat $OUT/sort_bench.txt ;;
     cweights:*) timeout 300 python tools/check_weights.py ${s#cweights:} 2>&1 | grep -v amdgpu.ids ;;
-    e2e:*) timeout 600 python tools/profile_e2e.py ${s#e2e:} 2>&1 | grep -v amdgpu.ids > $OUT/e2e_${s#e2e:}.txt; head -60 $OUT/e2e_${s#e2e:}.txt ;;
+    e2e:*) timeout 600 python tools/profile_e2e.py ${s#e2e:} tree 2>&1 | grep -v amdgpu.ids > $OUT/e2e_${s#e2e:}.txt; head -60 $OUT/e2e_${s#e2e:}.txt ;;
     tfps) timeout 600 python tools/time_fps.py > $OUT/time_fps.txt 2>&1; cat $OUT/time_fps.txt ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;

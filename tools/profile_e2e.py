@@ -26,6 +26,6 @@ for mode, extra in (("dict", {}), ("simplex tree", dict(return_simplex_tree=True
         ts.append(time.perf_counter() - t0)
     print(f"{which} flood_complex -> {mode}: {min(ts) * 1e3:.2f} ms (best of {len(ts)})", flush=True)
 pr = cProfile.Profile(); pr.enable()
-out = fa.flood_complex(tp, lms, **kw); torch.cuda.synchronize()
+out = fa.flood_complex(tp, lms, **kw, **(dict(return_simplex_tree=True) if 'tree' in sys.argv else {})); torch.cuda.synchronize()
 pr.disable()
 buf = io.StringIO(); pstats.Stats(pr, stream=buf).sort_stats('cumulative').print_stats(28); print(buf.getvalue()[:6000])
