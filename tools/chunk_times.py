@@ -1,5 +1,5 @@
 """Diagnostic: per-chunk start/end cycle stamps of the cell sweep (library built with -DFLOODER_PHASE_TIMERS):
-where is the tail?   usage: python tools/chunk_times.py [W]   (W: keep every W-th simplex, as one rank of W would)"""
+where is the tail?   usage: python tools/chunk_times.py [W] [cfg2|cfg3|cfg5]   (W: keep every W-th simplex, as one rank of W would)"""
 import sys, torch, numpy as np
 sys.path.insert(0, '.')
 import flooder_amd as fa
@@ -9,8 +9,16 @@ lib = _native.load()
 core.CELL_SUPER = False  # (the per-chunk records below assume one work item per chunk)
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
-pts = torch.randn(1_000_000, 3).to(dev)
-lms = fa.generate_landmarks(pts, 1000, start_idx=0)
+which = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+n_l = 1000
+if which == "cfg3":
+    pts = fa.generate_noisy_torus_points_3d(1_000_000, seed=42).to(dev)
+elif which == "cfg5":
+    from flooder_amd.synthetic import generate_swiss_cheese_points
+    pts, n_l = generate_swiss_cheese_points(16_000_000, k=6, seed=42)[0].to(dev), 4000
+else:
+    pts = torch.randn(1_000_000, 3).to(dev)
+lms = fa.generate_landmarks(pts, n_l, start_idx=0)
 stree, simplices = core._build_complex(lms, 3)
 simp = torch.as_tensor(simplices[3], device=dev)
 verts = lms[simp]
@@ -74,3 +82,15 @@ longm = ok & (dur > 10000)
 exh = ((t[:, 2] >> 44) & 1).astype(bool)
 print(f"chunks > 10000 ticks: {longm.sum()} (exhaustive {np.sum(longm & exh)}), wave-time share {dur[longm].sum() / dur[ok].sum() * 100:.1f}%; "
       f"phase shares inside them: " + " ".join(f"{n}={t[longm, 5 + i].sum() / t[longm, 5:16].sum() * 100:.0f}%" for i, n in enumerate(names)))
+
+# exhaustive chunks (kept set larger than the LDS stage) against the others
+for name, m in (("exhaustive", ok & exh), ("others", ok & ~exh)):
+    if m.sum() == 0:
+        continue
+    print(f"{name}: {m.sum()} chunks, {dur[m].sum() / dur[ok].sum() * 100:.1f}% of the wave-time, mean {dur[m].mean():.0f} ticks, n_keep mean "
+          f"{((t[m, 2] >> 20) & 0xfffff).mean():.0f}; phases: " + " ".join(f"{n}={t[m, 5 + i].sum() / t[m, 5:16].sum() * 100:.0f}%" for i, n in enumerate(names)))
+att = (t[:, 2] >> 40) & 15
+for a in range(1, 6):
+    m = ok & (att == a)
+    if m.sum():
+        print(f"attempts {a}: {m.sum()} chunks, {dur[m].sum() / dur[ok].sum() * 100:.1f}% of the wave-time, mean {dur[m].mean():.0f} ticks")

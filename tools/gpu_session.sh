@@ -63,12 +63,12 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:22]:
     print(f"{k:62s} n={len(v):4d} mean {sum(v)/len(v):9.1f} us")
 PY
             rm -rf $OUT/trace_$wl ;;
-    ctimes:*) W=${s#ctimes:}
+    ctimes:*) IFS=: read -r _ W wl <<< "$s"      # ctimes:<W>[:<workload>]
             cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
-            timeout 300 python tools/chunk_times.py $W > $OUT/chunk_times_$W.txt 2>&1
+            timeout 400 python tools/chunk_times.py $W ${wl:-cfg2} > $OUT/chunk_times_${W}_${wl:-cfg2}.txt 2>&1
             cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
-            grep -v "^  ends\|kcycles" $OUT/chunk_times_$W.txt ;;
+            grep -v "^  ends\|kcycles\|^  dur" $OUT/chunk_times_${W}_${wl:-cfg2}.txt ;;
     wends:*) IFS=: read -r _ wl W <<< "$s"
             cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
             FLOODER_HIPCC_FLAGS=-DFLOODER_WAVE_END python -m flooder_amd.build --force > $OUT/build_wend.log 2>&1
