@@ -363,6 +363,7 @@ def main():
                 "finish_tiles_dropped_on_arrival": sh[13], "finish_samples_live_on_arrival": sh[14],
                 "finish_focus_rounds": sh[15],
                 "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks,
+                "finish_shared_rounds": list(core.LAST_STATS.hard_entries),
                 "shared_face_slots": slots is not None}
     else:
         per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)

@@ -296,7 +296,7 @@ class SweepStats:
         self.slab_points = 0         # ball tests
         self.groups = 0
         self.deferred_chunks = 0     # chunks the run-of-four launch handed to the per-chunk launch
-        self.hard_entries = (0, 0, 0)  # tiles the finish searched with several waves (top pass, rest, rest again)
+        self.hard_entries = (0, 0)   # tiles the finish gave to a whole workgroup (top pass, rest pass)
 
 
 LAST_STATS = SweepStats()
@@ -755,10 +755,10 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         tiles = (R + 63) // 64
         slot_t, n_slots = face_slots if face_slots is not None else (None, S * F)
         # [0] sweep queue, [1] flag count, [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices,
-        # lists on; [24:40] finish (queue heads, [27] top count, [31:34] hard entries); [40:] histogram of the flagged
-        # tiles' bounds and the cursors of the finish's counting sort
-        ctl = torch.zeros(40 + 8192, dtype=torch.int32, device=dev)
-        hard = torch.empty(2 * (2 * FINISH_HARD_CAP + (FINISH_HARD_CAP + 1) // 2), dtype=torch.int64, device=dev)
+        # lists on; [24:48] finish (queue heads, [27] top count, [29], [31] hard tiles of the top / rest pass);
+        # [48:] histogram of the flagged tiles' bounds and the cursors of the finish's counting sort
+        ctl = torch.zeros(48 + 8192, dtype=torch.int32, device=dev)
+        hard = torch.empty(4 * FINISH_HARD_CAP, dtype=torch.int64, device=dev)
         face_bits = torch.zeros(n_slots, dtype=torch.int32, device=dev)
         top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
@@ -779,7 +779,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
                 ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
-                ctl[40:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
+                ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
                 ctl[27:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
                 _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(sub(0, 9)), st),
@@ -788,14 +788,15 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.check(lib.flooder_finish_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, _native.ptr(flags[0]), ctl[1:].data_ptr(),
-                _native.ptr(flags[1]) if CELL_PROBE else None, ctl[40:].data_ptr() if CELL_PROBE else None,
+                _native.ptr(flags[1]) if CELL_PROBE else None, ctl[48:].data_ptr() if CELL_PROBE else None,
                 _native.ptr(flags[2]) if CELL_PROBE else None, ctl[24:].data_ptr(),
                 _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(hard),
                 FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
-            LAST_STATS.hard_entries = tuple(int(v) for v in ctl[31:34].tolist())
+            c_h = ctl[24:48].tolist()
+            LAST_STATS.hard_entries = (int(c_h[5]), int(c_h[7]))
         out_face = torch.empty(n_slots if face_slots is not None else (S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
             _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), n_slots, _native.ptr(out_face), st),

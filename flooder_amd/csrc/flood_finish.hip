@@ -31,28 +31,29 @@ constexpr int TOP_NODES = 1024;  // nodes of the two top tree levels kept in LDS
 
 // Hard tiles.  A sample near the medial axis of the cloud is almost equidistant to thousands of leaves, and a tile of
 // such samples keeps ONE wave busy for milliseconds while the rest of the chip idles at the end of the pass (and on
-// a shard of the simplices nothing else is left to hide it).  A round that evaluates more than `budget` leaves is
-// therefore abandoned: the bounds reached so far go back to the scratch matrix and the tile, with the lanes of the
-// round's focus samples, is appended to a hard list.  The next launch (mode 3) searches every hard entry with
-// `parts` waves, wave j descending only into the level-1 nodes j, j + parts, ... (an interleaved 1/parts of the
-// sorted cloud); each takes the minimum into the scratch matrix, and the wave that finishes last - a counter per
-// entry - reads the exact values, delivers them and goes on with the tile's remaining samples as mode 2 would.
+// a shard of the simplices nothing else is left to hide it).  A tile that has evaluated more leaves than the budget
+// (over all its rounds so far; the budget scales with the length of the list, see the kernel) abandons its round:
+// the bounds reached so far go back to the scratch matrix and the tile is appended to a hard list.  The next launch
+// (mode 3, TEAM = true) gives every hard tile to a whole workgroup of 16 waves: all of them hold the tile's samples
+// and take the same decisions from the same data (the face maxima are read by wave 0 and passed on through LDS), but
+// wave j descends only into the level-1 nodes j, j + 16, ... (an interleaved 1/16 of the sorted cloud).  At the end
+// of a round the minima are combined in LDS (integer atomic min), wave 0 delivers, and the next round starts - all
+// rounds of the tile back to back, three workgroup barriers each.
 struct HardLists {
-  const unsigned long long* ent_in;   // item | sub << 32 | subs << 40 | stop_after_join << 48
-  const unsigned long long* mask_in;  // lanes of the focus samples
-  int32_t* join_in;                   // waves done per entry (zeroed by the producer)
+  const unsigned long long* ent_in;   // item | sub << 32 | subs << 40 | one_round_only << 48
+  const unsigned long long* mask_in;  // lanes of the focus samples of the abandoned round
   const int32_t* cnt_in;
   unsigned long long* ent_out;
   unsigned long long* mask_out;
-  int32_t* join_out;
   int32_t* cnt_out;
   int cap;     // entries per list
-  int budget;  // leaves per round before a round counts as hard (0: never)
-  int parts;
+  int budget;  // scale of the leaf budget of a tile (0: no hard tiles)
 };
 
-template <int DIM>
-__global__ __launch_bounds__(256, 4) void finish_faces_kernel(
+constexpr int TEAM_WAVES = 16;
+
+template <int DIM, bool TEAM>
+__global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, 4) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_sorted,
@@ -62,8 +63,13 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, HardLists hl,
     unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
-  __shared__ float s_lb[4][MAXL][FAN];
-  __shared__ int64_t s_grp[4][MAXL];
+  constexpr int NW = TEAM ? TEAM_WAVES : 4;  // waves of the workgroup
+  __shared__ float s_lb[NW][MAXL][FAN];
+  __shared__ int64_t s_grp[NW][MAXL];
+  // TEAM: the tile being worked on, wave 0's reading of the face maxima, the combined minima of a round
+  __shared__ long long s_titem;
+  __shared__ uint32_t s_tfb[64];
+  __shared__ uint32_t s_tbest[64];
   // the two top levels of the box tree (993 nodes for a million points) live in LDS, shared by the block's waves:
   // every search starts there, and a focus round restarts there - only the leaf groups are fetched from L2
   __shared__ float s_top[TOP_NODES * 2 * DP];
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
   // few items: split each tile over several waves (short tail, tight boxes); many: 64 distinct samples per wave
   int subs = 1;
   int64_t n_base = mode == 1 ? (int64_t)top_count[0] : (int64_t)n_list;  // (top_count: filled by the probe)
-  if (mode == 3) {
+  if constexpr (TEAM) {
     n_base = hl.cnt_in[0];
     if (n_base > hl.cap) n_base = hl.cap;  // (entries that did not fit were finished by their producer)
   }
@@ -86,10 +92,17 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
   if (n_base == 0) return;
   // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
   if (mode < 2 && n_list <= SHORT_LIST) return;
-  const int64_t n_items = n_base * (mode == 3 ? hl.parts : subs);
+  const int64_t n_items = TEAM ? n_base : n_base * subs;
   const int topl = lv.n_levels - 1;
   // (the split of a hard entry is by level-1 node: a tree without that level has no hard entries)
   const bool budgeted = hl.budget > 0 && hl.ent_out != nullptr && topl >= 1;
+  // leaves a tile may evaluate before it counts as hard: hl.budget per flagged tile and wave - a multiple of the
+  // share of the whole list one wave would work off if the tiles were all alike (the last pass evaluates about 25
+  // leaves per tile), so that only tiles that would outlast a balanced pass are split; a short list (a shard of the
+  // simplices) lowers it with the share
+  const int64_t budget_raw = (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * 4);
+  const int budget_min = hl.budget < 64 ? hl.budget : 64;
+  const int budget_eff = (int)(budget_raw < budget_min ? budget_min : (budget_raw > (1 << 20) ? (1 << 20) : budget_raw));
   // stage levels topl (first) and topl - 1 (behind it) when they fit
   const int top_cnt = (int)lv.count[topl];
   const int sub_cnt = topl >= 2 ? (int)lv.count[topl - 1] : 0;    // (level 0 = leaves: fetched per group)
@@ -97,10 +110,10 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
   const int stage_min_lvl = topl >= 1 ? (staged_sub ? topl - 1 : topl) : MAXL;  // levels >= this are read from LDS
   if (topl >= 1) {
     const float* src_top = nodes + lv.off[topl] * 2 * DP;
-    for (int i = threadIdx.x; i < top_cnt * 2 * DP; i += 256) s_top[i] = src_top[i];
+    for (int i = threadIdx.x; i < top_cnt * 2 * DP; i += 64 * NW) s_top[i] = src_top[i];
     if (staged_sub) {
       const float* src_sub = nodes + lv.off[topl - 1] * 2 * DP;
-      for (int i = threadIdx.x; i < staged_sub * 2 * DP; i += 256) s_top[top_cnt * 2 * DP + i] = src_sub[i];
+      for (int i = threadIdx.x; i < staged_sub * 2 * DP; i += 64 * NW) s_top[top_cnt * 2 * DP + i] = src_sub[i];
     }
     __syncthreads();
   }
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
 #define FIN_PHASE(i) do {} while (0)
 #endif
 
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t wave_id = (int64_t)blockIdx.x * NW + wv;
 #ifdef FLOODER_WAVE_END_FIN
   const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_longest = 0, t_item = 0;  // longest single item of this wave (10 ns ticks)
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
   long long g_prev = -1;
   unsigned long long m_prev = 0;
 #endif
-  const bool static_deal = n_items <= (int64_t)gridDim.x * 4;
+  const bool static_deal = !TEAM && n_items <= (int64_t)gridDim.x * 4;
   bool dealt = false;
   for (;;) {
 #ifdef FLOODER_WAVE_END_FIN
@@ -138,7 +151,13 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     }
 #endif
     int64_t g;
-    if (static_deal) {
+    if constexpr (TEAM) {  // one pop for the workgroup
+      __syncthreads();
+      if (threadIdx.x == 0) s_titem = (long long)atomicAdd(queue, 1);
+      __syncthreads();
+      g = (int64_t)s_titem;
+      if (g >= n_items) break;
+    } else if (static_deal) {
       if (dealt || wave_id >= n_items) break;
       dealt = true;
       g = wave_id;
@@ -155,28 +174,26 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     m_prev = 0;
     c_item[0] = n_rounds; c_item[1] = n_leaf_eval; c_item[2] = n_node_test; c_item[3] = n_leaf_test;
 #endif
-    int sub, subs_i = subs, part = -1;
-    int64_t ent_idx = -1;
+    int sub, subs_i = subs;
+    const int part = TEAM ? wv : -1;  // TEAM: this wave's share of the level-1 nodes
     bool stop_after = false;
     unsigned long long fmask = 0ull;
     int64_t s;
     int item;  // global tile id: simplex * tiles + tile
-    if (mode == 3) {
-      ent_idx = g / hl.parts;
-      part = (int)(g % hl.parts);
-      const unsigned long long ent = hl.ent_in[ent_idx];
+    if constexpr (TEAM) {
+      const unsigned long long ent = hl.ent_in[g];
       item = (int)(uint32_t)(ent & 0xffffffffull);
       sub = (int)((ent >> 32) & 0xffull);
       subs_i = (int)((ent >> 40) & 0xffull);
       stop_after = ((ent >> 48) & 1ull) != 0ull;
-      fmask = hl.mask_in[ent_idx];
+      fmask = hl.mask_in[g];
       s = item / tiles;
     } else {
       sub = (int)(g % subs);
       g /= subs;
     }
     const int per_sub = 64 / subs_i;
-    if (mode == 3) {
+    if constexpr (TEAM) {
     } else if (mode == 1) {
       s = top_list[g];
       item = (int)(uint32_t)(top[s] & 0xffffffffull);
@@ -215,9 +232,17 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     auto refresh = [&]() {
       // only the faces some not yet settled sample of the tile lies on are (re)loaded: usually one to three
       uint32_t um = wave_or_u32(done ? 0u : mb);
-      const uint32_t fb = (lane < acc.n_faces && ((um >> lane) & 1u))
-                              ? __hip_atomic_load(acc.face_bits + my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                              : 0xffffffffu;
+      uint32_t fb = 0xffffffffu;
+      if (!TEAM || wv == 0) {
+        if (lane < acc.n_faces && ((um >> lane) & 1u))
+          fb = __hip_atomic_load(acc.face_bits + my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if constexpr (TEAM) {  // one reading for the whole workgroup: its waves must agree on who is live
+        __syncthreads();
+        if (wv == 0) s_tfb[lane] = fb;
+        __syncthreads();
+        fb = s_tfb[lane];
+      }
       if (fb != 0xffffffffu) fb_seen = fb;
       uint32_t thr = 0xffffffffu;
       while (um) {  // (wave-uniform)
@@ -290,7 +315,7 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
           lb = __builtin_fmaf(gap, gap, lb);
         }
         // one wave of several on a hard entry: only its share of the level-1 nodes
-        if (part >= 0 && lvl == 1 && (int)(idx % hl.parts) != part) lb = __builtin_inff();
+        if (TEAM && lvl == 1 && (int)(idx % TEAM_WAVES) != part) lb = __builtin_inff();
       }
       return lb;
     };
@@ -358,13 +383,16 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
     // them alone - a few nearby points instead of a 64-sample tile - while every leaf it evaluates still tightens
     // the bounds of all lanes.  The settled values are delivered, face_bits rises, and most of the remaining
     // samples drop out without a search of their own; whatever is still live forms the next round.
-    bool joined = mode == 3;  // the first round of a hard entry: shared with the other waves on it
+    bool first_round = true;
     bool aborted = false;
     bool on_budget = budgeted;
+    int evals = 0;  // leaves evaluated for this tile (all rounds)
     for (;;) {
-      // (a sample another wave on the entry sees as not live is below its faces' maxima: whatever bound is
-      // delivered for it changes nothing, so the waves need not agree on the live set)
-      bool focus = joined ? (live && ((fmask >> lane) & 1ull) != 0ull) : (live && best >= focus_frac * M);
+      // (TEAM: every wave of the workgroup computes the same focus set from the same minima and face maxima.  An
+      // entry of the top pass asks for one sample only: its first round takes the lanes recorded with the entry.)
+      bool focus = (TEAM && stop_after && first_round) ? (live && ((fmask >> lane) & 1ull) != 0ull)
+                                                       : (live && best >= focus_frac * M);
+      first_round = false;
       float Mf;
       auto rebound = [&]() {
         Mf = wave_max_f32(focus ? best : -1.f);
@@ -385,9 +413,9 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
         s_lb[wv][topl][lane] = lb0;
         if (lane == 0) s_grp[wv][topl] = 0;
       }
-      int since = 0, evals = 0;
+      int since = 0;
       for (;;) {
-        if (joined && !(Mf >= 0.f)) break;
+        if (TEAM && !(Mf >= 0.f)) break;  // (nothing of the focus set is live any more)
         if (lvl > 0) {
           const float lbv = s_lb[wv][lvl][lane];
           const float mn = wave_min_f32(lbv);
@@ -458,26 +486,25 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
         FIN_PHASE(2);  // leaf selection + test
         eval_leaf(c);
         FIN_PHASE(3);  // leaf evaluation
-        if (on_budget && !joined && ++evals > hl.budget) {
+        if (!TEAM && on_budget && ++evals > budget_eff) {
           // a hard round: hand the tile to the next launch (unless its list is full: then carry on alone)
           const unsigned long long fm = __ballot(focus && mine);
           int h = 0;
           if (lane == 0) h = atomicAdd(hl.cnt_out, 1);
           h = wave_uniform(h);
           if (h < hl.cap) {
-            if (mine && !settled) d2[s * (int64_t)R + r] = __float_as_uint(best);  // bounds reached so far
+            if (mine && !settled && !done) d2[s * (int64_t)R + r] = __float_as_uint(best);  // bounds reached so far
             if (lane == 0) {
               hl.ent_out[h] = (unsigned long long)(uint32_t)item | ((unsigned long long)sub << 32) |
                               ((unsigned long long)subs_i << 40) | (mode == 1 ? (1ull << 48) : 0ull);
               hl.mask_out[h] = fm;
-              hl.join_out[h] = 0;
             }
             aborted = true;
             break;
           }
           on_budget = false;
         }
-        if (++since >= refresh_every) {
+        if (!TEAM && ++since >= refresh_every) {  // (TEAM: no workgroup barrier inside a search)
           since = 0;
           refresh();  // other waves may have raised the face maxima meanwhile: focus samples may drop out
           focus = focus && live;
@@ -489,21 +516,18 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
         if (!(Mf >= 0.f)) break;
       }
       if (aborted) break;
-      if (joined) {
-        // ---- a hard entry: minimum over the waves on it, the last one to arrive goes on
-        const bool fl = mine && !settled && ((fmask >> lane) & 1ull) != 0ull;
-        if (fl) atomicMin(&d2[s * (int64_t)R + r], __float_as_uint(best));
-        __threadfence();
-        int old = 0;
-        if (lane == 0) old = atomicAdd(&hl.join_in[ent_idx], 1);
-        old = wave_uniform(old);
-        if (old != hl.parts - 1) break;
-        __threadfence();
-        if (fl) best = __uint_as_float(__hip_atomic_load(&d2[s * (int64_t)R + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        focus = fl;
-        joined = false;
-        part = -1;
-        if (fl) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
+      if constexpr (TEAM) {
+        // ---- minima of the workgroup's waves (each searched its share of the tree) combined in LDS
+        __syncthreads();
+        if (wv == 0) s_tbest[lane] = __float_as_uint(best);
+        __syncthreads();
+        if (wv != 0) atomicMin(&s_tbest[lane], __float_as_uint(best));
+        __syncthreads();
+        best = __uint_as_float(s_tbest[lane]);
+        // a focus sample that some wave dropped on the way is below its faces' maxima: whatever is delivered for
+        // it changes nothing; every other focus sample has been searched by all sixteen and is exact
+        focus = mine && !done && !settled && focus;
+        if (wv == 0 && focus) d2[s * (int64_t)R + r] = __float_as_uint(best) | SETTLED_BIT;
       }
       // ---- deliver the round: focus samples that stayed live to its end are exact (a focus sample that dropped out
       // on the way is below the running maximum of each of its faces: its atomic changes nothing)
@@ -516,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void finish_faces_kernel(
           const uint32_t v = wave_max_u32(((mbm >> f) & 1u) ? __float_as_uint(best) : 0u);
           // (no atomic for a value that cannot raise the maximum: most deliveries of a shared face are such)
           const uint32_t seen = (uint32_t)__builtin_amdgcn_readlane((int)fb_seen, f);
-          if (lane == 0 && v > seen) atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
+          if (lane == 0 && v > seen && (!TEAM || wv == 0)) atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
         }
       }
       done = done || focus;
@@ -612,55 +636,56 @@ struct FinishOp {
                  unsigned long long* hard, int hard_cap, unsigned long long* stats, hipStream_t st) {
     const int grid = g_bvh_grid;
     // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile (filled by the probe -
-    // the cell sweep's when `probed`, else pass 0 here); ctl[4..6]: queue heads of the hard-entry launches,
-    // ctl[7..9]: lengths of the hard lists
+    // the cell sweep's when `probed`, else pass 0 here); the hard-entry launches' words: below
     const bool hard_on = hard != nullptr && hard_cap > 0 && g_finish_budget > 0;
     const bool ordered = flag_key != nullptr && flag_hist != nullptr && flag_sorted != nullptr && g_finish_order != 0;
     if (ordered)
       hipLaunchKernelGGL(order_flags_kernel, dim3(256), dim3(256), 0, st, flag_list, flag_key, flag_count, flag_hist,
                          flag_hist + KEY_BUCKETS, flag_sorted);
-    const int64_t words = (int64_t)hard_cap * 2 + (hard_cap + 1) / 2;  // entries, masks (u64), counters (i32)
+    const int64_t words = (int64_t)hard_cap * 2;  // entries, masks (u64)
     auto list = [&](int which, bool in, int32_t* cnt, HardLists& hl) {
       unsigned long long* base = hard + which * words;
       if (in) {
         hl.ent_in = base;
         hl.mask_in = base + hard_cap;
-        hl.join_in = reinterpret_cast<int32_t*>(base + 2 * (int64_t)hard_cap);
         hl.cnt_in = cnt;
       } else {
         hl.ent_out = base;
         hl.mask_out = base + hard_cap;
-        hl.join_out = reinterpret_cast<int32_t*>(base + 2 * (int64_t)hard_cap);
         hl.cnt_out = cnt;
       }
     };
     auto launch = [&](int mode, int32_t* queue, const HardLists& hl) {
-      hipLaunchKernelGGL((finish_faces_kernel<DIM>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, k1,
-                         R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count, mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct,
-                         (float)g_finish_focus_pct * 0.01f, g_finish_refresh, queue, d2, acc, top, top_list, ctl + 3,
-                         hl, stats);
+      if (mode == 3)  // one workgroup of 16 waves per hard tile, one workgroup per CU
+        hipLaunchKernelGGL((finish_faces_kernel<DIM, true>), dim3(g_bvh_grid / 4), dim3(64 * TEAM_WAVES), 0, st, pts,
+                           nodes, lv, verts, weights, k1, R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count,
+                           mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f,
+                           g_finish_refresh, queue, d2, acc, top, top_list, ctl + 3, hl, stats);
+      else
+        hipLaunchKernelGGL((finish_faces_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                           weights, k1, R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count, mode, g_bvh_subs,
+                           g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, g_finish_refresh,
+                           queue, d2, acc, top, top_list, ctl + 3, hl, stats);
     };
-    const HardLists none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hard_cap, 0,
-                         g_finish_parts};
+    const HardLists none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hard_cap, 0};
     if (!probed) launch(0, ctl + 0, none);
     if (!hard_on) {
       launch(1, ctl + 1, none);
       launch(2, ctl + 2, none);
       return check_launch("finish_faces");
     }
-    HardLists a = none, b = none, c = none, d = none, e = none;
-    a.budget = c.budget = d.budget = g_finish_budget;
-    list(0, false, ctl + 7, a);  // top pass: hard entries -> list 0
+    // ctl: [0..2] queue heads of the probe / top / rest passes, [3] simplices with a top tile, [4], [5] queue head
+    // and list length of the top pass's hard entries, [6], [7] those of the rest pass's
+    HardLists a = none, b = none, c = none, d = none;
+    a.budget = c.budget = g_finish_budget;
+    list(0, false, ctl + 5, a);  // top pass: hard entries -> list 0
     launch(1, ctl + 1, a);
-    list(0, true, ctl + 7, b);   // ... searched by several waves each
+    list(0, true, ctl + 5, b);   // ... one workgroup each (one sample per entry: one round)
     launch(3, ctl + 4, b);
-    list(1, false, ctl + 8, c);  // the other samples: hard entries -> list 1
+    list(1, false, ctl + 7, c);  // the other samples: hard tiles -> list 1
     launch(2, ctl + 2, c);
-    list(1, true, ctl + 8, d);   // ... searched; what is hard among the rest of their tiles -> list 0 again
-    list(0, false, ctl + 9, d);
-    launch(3, ctl + 5, d);
-    list(0, true, ctl + 9, e);   // ... searched, their tiles finished whatever it takes
-    launch(3, ctl + 6, e);
+    list(1, true, ctl + 7, d);   // ... one workgroup each, all their rounds
+    launch(3, ctl + 6, d);
     return check_launch("finish_faces");
   }
 };

@@ -651,10 +651,6 @@ int flooder_set_option(const char* name, int value) {
     g_finish_order = value;
     return FLOODER_OK;
   }
-  if (name && strcmp(name, "finish_parts") == 0 && value >= 1 && value <= 64 && (value & (value - 1)) == 0) {
-    g_finish_parts = value;
-    return FLOODER_OK;
-  }
   if (name && strcmp(name, "curve_bits") == 0 && value >= 0 && value <= 21) {
     g_curve_bits = value;
     return FLOODER_OK;

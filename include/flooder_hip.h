@@ -61,7 +61,7 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32; "curve_bits": bits per axis;
  *   "cell_brute_max": kept points up to which a chunk is evaluated straight from the compacted list (160);
  *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
- *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_parts", "finish_order":
+ *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_order":
  *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
@@ -256,17 +256,17 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Three passes: a probe (one
  * greedy descent per tile: finite upper bounds, and per simplex the tile with the largest one), the top tile of
  * every simplex, then all other tiles.  Face values equal the exhaustive result bit for bit.
- *   ctl: 16 zeroed int32 (queue heads and list lengths; ctl[3] = number of entries of top_list, which the cell
+ *   ctl: 8 zeroed int32 (queue heads and list lengths; ctl[3] = number of entries of top_list, which the cell
  *   sweep's probe may already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64
  *   (zeroed unless probed); top_list: n_simplices int32;
  *   flag_key / flag_hist / flag_sorted: all NULL, or what flooder_sweep_cell_faces_f32 filled plus scratch of the
  *   size of flag_list - a counting sort by descending bound puts the long searches first in the last pass's queue
  *   (option "finish_order" 0 turns it off);
- *   hard_scratch / hard_cap: NULL / 0, or 2 * (2 * hard_cap + (hard_cap + 1) / 2) uint64 of scratch - a round that
- *   evaluates more than option "finish_budget" (512) leaves is abandoned and its tile goes on a list of at most
- *   hard_cap entries; the next launch searches every entry with option "finish_parts" (16) waves, each over an
- *   interleaved share of the level-1 nodes of the box tree, and the last one to arrive delivers (five launches
- *   instead of two; without scratch, or with the budget 0, one wave works every tile off alone);
+ *   hard_scratch / hard_cap: NULL / 0, or 4 * hard_cap uint64 of scratch - a tile that has evaluated more leaves
+ *   than option "finish_budget" (14) times the tiles per wave of the whole list is taken off its wave and put on a
+ *   list of at most hard_cap entries; the next launch gives every such tile to a workgroup of 16 waves, each
+ *   searching an interleaved share of the level-1 nodes of the box tree, the minima combined in LDS round by round
+ *   (four launches instead of two; without scratch, or with the budget 0, one wave works every tile off alone);
  *   stats: NULL or 7 zeroed uint64 {leaves evaluated, leaves tested, nodes expanded, -, tiles dropped on arrival in
  *   the last pass, samples live on arrival in the last pass, -}.
  */

@@ -541,9 +541,9 @@ def test_runs_of_four_chunks_equal_chunk_by_chunk(dev, cloud, monkeypatch):
 
 @pytest.mark.parametrize("cloud", ["torus", "eight2d"])
 def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
-    """The finish's schedule - flagged tiles by descending probe bound, rounds over the leaf budget searched by several
-    waves over interleaved shares of the tree (joined by the last one to arrive) - must not change a single bit of the
-    face values: plain order / one wave per tile against tiny budgets, 4 / 16 / 64 waves per entry and a hard list
+    """The finish's schedule - flagged tiles by descending probe bound, tiles over the leaf budget handed to a
+    workgroup of 16 waves that search interleaved shares of the tree and combine their minima in LDS - must not
+    change a single bit of the face values: plain order / one wave per tile against several budgets and a hard list
     too short for its entries (those are finished by their producer)."""
     lib = _native.load()
     if cloud == "torus":
@@ -560,31 +560,30 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     index = core.PointIndex(pts)
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
 
-    def run(order, budget, parts, cap):
+    def run(order, budget, cap):
         monkeypatch.setattr(core, "FINISH_HARD_CAP", cap)
         try:
-            for name, val in ((b"finish_order", order), (b"finish_budget", budget), (b"finish_parts", parts)):
+            for name, val in ((b"finish_order", order), (b"finish_budget", budget)):
                 assert lib.flooder_set_option(name, val) == 0
             stats.zero_()
             out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
             torch.cuda.synchronize()
             return out.cpu().numpy(), core.LAST_STATS.hard_entries
         finally:
-            for name, val in ((b"finish_order", 1), (b"finish_budget", 512), (b"finish_parts", 16)):
+            for name, val in ((b"finish_order", 1), (b"finish_budget", 14)):
                 lib.flooder_set_option(name, val)
 
-    ref, hard = run(0, 0, 16, 32768)
-    assert hard == (0, 0, 0)
+    ref, hard = run(0, 0, 32768)
+    assert hard == (0, 0)
     unfused_before = core.FUSED_FACES
     monkeypatch.setattr(core, "FUSED_FACES", False)
     plain, _ = core._sweep_dimension_cell(index, verts, weights, faces, None)
     monkeypatch.setattr(core, "FUSED_FACES", unfused_before)
     np.testing.assert_array_equal(ref, plain.cpu().numpy())
     seen = 0
-    for order, budget, parts, cap in ((1, 0, 16, 32768), (1, 4, 16, 32768), (0, 1, 4, 32768), (1, 16, 64, 32768),
-                                      (1, 2, 16, 8), (1, 64, 1, 32768)):
-        got, hard = run(order, budget, parts, cap)
-        np.testing.assert_array_equal(got, ref, err_msg=str((cloud, order, budget, parts, cap)))
+    for order, budget, cap in ((1, 0, 32768), (1, 1, 32768), (0, 1, 32768), (1, 4, 32768), (1, 1, 8), (1, 14, 32768)):
+        got, hard = run(order, budget, cap)
+        np.testing.assert_array_equal(got, ref, err_msg=str((cloud, order, budget, cap)))
         seen += hard[1]
     assert seen > 0, "no round ever exceeded the budget: the hard-entry launches were not exercised"
 

@@ -38,7 +38,7 @@ try:
     d = json.load(open(sys.argv[1]))
     st = d["config"]["sweep_stats_rank0"] or {}
     print(sys.argv[2], "ms/step", d["ms_per_step"], "+-", d["ms_per_step_std"], {k: v["ms_per_step"] for k, v in d["kernels"].items()},
-          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds", "deferred_chunks", "chunks_total")})
+          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds", "deferred_chunks", "chunks_total", "finish_shared_rounds")})
 except Exception as e:
     print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-600:])
 PY
