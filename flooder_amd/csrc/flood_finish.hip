@@ -100,7 +100,9 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, 4) void finish_faces_
   // share of the whole list one wave would work off if the tiles were all alike (the last pass evaluates about 25
   // leaves per tile), so that only tiles that would outlast a balanced pass are split; a short list (a shard of the
   // simplices) lowers it with the share
-  const int64_t budget_raw = (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * 4);
+  // (top pass: one point query per simplex and about one query per wave - the pass lasts as long as its longest
+  // query, so the budget is a fixed few dozen leaves)
+  const int64_t budget_raw = mode == 1 ? (int64_t)hl.budget * 4 : (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * 4);
   const int budget_min = hl.budget < 64 ? hl.budget : 64;
   const int budget_eff = (int)(budget_raw < budget_min ? budget_min : (budget_raw > (1 << 20) ? (1 << 20) : budget_raw));
   // stage levels topl (first) and topl - 1 (behind it) when they fit
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(256) void order_flags_kernel(const int32_t* __restr
                                                           const int32_t* __restrict__ hist,
                                                           int32_t* __restrict__ cursor,
                                                           int32_t* __restrict__ flag_sorted) {
-  __shared__ int s_base[KEY_BUCKETS];
+  __shared__ int s_base[KEY_BUCKETS];  // start of the bucket in the sorted list, then of this block's share of it
+  __shared__ int s_cnt[KEY_BUCKETS];   // this block's entries per bucket, then its running fill
   __shared__ int s_part[256];
   const int n = flag_count[0];
   if (n <= SHORT_LIST) return;
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(256) void order_flags_kernel(const int32_t* __restr
   for (int u = 0; u < PER; ++u) {
     own[u] = hist[KEY_BUCKETS - 1 - (threadIdx.x * PER + u)];
     sum += own[u];
+    s_cnt[threadIdx.x * PER + u] = 0;
   }
   s_part[threadIdx.x] = sum;
   __syncthreads();
@@ -615,9 +619,23 @@ __global__ __launch_bounds__(256) void order_flags_kernel(const int32_t* __restr
     run += own[u];
   }
   __syncthreads();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  // the block's contiguous share of the list: count per bucket in LDS, ONE global atomic per bucket the block has
+  // entries in (the bounds crowd into a few dozen buckets: an atomic per entry would queue up on those words),
+  // then scatter
+  const int per_block = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int i0 = blockIdx.x * per_block;
+  const int i1 = i0 + per_block < n ? i0 + per_block : n;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) atomicAdd(&s_cnt[flag_key[i] >> 19], 1);
+  __syncthreads();
+  for (int b = threadIdx.x; b < KEY_BUCKETS; b += 256) {
+    const int c = s_cnt[b];
+    if (c > 0) s_base[b] += atomicAdd(&cursor[b], c);
+    s_cnt[b] = 0;
+  }
+  __syncthreads();
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const int b = (int)(flag_key[i] >> 19);
-    flag_sorted[s_base[b] + atomicAdd(&cursor[b], 1)] = flag_list[i];
+    flag_sorted[s_base[b] + atomicAdd(&s_cnt[b], 1)] = flag_list[i];
   }
 }
 

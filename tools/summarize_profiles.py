@@ -42,21 +42,24 @@ json.dump(out, open(f"profiles/{name}_pmc.json", "w"), indent=1)
 traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
 sha = kernel_source_sha()
 # span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
-SPANS = (("cell", "sweep", ("cell_sweep_kernel<3, true>", "cell_sweep_kernel<3, false>"), 1),
-         ("cell", "fallback", ("finish_faces_kernel<3>",), 2),     # two passes (launches) per step
-         ("bvh", "sweep", ("sweep_bvh_kernel<3, 2, 1>",), 1), ("ball", "sweep", ("sweep_kernel<3, true>",), 1))
-for method, span, kerns, per_step in SPANS:
-    have = [k for k in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
+# (method, span, ((kernel, launches per step), ...))
+SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true>", 1), ("cell_sweep_kernel<3, false>", 1))),
+         # top pass + rest pass, the hard tiles of either (one workgroup each), the ordering of the flagged tiles
+         ("cell", "fallback", (("finish_faces_kernel<3, false>", 2), ("finish_faces_kernel<3, true>", 2),
+                               ("order_flags_kernel", 1))),
+         ("bvh", "sweep", (("sweep_bvh_kernel<3, 2, 1>", 1),)), ("ball", "sweep", (("sweep_kernel<3, true>", 1),)))
+for method, span, kerns, in SPANS:
+    have = [(k, m) for k, m in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
     if not have:
         continue
-    f = sum(out[k]["FETCH_SIZE_mean_per_launch"] for k in have) * per_step
-    w = sum(out[k].get("WRITE_SIZE_mean_per_launch", 0.0) for k in have) * per_step
-    ent = {"kernels": have, "launches_per_step": per_step * len(have), "fetch_size_kb": round(f, 1),
+    f = sum(out[k]["FETCH_SIZE_mean_per_launch"] * m for k, m in have)
+    w = sum(out[k].get("WRITE_SIZE_mean_per_launch", 0.0) * m for k, m in have)
+    ent = {"kernels": [k for k, _ in have], "launches_per_step": sum(m for _, m in have), "fetch_size_kb": round(f, 1),
            "write_size_kb": round(w, 1), "fetch_correction": 2.0, "bytes_per_launch": int((2.0 * f + w) * 1024),
            "bytes_note": "HBM bytes per step of this span: sum over its launches of 2 x FETCH_SIZE + WRITE_SIZE",
            "source": f"profiles/{name}_pmc.json", "kernel_src_sha": sha}
-    us = sum(out[k].get("avg_duration_us_kernel_trace", 0.0) for k in have) * per_step
-    valu = sum(out[k].get("SQ_INSTS_VALU_mean_per_launch", 0.0) for k in have) * per_step
+    us = sum(out[k].get("avg_duration_us_kernel_trace", 0.0) * m for k, m in have)
+    valu = sum(out[k].get("SQ_INSTS_VALU_mean_per_launch", 0.0) * m for k, m in have)
     if us and valu:
         ent["issue_util"] = round(valu * 2.0 / (1024 * us * 1e-6 * 2.4e9), 4)
         ent["valu_wave_instructions"] = valu
