@@ -281,11 +281,13 @@ def main():
         index = build_index(timer)
         st = stats if with_stats else None
         if args.method == "cell":
-            stats.zero_()
+            if st is not None:
+                stats.zero_()
             out, _ = core._sweep_dimension_cell(index, verts, weights, faces, hook, timer=timer, stats=st, plan=plan,
                                                 face_slots=None if slots is None else slots[:2])
         elif args.method == "bvh":
-            stats.zero_()
+            if st is not None:
+                stats.zero_()
             out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer,
                                                stats=None if st is None else st[:4], plan=plan)
         else:

@@ -757,10 +757,12 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # [0] sweep queue, [1] flag count, [12] deferred chunks, [13] their queue, [14:17] light / heavy simplices,
         # lists on; [24:48] finish (queue heads, [27] top count, [29], [31] hard tiles of the top / rest pass);
         # [48:] histogram of the flagged tiles' bounds and the cursors of the finish's counting sort
-        ctl = torch.zeros(48 + 8192, dtype=torch.int32, device=dev)
+        # (one zero fill for everything that starts at zero: top | ctl | face_bits)
+        zeroed = torch.zeros(2 * S + 48 + 8192 + n_slots, dtype=torch.int32, device=dev)
+        top = zeroed[:2 * S].view(torch.int64)
+        ctl = zeroed[2 * S:2 * S + 48 + 8192]
+        face_bits = zeroed[2 * S + 48 + 8192:]
         hard = torch.empty(4 * FINISH_HARD_CAP, dtype=torch.int64, device=dev)
-        face_bits = torch.zeros(n_slots, dtype=torch.int32, device=dev)
-        top = torch.zeros(S, dtype=torch.int64, device=dev)
         top_list = torch.empty(S, dtype=torch.int32, device=dev)
         d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
         flags = torch.empty((3, S * tiles), dtype=torch.int32, device=dev)  # flagged tiles, their bounds, ordered
