@@ -56,6 +56,12 @@ struct GatherOp {
 
 }  // namespace
 
+// rocprim sorts up to 2^20 keys by merge sort: a block sort and ten merge passes of two launches each - 21 launches,
+// 150 us for the million points of cfg 2.  The onesweep radix sort (a histogram launch and one launch per 8 bits) is
+// what it uses above that size and is the faster one from a tenth of it on.
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
+                                           (size_t)128 * 1024>;
+
 extern "C" {
 
 int64_t flooder_index_sort_bytes(int64_t n_pts) {
@@ -64,7 +70,7 @@ int64_t flooder_index_sort_bytes(int64_t n_pts) {
   const uint64_t* k = nullptr;
   uint64_t* ko = nullptr;
   uint32_t* vo = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, ko, rocprim::counting_iterator<uint32_t>(0u), vo,
+  hipError_t e = rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, k, ko, rocprim::counting_iterator<uint32_t>(0u), vo,
                                            (size_t)n_pts, 0u, 64u, (hipStream_t)0);
   if (e != hipSuccess) return -1;
   return (int64_t)bytes + 256;
@@ -78,12 +84,12 @@ int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_
   size_t bytes = (size_t)tmp_bytes;
   hipError_t e;
   if (key_bits <= 32)  // narrow keys: flooder_morton_f32 wrote n uint32 words
-    e = rocprim::radix_sort_pairs(tmp, bytes, reinterpret_cast<const uint32_t*>(codes),
+    e = rocprim::radix_sort_pairs<SortCfg>(tmp, bytes, reinterpret_cast<const uint32_t*>(codes),
                                   reinterpret_cast<uint32_t*>(codes_sorted), rocprim::counting_iterator<uint32_t>(0u),
                                   reinterpret_cast<uint32_t*>(order), (size_t)n_pts, 0u, (unsigned)key_bits,
                                   (hipStream_t)stream);
   else
-    e = rocprim::radix_sort_pairs(tmp, bytes, reinterpret_cast<const uint64_t*>(codes),
+    e = rocprim::radix_sort_pairs<SortCfg>(tmp, bytes, reinterpret_cast<const uint64_t*>(codes),
                                   reinterpret_cast<uint64_t*>(codes_sorted), rocprim::counting_iterator<uint32_t>(0u),
                                   reinterpret_cast<uint32_t*>(order), (size_t)n_pts, 0u, (unsigned)key_bits,
                                   (hipStream_t)stream);

@@ -154,7 +154,7 @@ int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const f
                        void* stream);
 
 /* Number of low bits a curve code of flooder_morton_f32 occupies for ambient dimension dim (bits per axis x dim;
- * option "curve_bits": bits per axis, default 10 in 3D, 16 in 2D, 12 above, at most floor(63 / dim) and 21).  When
+ * option "curve_bits": bits per axis, default 8 in 3D, 12 elsewhere, at most floor(63 / dim) and 21).  When
  * this is <= 32 the `codes` buffers of flooder_morton_f32 / flooder_index_sort hold n uint32 words (in the first
  * half of the n x int64 allocation), else n int64 words. */
 int flooder_curve_key_bits(int dim);
