@@ -763,7 +763,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
             q = q_first + sub;
             if (sub != n_sub - 1) make_samples();
+            PHASE(1);
             brute_eval();
+            PHASE(9);
             bool any_open = false;
 #pragma unroll
             for (int i = 0; i < SPL; ++i) {
@@ -1018,8 +1020,11 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
           q = q_first + sub;
           if (sub != n_sub - 1) make_samples();
+          PHASE(1);
           const bool ao = query_cells();
+          PHASE(8);
           finalize_sub(ao, c);
+          PHASE(10);
         }
         sc_done = true;
         wave_lds_sync();
