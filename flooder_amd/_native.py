@@ -39,6 +39,7 @@ SIGNATURES = {
     "flooder_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_bvh_node_count": (c_int64, [c_int64]),
     "flooder_bvh_build_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "flooder_index_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -492,13 +492,12 @@ class PointIndex:
                                                  tmp_bytes, st), "flooder_index_sort")
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
         self.pts = torch.empty((n_pad, self.dp), dtype=torch.float32, device=dev)
-        _native.check(lib.flooder_gather_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
-                                                  _native.ptr(self.pts), n_pad, st), "flooder_gather_rows_f32")
         n_nodes = int(lib.flooder_bvh_node_count(n))
         self.nodes = torch.empty((n_nodes, 2 * self.dp), dtype=torch.float32, device=dev)
-        with _span(timer, "bvh_build"):
-            _native.check(lib.flooder_bvh_build_f32(_native.ptr(self.pts), n, dim, _native.ptr(self.nodes), st),
-                          "flooder_bvh_build_f32")
+        with _span(timer, "bvh_build"):  # rows in curve order + leaf boxes in one pass, then the inner levels
+            _native.check(lib.flooder_index_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
+                                                     _native.ptr(self.pts), n_pad, _native.ptr(self.nodes), st),
+                          "flooder_index_rows_f32")
 
 
 def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.ndarray], device):

@@ -207,6 +207,59 @@ __global__ __launch_bounds__(256) void bvh_leaf_kernel(const float* __restrict__
   for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
 }
 
+// Gather of the cloud into curve order AND the leaf boxes in one pass: lane j writes row j (padded, +inf beyond the
+// cloud), and the 16 lanes of a leaf reduce its box while the row is still in registers (the separate leaf kernel
+// re-read the 256 MB of a 16 M-point cloud).  Rows beyond n_pad exist only as empty leaves (levels are padded to x64).
+template <int DIM>
+__global__ __launch_bounds__(256) void gather_leaf_kernel(const float* __restrict__ pts, int64_t n, int ld,
+                                                          const uint32_t* __restrict__ order,
+                                                          float* __restrict__ out, int64_t n_pad, int64_t n_rows_all,
+                                                          float* __restrict__ leaves) {
+  constexpr int DP = padded_dim(DIM);
+  static_assert(LEAF == 16, "one DPP row of 16 lanes per leaf");
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_rows_all; j += stride) {
+    float x[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = j < n ? 0.f : __builtin_inff();  // pad rows: +inf (never a nearest neighbour)
+    if (j < n) {
+      const int64_t src = (int64_t)order[j];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) x[k] = pts[src * ld + k];
+    }
+    if (j < n_pad) {
+      float* dst = out + j * DP;
+      if constexpr (DP == 2) {
+        *reinterpret_cast<float2*>(dst) = make_float2(x[0], x[1]);
+      } else if constexpr (DP == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      }
+    }
+    float lo[DP], hi[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      lo[k] = (j < n && k < DIM) ? x[k] : __builtin_inff();
+      hi[k] = (j < n && k < DIM) ? x[k] : -__builtin_inff();
+    }
+#pragma unroll
+    for (int o = 1; o < LEAF; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], o));
+        hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], o));
+      }
+    }
+    if ((threadIdx.x & (LEAF - 1)) == 0) {
+      float* dst = leaves + (j / LEAF) * 2 * DP;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+    }
+  }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void bvh_inner_kernel(const float* __restrict__ child, int64_t n_child,
                                                         int64_t n_nodes_pad, float* __restrict__ nodes) {
@@ -688,6 +741,26 @@ struct BuildOp {
 };
 
 template <int DIM>
+struct IndexRowsOp {
+  static int run(const float* pts, int64_t n, int ld, const uint32_t* order, float* rows, int64_t n_pad,
+                 const Levels& lv, float* nodes, hipStream_t st) {
+    constexpr int DP = padded_dim(DIM);
+    const int64_t pad0 = (lv.count[0] + FAN - 1) / FAN * FAN;  // leaves incl. the empty ones that fill the level
+    const int64_t n_rows_all = pad0 * LEAF;
+    int64_t blocks = (n_rows_all + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((gather_leaf_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, order, rows, n_pad,
+                       n_rows_all, nodes + lv.off[0] * 2 * DP);
+    for (int l = 1; l < lv.n_levels; ++l) {
+      int64_t pad = (lv.count[l] + FAN - 1) / FAN * FAN;
+      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 3) / 4)), dim3(256), 0, st,
+                         nodes + lv.off[l - 1] * 2 * DP, lv.count[l - 1], pad, nodes + lv.off[l] * 2 * DP);
+    }
+    return check_launch("index_rows");
+  }
+};
+
+template <int DIM>
 struct SweepBvhOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, int32_t* queue, uint32_t* out,
@@ -756,6 +829,15 @@ int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const f
 int flooder_curve_key_bits(int dim) {
   if (dim < 1 || dim > FLOODER_MAX_DIM) return 0;
   return curve_bits_per_axis(dim) * dim;
+}
+
+int flooder_index_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* rows,
+                           int64_t n_pad, float* nodes, void* stream) {
+  if (!pts || !order || !rows || !nodes || n_pts < 1 || n_pad < n_pts || ld < dim)
+    return fail(FLOODER_E_ARG, "flooder_index_rows_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<IndexRowsOp>(dim, pts, n_pts, ld, reinterpret_cast<const uint32_t*>(order), rows, n_pad, lv,
+                                   nodes, (hipStream_t)stream);
 }
 
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream) {

@@ -179,6 +179,11 @@ int64_t flooder_bvh_node_count(int64_t n_pts);
  * x 2 x padded_dim floats (box lo then hi per node). */
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream);
 
+/* flooder_gather_rows_f32 + flooder_bvh_build_f32 in one call: the rows are written in curve order and the leaf boxes
+ * are reduced from them while they are in registers (one pass over the cloud instead of two), then the inner levels. */
+int flooder_index_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* rows,
+                           int64_t n_pad, float* nodes, void* stream);
+
 /* Sweep: out_d2[s, r] = bits(min over all points of |p(s,r) - x|^2) with p as in flooder_sweep_f32.
  * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or four
  * zeroed uint64 counters {leaves evaluated, leaves tested, inner nodes expanded, most tests by one item}. */

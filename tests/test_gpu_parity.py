@@ -588,6 +588,25 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     assert seen > 0, "no round ever exceeded the budget: the hard-entry launches were not exercised"
 
 
+@pytest.mark.parametrize("n,dim", [(1, 3), (17, 3), (1000, 2), (100_003, 3), (65_536, 3), (20_001, 6)])
+def test_fused_index_rows_equal_gather_then_build(dev, n, dim):
+    """flooder_index_rows_f32 (rows gathered into curve order, leaf boxes reduced from the rows in registers, inner
+    levels) against the two separate entry points: identical rows and identical boxes on every level, padding included."""
+    lib = _native.load()
+    g = torch.Generator().manual_seed(n + dim)
+    pts = torch.randn((n, dim), generator=g).to(dev)
+    index = core.PointIndex(pts)
+    st = _native.current_stream_ptr(dev)
+    rows = torch.empty_like(index.pts)
+    nodes = torch.full_like(index.nodes, float("nan"))
+    _native.check(lib.flooder_gather_rows_f32(_native.ptr(pts), n, dim, dim, _native.ptr(index.order32),
+                                              _native.ptr(rows), rows.shape[0], st), "flooder_gather_rows_f32")
+    _native.check(lib.flooder_bvh_build_f32(_native.ptr(rows), n, dim, _native.ptr(nodes), st), "flooder_bvh_build_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(rows.view(torch.int32), index.pts.view(torch.int32))
+    assert torch.equal(nodes.view(torch.int32), index.nodes.view(torch.int32))
+
+
 def test_index_sort_is_a_stable_sort(dev):
     """flooder_index_sort (radix sort over the used key bits; uint32 words for keys of at most 32 bits) against torch's
     stable sort: identical permutations, duplicates included."""
