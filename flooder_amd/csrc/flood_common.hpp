@@ -31,6 +31,7 @@ extern int g_curve_bits;
 extern int g_cell_exh_tries;
 extern int g_finish_items_cap;
 extern int g_finish_budget;  // scale of the leaf budget beyond which a tile of the finish counts as hard (0: off)
+extern int g_finish_top;     // 1: the finish settles one sample per simplex (its largest bound) before everything else
 extern int g_finish_order;   // 1: the finish works the flagged tiles off by descending probe bound
 extern int g_fps_switch;
 extern int g_fps_rpl;

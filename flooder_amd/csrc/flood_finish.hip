@@ -688,7 +688,7 @@ struct FinishOp {
     const HardLists none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hard_cap, 0};
     if (!probed) launch(0, ctl + 0, none);
     if (!hard_on) {
-      launch(1, ctl + 1, none);
+      if (g_finish_top) launch(1, ctl + 1, none);
       launch(2, ctl + 2, none);
       return check_launch("finish_faces");
     }
@@ -696,10 +696,12 @@ struct FinishOp {
     // and list length of the top pass's hard entries, [6], [7] those of the rest pass's
     HardLists a = none, b = none, c = none, d = none;
     a.budget = c.budget = g_finish_budget;
-    list(0, false, ctl + 5, a);  // top pass: hard entries -> list 0
-    launch(1, ctl + 1, a);
-    list(0, true, ctl + 5, b);   // ... one workgroup each (one sample per entry: one round)
-    launch(3, ctl + 4, b);
+    if (g_finish_top) {
+      list(0, false, ctl + 5, a);  // top pass: hard entries -> list 0
+      launch(1, ctl + 1, a);
+      list(0, true, ctl + 5, b);   // ... one workgroup each (one sample per entry: one round)
+      launch(3, ctl + 4, b);
+    }
     list(1, false, ctl + 7, c);  // the other samples: hard tiles -> list 1
     launch(2, ctl + 2, c);
     list(1, true, ctl + 7, d);   // ... one workgroup each, all their rounds

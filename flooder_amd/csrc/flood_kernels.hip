@@ -647,6 +647,10 @@ int flooder_set_option(const char* name, int value) {
     g_finish_budget = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "finish_top") == 0 && (value == 0 || value == 1)) {
+    g_finish_top = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "finish_order") == 0 && (value == 0 || value == 1)) {
     g_finish_order = value;
     return FLOODER_OK;

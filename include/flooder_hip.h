@@ -61,7 +61,7 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32; "curve_bits": bits per axis;
  *   "cell_brute_max": kept points up to which a chunk is evaluated straight from the compacted list (160);
  *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
- *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_order":
+ *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_order", "finish_top":
  *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
@@ -258,9 +258,10 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
  * exceed the running maximum of every face it lies on cannot change a result and is dropped; the others are
- * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Three passes: a probe (one
- * greedy descent per tile: finite upper bounds, and per simplex the tile with the largest one), the top tile of
- * every simplex, then all other tiles.  Face values equal the exhaustive result bit for bit.
+ * traversed exactly (box tree, nearest first) and delivered with integer atomic max.  Passes: a probe (one greedy
+ * descent per tile: finite upper bounds, and per simplex the tile with the largest one; skipped when the cell sweep
+ * did it), optionally ("finish_top" 1) the top tile of every simplex, then all tiles, largest bound first.  Face
+ * values equal the exhaustive result bit for bit.
  *   ctl: 8 zeroed int32 (queue heads and list lengths; ctl[3] = number of entries of top_list, which the cell
  *   sweep's probe may already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64
  *   (zeroed unless probed); top_list: n_simplices int32;

@@ -542,8 +542,8 @@ def test_runs_of_four_chunks_equal_chunk_by_chunk(dev, cloud, monkeypatch):
 @pytest.mark.parametrize("cloud", ["torus", "eight2d"])
 def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     """The finish's schedule - flagged tiles by descending probe bound, tiles over the leaf budget handed to a
-    workgroup of 16 waves that search interleaved shares of the tree and combine their minima in LDS - must not
-    change a single bit of the face values: plain order / one wave per tile against several budgets and a hard list
+    workgroup of 16 waves that search interleaved shares of the tree and combine their minima in LDS, with or without
+    the top pass (one sample per simplex first) - must not change a single bit of the face values: plain order / one wave per tile against several budgets and a hard list
     too short for its entries (those are finished by their producer)."""
     lib = _native.load()
     if cloud == "torus":
@@ -560,17 +560,17 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     index = core.PointIndex(pts)
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
 
-    def run(order, budget, cap):
+    def run(order, budget, cap, top=0):
         monkeypatch.setattr(core, "FINISH_HARD_CAP", cap)
         try:
-            for name, val in ((b"finish_order", order), (b"finish_budget", budget)):
+            for name, val in ((b"finish_order", order), (b"finish_budget", budget), (b"finish_top", top)):
                 assert lib.flooder_set_option(name, val) == 0
             stats.zero_()
             out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
             torch.cuda.synchronize()
             return out.cpu().numpy(), core.LAST_STATS.hard_entries
         finally:
-            for name, val in ((b"finish_order", 1), (b"finish_budget", 14)):
+            for name, val in ((b"finish_order", 1), (b"finish_budget", 14), (b"finish_top", 0)):
                 lib.flooder_set_option(name, val)
 
     ref, hard = run(0, 0, 32768)
@@ -581,9 +581,10 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     monkeypatch.setattr(core, "FUSED_FACES", unfused_before)
     np.testing.assert_array_equal(ref, plain.cpu().numpy())
     seen = 0
-    for order, budget, cap in ((1, 0, 32768), (1, 1, 32768), (0, 1, 32768), (1, 4, 32768), (1, 1, 8), (1, 14, 32768)):
-        got, hard = run(order, budget, cap)
-        np.testing.assert_array_equal(got, ref, err_msg=str((cloud, order, budget, cap)))
+    for order, budget, cap, top in ((1, 0, 32768, 0), (1, 1, 32768, 0), (0, 1, 32768, 0), (1, 4, 32768, 1), (1, 1, 8, 0),
+                                    (1, 14, 32768, 0), (0, 0, 32768, 1), (1, 1, 32768, 1)):
+        got, hard = run(order, budget, cap, top)
+        np.testing.assert_array_equal(got, ref, err_msg=str((cloud, order, budget, cap, top)))
         seen += hard[1]
     assert seen > 0, "no round ever exceeded the budget: the hard-entry launches were not exercised"
 
