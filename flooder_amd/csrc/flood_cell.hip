@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
    
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
+    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int retry_pct, int retry_keep, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl) {
   constexpr int DP = padded_dim(DIM);
@@ -602,6 +602,26 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     }
     };
     // SUPER: a chunk is done after its one query; with open samples left it is parked and deferred (next cell size 2c)
+    // Is a second try at twice the cell size worth it?  (Per-chunk launch only: a run of four defers its open chunks
+    // as before.)  An open sample whose minimum over the staged points lies within 2c is certain to settle then; one
+    // that has seen nothing nearer (or nothing at all: far field) most likely stays open and costs a second gather,
+    // classification and query before the finish gets it anyway; and where the first try already kept hundreds of
+    // points the second keeps thousands, while the finish's search for a sample in such a dense place is short.
+    // Retry when the try kept at most retry_keep points and at least retry_pct percent of the open samples are of the
+    // first kind (0: whatever they are).
+    int kept_last = 0;  // points the last attempt kept per chunk (the next one keeps several times as many)
+    auto retry_pays = [&](float c_now) -> bool {
+      if (kept_last > retry_keep) return false;
+      if (retry_pct <= 0) return true;
+      const float lim = (1.998f * c_now) * (1.998f * c_now);
+      int n_open = 0, n_near = 0;
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) {
+        n_open += __popcll(__ballot(open[i]));
+        n_near += __popcll(__ballot(open[i] && best[i] <= lim));
+      }
+      return n_near * 100 >= n_open * retry_pct;
+    };
     auto finalize_sub = [&](bool any_open_lane, float c_now) {
       const bool any = __ballot(any_open_lane) != 0ull;
       finalize(any);
@@ -721,6 +741,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
                ((unsigned long long)(n_keep > CAPW) << 44);
       d_tb = 0;
 #endif
+      kept_last = n_keep;
       const float c_ok = (0.999f * c) * (0.999f * c);
       // Exhaustive evaluation pays when the kept points really are the samples' neighbours (a chunk box full
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
@@ -792,6 +813,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         PHASE(8);
         if (__ballot(any_open) == 0ull) break;
         if (attempt == max_tries - 1) ++g_tries;
+        if (!retry_pays(c)) break;
         c *= 2.f;
         continue;
       }
@@ -883,6 +905,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         PHASE(9);
         if (__ballot(any_open) == 0ull) break;
         if (attempt == max_tries - 1) ++g_tries;
+        if (!retry_pays(c)) break;
         c *= 2.f;
         continue;
       }
@@ -1034,6 +1057,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       PHASE(8);
       if (__ballot(any_open) == 0ull) break;
       if (attempt == max_tries - 1) ++g_tries;
+      if (!retry_pays(c)) break;
       c *= 2.f;
     }
 
@@ -1108,14 +1132,14 @@ struct CellOp {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, true>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, acc, dl);
+                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list, flag_count, stats, acc, dl);
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue2, out, flag_list, flag_count, stats, acc, dl);
+                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue2, out, flag_list, flag_count, stats, acc, dl);
       } else {
         hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                            k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, queue, out, flag_list, flag_count, stats, acc, dl);
+                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list, flag_count, stats, acc, dl);
       }
       return check_launch("cell_sweep");
     } else {

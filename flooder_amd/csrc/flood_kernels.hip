@@ -651,6 +651,14 @@ int flooder_set_option(const char* name, int value) {
     g_finish_top = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_retry_keep") == 0 && value >= 0) {
+    g_cell_retry_keep = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_retry_pct") == 0 && value >= 0) {
+    g_cell_retry_pct = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "finish_order") == 0 && (value == 0 || value == 1)) {
     g_finish_order = value;
     return FLOODER_OK;

@@ -60,6 +60,9 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *                     by the work-list tree sweep (1, or 4 through LDS);
  *   "curve": 1 (default) Hilbert, 0 Morton order of the cloud in flooder_morton_f32; "curve_bits": bits per axis;
  *   "cell_brute_max": kept points up to which a chunk is evaluated straight from the compacted list (160);
+ *   "cell_retry_keep" / "cell_retry_pct": a chunk of the per-chunk launch gets its second cell size only if the first
+ *                     try kept at most this many points (200) and this share of its open samples has a point within
+ *                     twice the cell size (50 %; 0: whatever they are) - else its open tiles go to the finish;
  *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
  *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_order", "finish_top":
  *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
