@@ -275,7 +275,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  *   than option "finish_budget" (14) times the tiles per wave of the whole list is taken off its wave and put on a
  *   list of at most hard_cap entries; the next launch gives every such tile to a workgroup of 16 waves, each
  *   searching an interleaved share of the level-1 nodes of the box tree, the minima combined in LDS round by round
- *   (four launches instead of two; without scratch, or with the budget 0, one wave works every tile off alone);
+ *   (one more launch; without scratch, or with the budget 0, one wave works every tile off alone);
  *   stats: NULL or 7 zeroed uint64 {leaves evaluated, leaves tested, nodes expanded, -, tiles dropped on arrival in
  *   the last pass, samples live on arrival in the last pass, -}.
  */
