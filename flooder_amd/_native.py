@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libflooder_hip.so")
 
 _lib = None
 _load_error: Exception | None = None
+_load_missing = False  # the last failure was "file not found" (worth another look after a build)
 
 # name -> (restype, argtypes); the single source the symbol test checks against the header
 SIGNATURES = {
@@ -74,15 +75,20 @@ SIGNATURES = {
 
 def load():
     """Load the library once (after torch, so both share one HIP runtime) and type its symbols."""
-    global _lib, _load_error
+    global _lib, _load_error, _load_missing
     if _lib is not None:
         return _lib
     if _load_error is not None:
-        raise ImportError(str(_load_error)) from _load_error
+        # (a library that was missing may have been built since - __graft_entry__.build() imports the package
+        # before it compiles: look again; any other failure stays cached)
+        if not (_load_missing and os.path.exists(LIB_PATH)):
+            raise ImportError(str(_load_error)) from _load_error
+        _load_error = None
     try:
         import torch  # noqa: F401  (loads libamdhip64.so.7 first; our DT_NEEDED resolves to it)
 
-        if not os.path.exists(LIB_PATH):
+        _load_missing = not os.path.exists(LIB_PATH)
+        if _load_missing:
             raise OSError(f"{LIB_PATH} not found")
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
