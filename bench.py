@@ -47,11 +47,20 @@ WORKLOADS = {
                       "configs[4]; cloud resident in HBM: 256 MB of 288 GB - host-pinned streaming is not needed, "
                       "the H2D copy is reported as h2d_ms)",
                  gen="cheese", n=16_000_000, dim=3, n_lms=4000, ppe=30),
+    # BASELINE.json configs[3]: the tractable setting of SURVEY.md 8d (max_dimension 2, points_per_edge 8); the
+    # sweep runs over the 1.2 M Delaunay triangles of the 2000 landmarks (Qhull's 6-D triangulation: ~8 s, untimed)
+    "cfg4": dict(desc="2M-point 6D Gaussian, 2k landmarks, max_dimension 2, points_per_edge 8, fp32 coverage sweep "
+                      "of the Delaunay triangles (BASELINE.json configs[3])",
+                 gen="gauss", n=2_000_000, dim=6, n_lms=2000, ppe=8, max_dim=2, method="bvh", p_sample=2048,
+                 cpu_sample=1500),
     "small": dict(desc="100k-point 3D Gaussian, 300 landmarks, points_per_edge 12 (debug)",
                   gen="gauss", n=100_000, dim=3, n_lms=300, ppe=12),
+    "small6d": dict(desc="100k-point 6D Gaussian, 150 landmarks, max_dimension 2, points_per_edge 8 (debug)",
+                    gen="gauss", n=100_000, dim=6, n_lms=150, ppe=8, max_dim=2, method="bvh", p_sample=2048,
+                    cpu_sample=400),
 }
 
-KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
+KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "sweep_bvh": "sweep_bvh_kernel", "sweep_ball": "sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
                   "face_max": "face_values_kernel", "reduce": "all_reduce(MIN)",
                   "index": "index build (bbox, curve codes, rocprim radix sort, gather, box tree)",
                   "ball_count": "ball_scan_kernel<count>", "ball_fill": "ball_scan_kernel<fill>"}
@@ -94,14 +103,17 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="simplices in the 1-core CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="simplices in the 1-core CPU baseline sample (default: 1200, or the workload's own)")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the workers=-1 leg of the CPU baseline")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache steps (512 MB flush before each)")
     ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
     ap.add_argument("--emulate-shard", default=None, metavar="r/W",
                     help="diagnostic (N=1 only): time rank r's share of a W-rank simplex-sharded step, no collective")
     ap.add_argument("--alpha", type=float, default=None, help="cell size of the cell sweep in units of the local spacing")
-    ap.add_argument("--method", default="cell", choices=["cell", "bvh", "ball"],
+    ap.add_argument("--method", default=None, choices=["cell", "bvh", "ball"],
                     help="cell: LDS cell-grid sweep + exact tree finish (default); bvh: box-tree culled sweep; "
                          "ball: the reference's formulation")
     ap.add_argument("--order", default="axis", choices=["axis", "ball", "weight", "axis_rev", "random", "middle_out", "ends_in"],
@@ -178,6 +190,10 @@ def main():
     if args.units:
         core.SAMPLE_UNITS = tuple(int(v) for v in args.units.split("/"))
     w = WORKLOADS[args.workload]
+    if args.method is None:
+        args.method = w.get("method", "cell")
+    if args.cpu_sample is None:
+        args.cpu_sample = w.get("cpu_sample", 1200)
     # ------------------------------------------------------------------ untimed setup
     pts_cpu = make_points(w)
     torch.cuda.synchronize()
@@ -185,14 +201,25 @@ def main():
     pts_full = pts_cpu.to(dev)
     torch.cuda.synchronize()
     h2d_ms = (time.perf_counter() - t_h0) * 1e3     # pageable host memory -> HBM, once per call (not in the step)
-    fa.generate_landmarks(pts_full, 8, start_idx=0)  # warm-up
-    torch.cuda.synchronize()
-    t_fps0 = time.perf_counter()
-    lms = fa.generate_landmarks(pts_full, w["n_lms"], start_idx=0)
-    torch.cuda.synchronize()
-    t_fps = time.perf_counter() - t_fps0
-    stree, simplices = core._build_complex(lms, w["dim"])
-    d = w["dim"]
+
+    # landmark selection (generate_landmarks, outside the step).  cold = first call of the process (code-object
+    # loads, allocator, first PointIndex); warm = the same call again (it builds its own PointIndex where the
+    # bucketed path runs); ready = with a PointIndex of the cloud passed in, as flood_complex(points, int) does
+    def timed_fps(**kw):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        out_ = fa.generate_landmarks(pts_full, w["n_lms"], start_idx=0, **kw)
+        torch.cuda.synchronize()
+        return out_, time.perf_counter() - t0_
+
+    lms, t_fps_cold = timed_fps()
+    lms, t_fps = timed_fps()
+    fps_bucketed = w["dim"] <= core.FPS_BUCKET_MAX_DIM and w["n"] >= core.FPS_BUCKET_MIN_POINTS and w["n_lms"] > 64
+    t_fps_ready = None
+    if fps_bucketed:
+        _, t_fps_ready = timed_fps(index=core.PointIndex(pts_full))
+    d = w.get("max_dim", w["dim"])                   # dimension of the swept simplices (grid mode: the top one)
+    stree, simplices = core._build_complex(lms, d)
     simp = torch.as_tensor(simplices[d], device=dev)
     verts = lms[simp]
     centers, radii = core._ball_prep(verts, d)
@@ -204,16 +231,29 @@ def main():
     S_all = verts.shape[0]
     dp = lib.flooder_padded_dim(w["dim"])
 
-    # reference-defined work of this input (untimed): candidate pairs per simplex |X n ball_s| (core.py:156-217)
+    # reference-defined work of this input (untimed): candidate pairs per simplex |X n ball_s| (core.py:156-217);
+    # workloads with "p_sample" count them on that many random simplices and scale (cfg 4: 1.2 M triangles whose
+    # slabs hold half the cloud each - the full count is ~1e12 ball tests)
     pts_pad0 = core._pad_rows(pts_full[torch.argsort(pts_full[:, axis])], dp)
     search0 = pts_pad0[:, axis].contiguous()
-    lo0 = torch.searchsorted(search0, (centers[:, axis] - radii).contiguous(), right=False)
-    hi0 = torch.searchsorted(search0, (centers[:, axis] + radii).contiguous(), right=True)
-    cnt0 = torch.zeros(S_all, dtype=torch.int32, device=dev)
+    p_sample = w.get("p_sample")
+    if p_sample and p_sample < S_all:
+        pick0 = torch.randperm(S_all, generator=torch.Generator().manual_seed(0))[:p_sample].to(dev)
+        c0, r0 = centers[pick0].contiguous(), radii[pick0].contiguous()
+    else:
+        p_sample, c0, r0 = None, centers.contiguous(), radii.contiguous()
+    lo0 = torch.searchsorted(search0, (c0[:, axis] - r0).contiguous(), right=False)
+    hi0 = torch.searchsorted(search0, (c0[:, axis] + r0).contiguous(), right=True)
+    cnt0 = torch.zeros(c0.shape[0], dtype=torch.int32, device=dev)
     _native.check(lib.flooder_ball_count_f32(_native.ptr(pts_pad0), pts_pad0.shape[0], w["dim"], dp,
-                                             _native.ptr(centers.contiguous()), _native.ptr(radii.contiguous()),
-                                             _native.ptr(lo0), _native.ptr(hi0), S_all, _native.ptr(cnt0),
-                                             _native.current_stream_ptr(dev)), "ball_count")
+                                             _native.ptr(c0), _native.ptr(r0), _native.ptr(lo0), _native.ptr(hi0),
+                                             c0.shape[0], _native.ptr(cnt0), _native.current_stream_ptr(dev)),
+                  "ball_count")
+    P_scale = 1.0
+    if p_sample:
+        P_scale = S_all / float(p_sample)
+        cnt_mean = float(cnt0.to(torch.float64).mean().item())
+        cnt0 = torch.full((S_all,), 0, dtype=torch.int32, device=dev)   # (per-simplex counts unknown: orders below unused)
     del pts_pad0, search0, lo0, hi0
     if args.order == "ball":  # experiment: heaviest simplices (by the reference's candidate count) first
         perm = torch.argsort(cnt0, descending=True)
@@ -255,7 +295,10 @@ def main():
         cnt0 = cnt0[mine]
     del pts_full
     S, R = verts.shape[0], weights.shape[0]
-    P_local = int(cnt0.sum().item()) if not (world > 1 and args.shard == "points") else int(cnt0.sum().item()) // world
+    if p_sample:
+        P_local = int(cnt_mean * S) if not (world > 1 and args.shard == "points") else int(cnt_mean * S) // world
+    else:
+        P_local = int(cnt0.sum().item()) if not (world > 1 and args.shard == "points") else int(cnt0.sum().item()) // world
     del cnt0
     stats = torch.zeros(16, dtype=torch.int64, device=dev)
     plan = core.SamplePlan(weights, faces)
@@ -273,12 +316,13 @@ def main():
             pts_pad = core._pad_rows(shard_raw[o], dp)
             return (pts_pad, pts_pad[:, axis].contiguous())
 
-    def step(timer=None, with_stats=False):
+    def step(timer=None, with_stats=False, index=None):
         """raw cloud + simplices in HBM -> per-face filtration values in HBM.  The work counters are collected by
         ONE extra, untimed step: flood_complex() never asks for them, and thousands of waves adding to the same
-        few words cost ~0.1 ms."""
+        few words cost ~0.1 ms.  ``index``: a ready PointIndex (the cached-index variant of the step)."""
         core.LAST_STATS.reset()
-        index = build_index(timer)
+        if index is None:
+            index = build_index(timer)
         st = stats if with_stats else None
         if args.method == "cell":
             if st is not None:
@@ -307,27 +351,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(n_steps, timer=None, index=None):
+        """EXACTLY n_steps steps between two barrier + synchronize brackets; MAX over ranks; per-step HIP events."""
+        sync_all()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]  # on the launch stream
+        t0 = time.perf_counter()
+        marks[0].record()
+        o = None
+        for i in range(n_steps):
+            o = step(timer, index=index)
+            marks[i + 1].record()
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]), o
+
     if world > 1:  # create the communicator outside the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, device=dev), op=dist.ReduceOp.MIN)
     for _ in range(max(args.warmup, 0)):
         out = step()
-    sync_all()
     timer = core._KernelTimer()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # on the launch stream
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        out = step(timer)
-        marks[i + 1].record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, step_ms, out = timed_loop(args.steps, timer)
     ms_per_step = elapsed / args.steps * 1e3
     value = w["n"] * S_all / (elapsed / args.steps) / 1e6
-    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+
+    # the same step with a ready index (flood_complex(..., index=...) / the index generate_landmarks built): what a
+    # caller pays who sweeps one cloud more than once - and each rank of a multi-GPU run, where the index build is
+    # the part that does not divide
+    ready_index = build_index()
+    elapsed_ci, step_ms_ci, _ = timed_loop(args.steps, None, index=ready_index)
+    ms_cached = elapsed_ci / args.steps * 1e3
+
+    # cold steps: 512 MB written to another buffer before every step (L2 + the 256 MB Infinity Cache hold none of
+    # the cloud, the tree or the tables: what one flood_complex call on a fresh cloud sees)
+    cold_ms = None
+    if not args.no_cold and world == 1:
+        flush = torch.empty(128 << 20, dtype=torch.float32, device=dev)
+        cold = []
+        for i in range(5):
+            flush.fill_(float(i))
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            step()
+            b_.record()
+            torch.cuda.synchronize()
+            cold.append(a_.elapsed_time(b_))
+        cold_ms = float(np.median(cold))
+        del flush
 
     out = step(None, with_stats=True)  # untimed: work counters for the report
     torch.cuda.synchronize()
@@ -336,19 +409,32 @@ def main():
 
     # ------------------------------------------------------------------ per-kernel numbers (rank 0's share)
     k_ms = {k: v / args.steps for k, v in timer.totals_ms().items()}   # HIP events on the launch stream
+    if args.method != "cell" and "sweep" in k_ms:
+        k_ms["sweep_bvh" if args.method == "bvh" else "sweep_ball"] = k_ms.pop("sweep")
+    sweep_span = {"cell": "sweep", "bvh": "sweep_bvh", "ball": "sweep_ball"}[args.method]
     ms_index = k_ms.get("index", 0.0)
     ms_sweep_only = ms_per_step - ms_index
-    # algorithmic bytes of one step on this rank: every candidate row read once per
-    # simplex (P x 4 x dim), vertices, weights, and the (S, R) minimum buffer written once
-    alg_bytes = P_local * w["dim"] * 4 + S * (d + 1) * w["dim"] * 4 + R * (d + 1) * 4 + S * R * 4
+    # algorithmic bytes of one step on this rank: every candidate row read once per simplex
+    # (P x 4 x dim), vertices, weights, and the result written once - the (S, F) face values on the fused path,
+    # the (S, R) minima where they are materialised (unfused / tree / ball sweeps, point-sharded reduction)
+    F = faces.n_faces
+    fused = args.method == "cell" and core.FUSED_FACES and hook is None
+    out_bytes = S * F * 4 if fused else S * R * 4
+    alg_bytes = P_local * w["dim"] * 4 + S * (d + 1) * w["dim"] * 4 + R * (d + 1) * 4 + out_bytes
+    flop_per_pair = 3 * w["dim"] + 1               # dim sub + dim mul/fma + 1 min
     pair_evals = P_local * R                       # what the reference's formulation evaluates
     st_h = None
     per_kernel = {}                                # span -> dict(pairs, share of the step's units)
     if args.method == "bvh":
         sh = stats.cpu().tolist()
         ks = 2 if R > 64 else 1
-        per_kernel["sweep"] = dict(pairs=sh[0] * 16 * 64 * ks, share=1.0)
-        st_h = {"leaves_evaluated": sh[0], "leaves_tested": sh[1], "nodes_expanded": sh[2]}
+        per_kernel[sweep_span] = dict(pairs=sh[0] * 16 * min(64 * ks, R), share=1.0)
+        n_tiles = S * ((R + 64 * ks - 1) // (64 * ks))
+        st_h = {"leaves_evaluated": sh[0], "leaves_tested": sh[1], "nodes_expanded": sh[2], "tiles_total": n_tiles,
+                "leaves_evaluated_per_tile": round(sh[0] / max(n_tiles, 1), 2),
+                "leaves_tested_per_tile": round(sh[1] / max(n_tiles, 1), 2),
+                "nodes_expanded_per_tile": round(sh[2] / max(n_tiles, 1), 2),
+                "max_tests_one_tile": sh[3], "samples_per_tile": min(64 * ks, R), "lanes_per_tile": 64}
     elif args.method == "cell":
         sh = stats.cpu().tolist()
         tiles_total = S * ((R + 63) // 64)
@@ -368,7 +454,7 @@ def main():
                 "finish_shared_rounds": list(core.LAST_STATS.hard_entries),
                 "shared_face_slots": slots is not None}
     else:
-        per_kernel["sweep"] = dict(pairs=pair_evals, share=1.0)
+        per_kernel[sweep_span] = dict(pairs=pair_evals, share=1.0)
     done_evals = sum(v["pairs"] for v in per_kernel.values())
     kernels = {}
     for span, ms in sorted(k_ms.items(), key=lambda kv: -kv[1]):
@@ -376,28 +462,30 @@ def main():
         if span in per_kernel and ms > 0:
             pk = per_kernel[span]
             gbs = alg_bytes * pk["share"] / (ms * 1e-3) / 1e9
-            tf = 10.0 * pk["pairs"] / (ms * 1e-3) / 1e12       # 3d+1 flop per evaluated pair, d = 3
+            tf = float(flop_per_pair) * pk["pairs"] / (ms * 1e-3) / 1e12
             rec.update({"unit_share": round(pk["share"], 5), "algorithmic_GBs": round(gbs, 2),
                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "pairs_evaluated": int(pk["pairs"]),
                         "valu_TFLOPs": round(tf, 2), "valu_frac": round(tf / VALU_PEAK_TFLOPS, 4)})
         kernels[span] = rec
-    dom = max((s for s in k_ms if s in per_kernel), key=lambda s: k_ms[s])      # dominant compute kernel
+    dom = max((s_ for s_ in k_ms if s_ in per_kernel), key=lambda s_: k_ms[s_])      # dominant compute kernel
     dom_rec = kernels[dom]
     step_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
 
     # measured HBM traffic and issue utilisation of the dominant kernel: rocprofv3 PMC passes
     # (tools/collect_profiles.sh -> profiles/traffic.json), valid only for the kernel sources they were taken with
-    traffic = traffic_src = issue_util = None
+    traffic = traffic_src = issue_util = prof_us = None
     try:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(tpath):
             ent = json.load(open(tpath)).get(f"{args.workload}:{args.method}:{dom}")
             if ent and ent.get("kernel_src_sha") == kernel_source_sha():
                 traffic, traffic_src, issue_util = ent.get("bytes_per_launch"), ent.get("source"), ent.get("issue_util")
+                prof_us = ent.get("duration_us_kernel_trace")
             elif ent:
                 traffic_src = f"stale ({ent.get('source')} was measured with other kernel sources)"
     except Exception:
         pass
+    dom_bytes = int(alg_bytes * dom_rec["unit_share"])
     result = {
         "metric": "M points×simplices/s (coverage sweep)",
         "value": round(value, 3),
@@ -411,8 +499,15 @@ def main():
         "ms_per_step_min": round(float(step_ms.min()), 4),
         "ms_index_build": round(ms_index, 4),
         "value_sweep_only": round(w["n"] * S_all / (ms_sweep_only * 1e-3) / 1e6, 3),
+        "ms_per_step_index_ready": round(ms_cached, 4),
+        "value_index_ready": round(w["n"] * S_all / (ms_cached * 1e-3) / 1e6, 3),
+        "cold_step_ms": None if cold_ms is None else round(cold_ms, 4),
         "step_definition": "raw cloud + simplices in HBM -> index build (Hilbert sort + box tree) -> sweep -> exact "
-                           "finish -> [all_reduce] -> per-face values in HBM; value_sweep_only leaves the index build out",
+                           "finish -> [all_reduce] -> per-face values in HBM (value, ms_per_step: back-to-back steps, "
+                           "caches warm); cold_step_ms: the same step after a 512 MB flush of L2 / Infinity Cache "
+                           "(median of 5); ms_per_step_index_ready / value_index_ready: the step with a PointIndex "
+                           "of the cloud passed in (flood_complex(..., index=...)), timed over the same number of "
+                           "steps; value_sweep_only = value with the index span subtracted",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -420,36 +515,50 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S_all,
-            "top_simplices_rank0": S,
-            "samples_per_simplex": R, "candidate_pairs_rank0": P_local, "pair_evals_rank0": pair_evals,
+            "top_simplices_rank0": S, "swept_dimension": d,
+            "samples_per_simplex": R, "candidate_pairs_rank0": P_local,
+            "candidate_pairs_note": (f"mean of {p_sample} random simplices x S" if p_sample else "counted on every simplex"),
+            "pair_evals_rank0": pair_evals,
             "parallelism": (f"{args.shard}-shard x{world} ({backend})" if world > 1 else "single GPU"),
             "method": args.method, "pair_evals_done_rank0": int(done_evals),
             "sweep_stats_rank0": st_h,
             "sweep_stats_note": "work counters come from one extra untimed step (the timed steps run without them, as flood_complex does)",
             "h2d_ms": round(h2d_ms, 3),
+            "not_in_this_line": (["points streamed from host pinned memory in chunks (BASELINE.json configs[4]): the cloud "
+                                  "is resident in HBM here; flooder_amd.PointIndex.from_host streams it, see DESIGN.md"]
+                                 if args.workload == "cfg5" else []),
         },
-        # the metric's roofline (BASELINE.json asks for HBM GB/s): algorithmic bytes of the dominant kernel's
-        # share of the step / that kernel's average launch duration.  The kernel is NOT HBM-bound (SURVEY.md 8d:
-        # the path is arithmetic/latency-bound): "limiter" says what binds it, "valu" gives that roofline.
+        # The binding roofline of the dominant kernel.  The sweep is NOT HBM-bound (3.6-4 k flop/byte
+        # in the reference's formulation): it is bound by fp32 vector issue + dependent latency, so "bound" names
+        # the vector ALU and achieved/peak/frac are useful fp32 flop (3 dim + 1 per evaluated pair) against the
+        # 157.3 TFLOP/s vector peak.  "hbm" carries BASELINE.json's metric: algorithmic bytes of this kernel's share
+        # of the step / its average launch duration, against 8 TB/s; "traffic" = counter-measured
+        # HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes).
         "roofline": {
-            "kernel": dom_rec["kernel"], "bound": "hbm", "achieved": dom_rec["algorithmic_GBs"],
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_rec["hbm_frac"], "traffic": traffic,
-            "traffic_source": traffic_src,
-            "algorithmic_bytes": int(alg_bytes * dom_rec["unit_share"]), "avg_launch_ms": dom_rec["ms_per_step"],
-            "limiter": "VALU issue + dependent-latency chains (occupancy-limited by LDS), not HBM",
+            "kernel": dom_rec["kernel"], "bound": "valu",
+            "achieved": dom_rec["valu_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom_rec["valu_frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "flop_per_pair": flop_per_pair, "pairs": dom_rec["pairs_evaluated"],
+            "avg_launch_ms": dom_rec["ms_per_step"], "avg_launch_ms_rocprof": None if prof_us is None else round(prof_us / 1e3, 4),
             "issue_util": issue_util,
-            "valu": {"achieved": dom_rec["valu_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": dom_rec["valu_frac"], "flop_per_pair": 10, "pairs": dom_rec["pairs_evaluated"]},
+            "limiter": "fp32 VALU issue + dependent-latency chains (LDS round trips, tree-node loads) at 3 waves per "
+                       "SIMD; HBM traffic is a few percent of peak",
+            "hbm": {"bound": "hbm", "achieved": dom_rec["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom_rec["hbm_frac"], "algorithmic_bytes": dom_bytes,
+                    "traffic_frac_of_algorithmic": None if not traffic else round(traffic / max(dom_bytes, 1), 4),
+                    "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + result "
+                            "((S,F) face values on the fused path, (S,R) minima where materialised), apportioned to "
+                            "a kernel by the share of (simplex, sample) units it resolves"},
             "step": {"algorithmic_bytes": int(alg_bytes), "ms": round(ms_per_step, 4),
                      "achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5)},
-            "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + (S,R) minima "
-                    "(SURVEY.md 8d), apportioned to a kernel by the share of (simplex, sample) units it resolves",
         },
         "kernels": kernels,
         "emulated_shard": args.emulate_shard,
         # landmark selection (generate_landmarks, outside the step): algorithmic bytes of the brute-force
         # formulation = (4*dim + 8) B per point and iteration
-        "fps": {"points": w["n"], "landmarks": w["n_lms"], "ms": round(t_fps * 1e3, 3),
+        "fps": {"points": w["n"], "landmarks": w["n_lms"], "path": "bucketed" if fps_bucketed else "brute",
+                "ms": round(t_fps * 1e3, 3), "ms_cold_first_call": round(t_fps_cold * 1e3, 3),
+                "ms_index_ready": None if t_fps_ready is None else round(t_fps_ready * 1e3, 3),
                 "us_per_landmark": round(t_fps / w["n_lms"] * 1e6, 3),
                 "algorithmic_GBs": round((4 * w["dim"] + 8) * w["n"] * w["n_lms"] / t_fps / 1e9, 1),
                 "hbm_peak_GBs": HBM_PEAK_GBS},
@@ -462,27 +571,34 @@ def main():
         P_np, L_np, simp_np = pts_cpu.numpy(), lms.cpu().numpy(), simp.cpu().numpy()
         cb = fo.kdtree_sweep_sample(P_np, L_np, simp_np, w["ppe"], d, n_sample=min(args.cpu_sample, S_all), seed=0,
                                     workers=1)
-        got = out.cpu().numpy()[cb["picked"]]
+        got_all = out.cpu().numpy()
+        got = got_all[cb["picked"]]
         ref = cb["face_max"]
-        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6 * float(pts_cpu.abs().max()))
+        floor = 1e-6 * float(pts_cpu.abs().max())
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), floor)
         cpu_value = w["n"] * cb["n_sample"] / (cb["query_s"] + cb["build_s"] * cb["n_sample"] / S_all) / 1e6
         result["cpu_baseline"] = {
             "value": round(cpu_value, 4), "unit": "M points×simplices/s", "cores": 1, "kind": "port",
             "sample": f"oracle kd-tree sweep (scipy KDTree.query, workers=1, as reference core.py:197-199) of "
-                      f"{cb['n_sample']} of {S_all} tetrahedra x {R} samples; tree build {cb['build_s']:.2f}s "
+                      f"{cb['n_sample']} of {S_all} top simplices x {R} samples; tree build {cb['build_s']:.2f}s "
                       f"(charged pro rata), query {cb['query_s']:.2f}s; host has {os.cpu_count()} cores",
         }
-        result["parity"] = {"checked_simplices": int(cb["n_sample"]), "values": int(got.size),
-                            "max_abs_err": float(np.abs(got - ref).max()),
-                            "max_rel_err": float(rel.max())}
-        n_all = min(S_all, max(args.cpu_sample, 6000))
-        ca = fo.kdtree_sweep_sample(P_np, L_np, simp_np, w["ppe"], d, n_sample=n_all, seed=1, workers=-1)
-        all_value = w["n"] * ca["n_sample"] / (ca["query_s"] + ca["build_s"] * ca["n_sample"] / S_all) / 1e6
-        result["cpu_baseline_all_cores"] = {
-            "value": round(all_value, 4), "unit": "M points×simplices/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"same sweep with scipy workers=-1 on {ca['n_sample']} of {S_all} tetrahedra; tree build "
-                      f"{ca['build_s']:.2f}s (single-threaded, charged pro rata), query {ca['query_s']:.2f}s",
-        }
+        checked, max_abs, max_rel = int(cb["n_sample"]), float(np.abs(got - ref).max()), float(rel.max())
+        if not args.no_all_cores:
+            n_all = min(S_all, max(args.cpu_sample, w.get("all_cores_sample", 6000)))
+            ca = fo.kdtree_sweep_sample(P_np, L_np, simp_np, w["ppe"], d, n_sample=n_all, seed=1, workers=-1)
+            all_value = w["n"] * ca["n_sample"] / (ca["query_s"] + ca["build_s"] * ca["n_sample"] / S_all) / 1e6
+            result["cpu_baseline_all_cores"] = {
+                "value": round(all_value, 4), "unit": "M points×simplices/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"same sweep with scipy workers=-1 on {ca['n_sample']} of {S_all} top simplices; tree build "
+                          f"{ca['build_s']:.2f}s (single-threaded, charged pro rata), query {ca['query_s']:.2f}s",
+            }
+            got2, ref2 = got_all[ca["picked"]], ca["face_max"]   # the all-cores leg is a parity check as well
+            rel2 = np.abs(got2 - ref2) / np.maximum(np.abs(ref2), floor)
+            checked = int(len(np.union1d(cb["picked"], ca["picked"])))
+            max_abs, max_rel = max(max_abs, float(np.abs(got2 - ref2).max())), max(max_rel, float(rel2.max()))
+        result["parity"] = {"checked_simplices": checked, "of": S_all, "values": checked * int(got.shape[1]),
+                            "max_abs_err": max_abs, "max_rel_err": max_rel, "tolerance_rel": 1e-5}
 
     if rank == 0:
         print(json.dumps(result, ensure_ascii=False))

@@ -11,7 +11,9 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libflooder_hip.so")
+# FLOODER_HIP_LIB: another build of the library (the diagnostic variants of tools/gpu_session.sh are built beside
+# the product library and selected here - the product file is never overwritten)
+LIB_PATH = os.environ.get("FLOODER_HIP_LIB") or os.path.join(_PKG_DIR, "libflooder_hip.so")
 
 _lib = None
 _load_error: Exception | None = None

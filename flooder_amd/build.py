@@ -36,7 +36,15 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm's hipcc to build libflooder_hip.so)")
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
+def build_hip(force: bool = False, verbose: bool = False, out: str = None) -> str:
+    """``out``: write the library there instead of the product path (diagnostic builds with FLOODER_HIPCC_FLAGS;
+    load them with FLOODER_HIP_LIB=<out>)."""
+    if out:
+        return _build_hip_to(os.path.abspath(out), True, verbose)
+    return _build_hip_to(HIP_LIB, force, verbose)
+
+
+def _build_hip_to(HIP_LIB: str, force: bool, verbose: bool) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp"),
                    os.path.join(CSRC, "flood_bvh.hpp")]
@@ -76,4 +84,7 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--out" in sys.argv:   # python -m flooder_amd.build --out /tmp/libflooder_hip_timers.so  (diagnostic variant)
+        print(build_hip(verbose=True, out=sys.argv[sys.argv.index("--out") + 1]))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

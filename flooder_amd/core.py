@@ -133,6 +133,7 @@ def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int]
 
 FPS_METHOD = "auto"   # "bucket" (dim <= 3: bucketed over the curve-sorted cloud), "brute" (one full sweep per landmark)
 FPS_BUCKET_MIN_POINTS = 200_000   # below this a brute-force step costs no more than its launch
+FPS_BUCKET_MAX_DIM = 3            # ambient dimensions the bucketed selection supports
 
 
 def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Optional[str] = None,
@@ -151,11 +152,12 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
         n = pts.shape[0]
         method = FPS_METHOD if method is None else method
         if method == "auto":
-            method = "bucket" if dim <= 3 and (n >= FPS_BUCKET_MIN_POINTS or index is not None) and n_lms > 64 else "brute"
+            method = ("bucket" if dim <= FPS_BUCKET_MAX_DIM and (n >= FPS_BUCKET_MIN_POINTS or index is not None)
+                      and n_lms > 64 else "brute")
         if method not in ("bucket", "brute"):
             raise ValueError("method must be 'bucket' or 'brute'")
-        if method == "bucket" and dim > 3:
-            raise ValueError("bucketed FPS supports ambient dimension <= 3")
+        if method == "bucket" and dim > FPS_BUCKET_MAX_DIM:
+            raise ValueError(f"bucketed FPS supports ambient dimension <= {FPS_BUCKET_MAX_DIM}")
         out_idx = torch.empty(n_lms, dtype=torch.int64, device=pts.device)
         if method == "bucket":
             index = index if index is not None else PointIndex(pts)
@@ -860,6 +862,7 @@ def flood_complex(
     method: Optional[str] = None,
     simplex_shard: Optional[Tuple[int, int]] = None,
     face_reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
+    index: Optional["PointIndex"] = None,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -871,9 +874,10 @@ def flood_complex(
     the HIP kernels (``use_triton=True`` still raises ``ImportError`` if they are unavailable, as the
     reference does when Triton is); ``batch_size`` is accepted, the HBM workspace is bounded by
     grouping simplices against ``CAND_WORKSPACE_BYTES`` instead.  ``reduce_hook`` (keyword-only
-    extension) is called with the (S, R) int32 tensor of minimum squared-distance bit patterns of every
-    dimension pass before the per-face maxima are taken; ``flooder_amd.distributed`` uses it for the
-    cross-GPU ``all_reduce(MIN)``.  ``sort_axis`` (keyword-only) fixes the coordinate axis used for the
+    extension) is called with the (S, R) tensor of minimum squared-distance bit patterns of every
+    dimension pass before the per-face maxima are taken - int32 words of float32 values for float32 inputs,
+    int64 words of float64 values for float64 inputs (integer order == numeric order either way; CPU tensors:
+    the float distance matrix); ``flooder_amd.distributed`` uses it for the cross-GPU ``all_reduce(MIN)``.  ``sort_axis`` (keyword-only) fixes the coordinate axis used for the
     cloud sort and the simplex order instead of deriving it from ``points`` (ranks holding different
     shards must agree on the simplex order of the reduced buffer).  ``method`` (keyword-only):
     ``"cell"`` (default in 2D/3D: per-simplex cell grid in LDS, exact tree finish) and ``"bvh"`` (default
@@ -881,7 +885,10 @@ def flood_complex(
     formulation literally (bounding-ball candidates, exhaustive sweep).  All give the same values
     whenever the landmarks are points of the cloud (the reference's precondition for its own GPU path,
     SURVEY.md section 8 a-2); for other landmarks ``"cell"``/``"bvh"`` return the exact value of the
-    reference's CPU path.
+    reference's CPU path.  ``index`` (keyword-only): a ``PointIndex`` built from these very ``points`` (ROCm
+    tensors, methods ``"cell"``/``"bvh"``) - the curve-sorted copy and box tree are reused instead of rebuilt
+    (callers that sweep one cloud several times, and every rank of a multi-GPU run; the caller vouches that
+    ``points`` has not changed since: only the shape is checked).
     """
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
@@ -903,8 +910,14 @@ def flood_complex(
     if max_dimension is None:
         max_dimension = points.shape[1]
     shared_index = None  # one curve-sorted copy of the cloud serves the landmark selection and the sweep
+    if index is not None:
+        if not points.is_cuda or method == "ball":
+            raise ValueError("index= applies to ROCm tensors with method 'cell' or 'bvh'")
+        if not isinstance(index, PointIndex) or (index.n, index.dim) != tuple(points.shape) or index.pts.device != points.device:
+            raise ValueError("index= is not a PointIndex of these points (shape or device differ)")
+        shared_index = index
     if isinstance(landmarks, Integral):
-        if (points.is_cuda and method != "ball" and points.shape[1] <= 3 and points.dtype in SUPPORTED_DTYPES
+        if (shared_index is None and points.is_cuda and method != "ball" and points.shape[1] <= FPS_BUCKET_MAX_DIM and points.dtype in SUPPORTED_DTYPES
                 and _has_hip_kernels() and points.shape[0] >= FPS_BUCKET_MIN_POINTS and landmarks > 64):
             shared_index = PointIndex(points.to(torch.float32))
         landmarks = generate_landmarks(points, min(landmarks, points.shape[0]), fps_h, start_idx=start_idx,

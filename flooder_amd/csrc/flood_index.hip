@@ -59,21 +59,33 @@ struct GatherOp {
 // rocprim sorts up to 2^20 keys by merge sort: a block sort and ten merge passes of two launches each - 21 launches,
 // 150 us for the million points of cfg 2.  The onesweep radix sort (a histogram launch and one launch per 8 bits) is
 // what it uses above that size and is the faster one from a tenth of it on.
+// (the four-parameter radix_sort_config - single / merge / onesweep configuration + merge-sort limit - is the form of
+// rocPRIM 3.x and later; an older toolchain gets the library's default configuration: same results, slower below 2^20 keys)
+#if defined(ROCPRIM_VERSION) && ROCPRIM_VERSION >= 300000
 using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
                                            (size_t)128 * 1024>;
+#else
+using SortCfg = rocprim::default_config;
+#endif
 
 extern "C" {
 
 int64_t flooder_index_sort_bytes(int64_t n_pts) {
   if (n_pts < 1) return 0;
-  size_t bytes = 0;
+  // (the caller does not say yet which key width flooder_index_sort will be given: the larger of the two needs)
+  size_t bytes = 0, bytes32 = 0;
   const uint64_t* k = nullptr;
   uint64_t* ko = nullptr;
+  const uint32_t* k32 = nullptr;
+  uint32_t* ko32 = nullptr;
   uint32_t* vo = nullptr;
   hipError_t e = rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, k, ko, rocprim::counting_iterator<uint32_t>(0u), vo,
                                            (size_t)n_pts, 0u, 64u, (hipStream_t)0);
   if (e != hipSuccess) return -1;
-  return (int64_t)bytes + 256;
+  e = rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes32, k32, ko32, rocprim::counting_iterator<uint32_t>(0u), vo,
+                                (size_t)n_pts, 0u, 32u, (hipStream_t)0);
+  if (e != hipSuccess) return -1;
+  return (int64_t)(bytes > bytes32 ? bytes : bytes32) + 256;
 }
 
 int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,

@@ -40,8 +40,11 @@ def shard_points(points: torch.Tensor, rank: int, world_size: int) -> torch.Tens
 def min_reduce_hook(group: Optional[dist.ProcessGroup] = None):
     """``reduce_hook`` for ``flood_complex``: in-place ``all_reduce(MIN)`` over the process group.
 
-    On ROCm tensors the buffer is int32 bit patterns of non-negative float32 squared distances
-    (integer order == numeric order, +inf = 0x7f800000); on CPU it is the float distance matrix.
+    On ROCm tensors the buffer holds bit patterns of non-negative squared distances, for which integer order ==
+    numeric order: int32 words of float32 values (+inf = 0x7f800000) for float32 inputs, int64 words of float64
+    values (+inf = 0x7ff0000000000000) for float64 inputs; on CPU it is the float distance matrix.  A hook that
+    wants numbers must view the buffer by its dtype (``buf.view(torch.float32 if buf.dtype == torch.int32 else
+    torch.float64)``); MIN needs no view.
     """
 
     def hook(buf: torch.Tensor) -> None:

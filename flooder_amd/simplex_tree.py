@@ -165,6 +165,12 @@ class SimplexTree:
         1.4 million."""
         st = cls()
         cells = np.asarray(cells, dtype=np.int64)
+        # Ascending vertex ids are relied upon: a face shared by several cells then has the same vertex ORDER in each
+        # of them, so its samples (weights x vertices, same fma order) and its value are bit-identical from every
+        # cell - which is why "last writer wins" (assign_cell_faces) and "max per distinct face" (the fused
+        # shared-slot sweep) agree bit for bit, and why sharded and unsharded runs are bit-equal.
+        if cells.shape[1] > 1 and not (np.diff(cells, axis=1) > 0).all():
+            raise ValueError("SimplexTree.from_cells: every cell must list its vertex ids in ascending order")
         st._cells = cells
         st._n_points = int(n_points)
         top = cells.shape[1] - 1
@@ -305,8 +311,10 @@ class SimplexTree:
 
     def assign_cell_faces(self, d: int, cell_rows: np.ndarray, face_cols: Sequence[int], values: np.ndarray) -> bool:
         """``values[i, j]`` -> face ``face_cols[j]`` (numbering of ``cell_face_index``) of top cell ``cell_rows[i]``,
-        through the index kept from the enumeration of the faces instead of a search per row.  Later rows win on
-        duplicates, as in ``assign_filtration_bulk``.  False (nothing done) when no such index exists."""
+        through the index kept from the enumeration of the faces instead of a search per row.  A face shared by
+        several cells receives the same value from each of them (``from_cells`` insists on ascending vertex ids, see
+        there), so which duplicate numpy's indexed assignment keeps does not matter.  False (nothing done) when no
+        such index exists."""
         index = self.cell_face_index(d)
         if index is None or d not in self._vals:
             return False

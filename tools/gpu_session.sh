@@ -13,21 +13,21 @@ for s in $STEPS; do
     test)   timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
     testall) timeout 1500 python -m pytest tests -m gpu -q --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -15 $OUT/pytest_gpu.txt ;;
     bench)  timeout 600 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; cut -c1-600 $OUT/bench_cfg2.json ;;
-    bench3) timeout 600 python bench.py --workload cfg3 --no-cpu-baseline > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ;;
-    bench5) timeout 900 python bench.py --workload cfg5 --no-cpu-baseline --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ;;
+    bench3) timeout 900 python bench.py --workload cfg3 --cpu-sample 600 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ;;
+    bench4) timeout 1500 python bench.py --workload cfg4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; cut -c1-1500 $OUT/bench_cfg4.json; tail -3 $OUT/bench_cfg4.err ;;
+    bench5) timeout 1500 python bench.py --workload cfg5 --cpu-sample 300 --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ;;
     bench2) timeout 600 python bench.py --gpus 2 --no-cpu-baseline > $OUT/bench_cfg2_2ranks.json 2> $OUT/bench_cfg2_2ranks.err; cut -c1-400 $OUT/bench_cfg2_2ranks.json; tail -3 $OUT/bench_cfg2_2ranks.err ;;
     prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
-            python tools/summarize_profiles.py ${s#prof:} r2_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
-            mkdir -p $OUT/profiles && cp profiles/r2_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
+            python tools/summarize_profiles.py ${s#prof:} r3_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
+            mkdir -p $OUT/profiles && cp profiles/r3_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
     emul:*) bash tools/emulate_scaling.sh ${s#emul:} > $OUT/emulate_${s#emul:}.txt 2>&1; cat $OUT/emulate_${s#emul:}.txt ;;
-    timers) cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
-            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+    timers) FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 300 python tools/phase_timers.py > $OUT/phase_timers.txt 2>&1
             timeout 300 python tools/chunk_times.py 1 > $OUT/chunk_times_1.txt 2>&1
             timeout 300 python tools/chunk_times.py 8 > $OUT/chunk_times_8.txt 2>&1
             timeout 300 python tools/bvh_phase.py cfg3 > $OUT/bvh_phase_cfg3.txt 2>&1
-            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            unset FLOODER_HIP_LIB
             cat $OUT/phase_timers.txt; head -20 $OUT/chunk_times_1.txt; cat $OUT/bvh_phase_cfg3.txt ;;
     ab:*)   # ab:<workload>:<name>:<flags with , for space>   one bench line per variant
             IFS=: read -r _ wl name flags <<< "$s"
@@ -64,33 +64,51 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:22]:
 PY
             rm -rf $OUT/trace_$wl ;;
     ctimes:*) IFS=: read -r _ W wl <<< "$s"      # ctimes:<W>[:<workload>]
-            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
-            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 400 python tools/chunk_times.py $W ${wl:-cfg2} > $OUT/chunk_times_${W}_${wl:-cfg2}.txt 2>&1
-            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            unset FLOODER_HIP_LIB
             grep -v "^  ends\|kcycles\|^  dur" $OUT/chunk_times_${W}_${wl:-cfg2}.txt ;;
     wends:*) IFS=: read -r _ wl W <<< "$s"
-            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
-            FLOODER_HIPCC_FLAGS=-DFLOODER_WAVE_END python -m flooder_amd.build --force > $OUT/build_wend.log 2>&1
+            FLOODER_HIPCC_FLAGS=-DFLOODER_WAVE_END python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_wend.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 300 python tools/wave_ends.py $wl ${W:-1} > $OUT/wave_ends_${wl}_${W:-1}.txt 2>&1
-            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            unset FLOODER_HIP_LIB
             tail -2 $OUT/wave_ends_${wl}_${W:-1}.txt ;;
     fphase:*) wl=${s#fphase:}
-            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
-            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 300 python tools/bvh_phase.py $wl 2>&1 | grep -v amdgpu.ids > $OUT/fin_phase_$wl.txt
-            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            unset FLOODER_HIP_LIB
             cat $OUT/fin_phase_$wl.txt ;;
     ptimers:*) IFS=: read -r _ wl md <<< "$s"
-            cp flooder_amd/libflooder_hip.so /tmp/libflooder_hip.so.keep
-            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --force > $OUT/build_timers.log 2>&1
+            FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 300 python tools/phase_timers.py $wl ${md:-} > $OUT/phase_timers_$wl.txt 2>&1
-            cp /tmp/libflooder_hip.so.keep flooder_amd/libflooder_hip.so
+            unset FLOODER_HIP_LIB
             cat $OUT/phase_timers_$wl.txt ;;
     sortbench) hipcc -O3 --offload-arch=gfx950 tools/sort_bench.hip -o /tmp/sort_bench > $OUT/sort_build.log 2>&1 && timeout 120 /tmp/sort_bench > $OUT/sort_bench.txt 2>&1; cat $OUT/sort_bench.txt ;;
     cweights:*) timeout 300 python tools/check_weights.py ${s#cweights:} 2>&1 | grep -v amdgpu.ids ;;
     e2e:*) timeout 600 python tools/profile_e2e.py ${s#e2e:} tree 2>&1 | grep -v amdgpu.ids > $OUT/e2e_${s#e2e:}.txt; head -60 $OUT/e2e_${s#e2e:}.txt ;;
     tfps) timeout 600 python tools/time_fps.py > $OUT/time_fps.txt 2>&1; cat $OUT/time_fps.txt ;;
+    icache:*) # instruction-cache counters of the sweep kernels (is the 66-83 KB kernel thrashing the 64 KB cache two CUs share?)
+            wl=${s#icache:}
+            ( cd /tmp && export TMPDIR=/tmp
+              timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_icache_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-cold > $OUT/icache_$wl.json 2> $OUT/icache_$wl.err
+              timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_inst_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-cold > $OUT/inst_$wl.json 2>> $OUT/icache_$wl.err )
+            python - $OUT $wl <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(f"{sys.argv[1]}/pmc_i*_{sys.argv[2]}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "anonymous namespace" not in k: continue
+        k = k.split("(anonymous namespace)::")[1].split("(")[0]
+        a = acc[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+last = None
+for (k, c) in sorted(acc):
+    v, n = acc[(k, c)]
+    if v / n < 1e4: continue
+    if k != last: print(k); last = k
+    print(f"    {c:32s} {v / n:14.4g} per launch ({n} launches)")
+PY
+            find $OUT -name "*.csv" -size +4M -delete ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
   esac

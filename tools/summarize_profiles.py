@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from bench import kernel_source_sha
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-name = sys.argv[2] if len(sys.argv) > 2 else f"r2_{tag}"
+name = sys.argv[2] if len(sys.argv) > 2 else f"r3_{tag}"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
@@ -44,10 +44,12 @@ sha = kernel_source_sha()
 # span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
 # (method, span, ((kernel, launches per step), ...))
 SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true>", 1), ("cell_sweep_kernel<3, false>", 1))),
-         # top pass + rest pass, the hard tiles of either (one workgroup each), the ordering of the flagged tiles
-         ("cell", "fallback", (("finish_faces_kernel<3, false>", 2), ("finish_faces_kernel<3, true>", 2),
+         # the pass over the flagged tiles, its hard tiles (one workgroup each), the ordering of the flagged tiles:
+         # one launch each per step (the "top pass" that doubled the first two is off by default since round 2)
+         ("cell", "fallback", (("finish_faces_kernel<3, false>", 1), ("finish_faces_kernel<3, true>", 1),
                                ("order_flags_kernel", 1))),
-         ("bvh", "sweep", (("sweep_bvh_kernel<3, 2, 1>", 1),)), ("ball", "sweep", (("sweep_kernel<3, true>", 1),)))
+         ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)), ("bvh", "sweep_bvh", (("sweep_bvh_kernel<6, 1, 1>", 1),)),
+         ("ball", "sweep_ball", (("sweep_kernel<3, true>", 1),)))
 for method, span, kerns, in SPANS:
     have = [(k, m) for k, m in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
     if not have:
