@@ -679,11 +679,34 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    sorted_samples = (BVH_SORTED_SAMPLES if BVH_SORTED_SAMPLES is not None else index.dim > 3) \
+        and BVH_SORTED_MIN_SAMPLES <= S * R < (1 << 32) - 2
     with _span(timer, "sweep"):
-        _native.check(lib.flooder_sweep_bvh_f32(
-            _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-            _native.ptr(w_perm), k1, R, S, _native.ptr(queue), _native.ptr(d2), _native.ptr(stats), st),
-            "flooder_sweep_bvh_f32")
+        if sorted_samples:
+            # tiles of 64 spatially consecutive samples of ALL simplices (Z-order keys, one radix sort) instead of
+            # the samples of one simplex each: see csrc/flood_sorted.hip
+            n_s = S * R
+            keys = torch.empty(n_s, dtype=torch.int32, device=dev)
+            keys_sorted = torch.empty(n_s, dtype=torch.int32, device=dev)
+            order = torch.empty(n_s, dtype=torch.int32, device=dev)
+            tmp_bytes = int(lib.flooder_index_sort_bytes(n_s))
+            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+            _native.check(lib.flooder_sample_keys_f32(_native.ptr(verts), _native.ptr(w_perm), k1, R, S, index.dim,
+                                                      _native.ptr(index.box), _native.ptr(keys), st),
+                          "flooder_sample_keys_f32")
+            _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, int(lib.flooder_sample_key_bits(index.dim)),
+                                                 _native.ptr(keys_sorted), _native.ptr(order), _native.ptr(tmp),
+                                                 tmp_bytes, st), "flooder_index_sort (samples)")
+            _native.check(lib.flooder_sweep_bvh_sorted_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, _native.ptr(order), _native.ptr(queue), _native.ptr(d2),
+                _native.ptr(stats), st), "flooder_sweep_bvh_sorted_f32")
+            del keys, keys_sorted, tmp
+        else:
+            _native.check(lib.flooder_sweep_bvh_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, _native.ptr(queue), _native.ptr(d2), _native.ptr(stats), st),
+                "flooder_sweep_bvh_f32")
     if reduce_hook is not None:
         with _span(timer, "reduce"):
             reduce_hook(d2)
@@ -699,6 +722,9 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     return out_face, out_dist
 
 
+# tree sweep over spatially sorted samples (csrc/flood_sorted.hip): None = above 3 dimensions, True / False = always / never
+BVH_SORTED_SAMPLES: Optional[bool] = None
+BVH_SORTED_MIN_SAMPLES = 64 * 1024   # below this the sort costs more than it saves
 CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spacing
 # Per-face maxima folded into the cell sweep and its exact finish (only when neither the per-sample distances nor
 # a cross-shard reduction of them is wanted): no (S, R) store, no face-max pass, and the finish skips every sample

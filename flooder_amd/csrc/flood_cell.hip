@@ -68,6 +68,17 @@ __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint
   load_row<DP>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)byte_off), out);
 }
 
+// One staged point (x, y, z, -) from LDS.  The fourth word is not needed, and left to itself the compiler reads 12
+// bytes: ds_read_b96 takes 8 LDS cycles per wave instruction where ds_read_b128 takes 4 (MI355X_MICROARCH.md, LDS
+// table) - keeping .w "used" (an empty asm statement, no instruction) makes it the 16-byte read.
+__device__ __forceinline__ float4 lds_point(const float4* p) {
+  const float4 v = *p;
+#ifndef FLOODER_LDS_B96
+  asm volatile("" ::"v"(v.w));
+#endif
+  return v;
+}
+
 __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           for (int j = 0; j < n_keep; j += 4) {
             float4 x[4];
   #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+            for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
   #pragma unroll
             for (int i = 0; i < SPL; ++i) {
               float bb = best[i];
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           for (int j = 0; j < n_st; j += 4) {
             float4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+            for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
 #pragma unroll
             for (int i = 0; i < SPL; ++i) {
               float bb = best[i];
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
               for (int j = bg; j < en; j += 4) {
                 float4 x[4];
   #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+                for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
   #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   float t0 = p[i][0] - x[u].x;

@@ -1,0 +1,308 @@
+// flood_sorted.hip - tree sweep over spatially sorted samples (gfx950; any dimension, default above 3D).
+//
+// The tree sweep of flood_bvh.hip gives a wave the samples of ONE simplex (a tile of 64 * KS lattice rows) and
+// walks the box tree with the tile's bounding box.  In 2D / 3D, with thousands of samples per simplex, a tile is a
+// small patch.  In higher dimensions only coarse lattices are tractable (cfg 4 of BASELINE.json: triangles in 6D
+// with 36 samples each), a tile is the WHOLE simplex, its box spans a landmark spacing in every axis and most of
+// the tree overlaps it: 6400 leaf-box tests and 270 node expansions per tile for 260 evaluated leaves.
+//
+// Here the samples of all simplices are ordered along a Z-order curve first (one key per sample, one radix sort)
+// and a wave takes 64 CONSECUTIVE samples of that order - neighbours in space whatever simplex they belong to, all
+// 64 lanes busy.  The per-sample minima land in the same (S, R) buffer as before (scattered 4-byte stores), so the
+// face maxima, the cross-shard reduction and the results are unchanged: the minimum over ALL points, bit for bit.
+//
+//   sample_keys     key[i] = Morton code (floor(32 / dim) bits per axis) of sample i = (s, r) inside the cloud's box
+//   (sort)          flooder_index_sort: rocprim radix sort of (key, i), as for the cloud itself
+//   sweep_sorted    wave = 64 consecutive sorted samples; wave-uniform nearest-first traversal as in flood_bvh.hip
+
+#include "flood_common.hpp"
+#include "flood_bvh.hpp"
+
+using namespace flooder;
+
+namespace {
+
+constexpr float SAFE = 0.99999f;
+
+template <int DIM>
+__global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restrict__ verts,
+                                                          const float* __restrict__ weights, int k1, int R,
+                                                          int64_t n_samples, const float* __restrict__ dbox,
+                                                          uint32_t* __restrict__ keys) {
+  constexpr int BITS = 32 / DIM > 10 ? 10 : 32 / DIM;
+  float lo[DIM], scale[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const float ext = dbox[8 + k] - dbox[k];
+    lo[k] = dbox[k];
+    scale[k] = ext > 0.f ? (float)((1u << BITS) - 1u) / ext : 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_samples; i += stride) {
+    const int64_t s = i / R;
+    const int r = (int)(i - s * R);
+    float p[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) p[k] = 0.f;
+    for (int j = 0; j < k1; ++j) {
+      const float w = weights[(int64_t)r * k1 + j];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(w, verts[(s * k1 + j) * DIM + k], p[k]);
+    }
+    uint32_t code = 0u;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      float t = (p[k] - lo[k]) * scale[k];
+      t = t < 0.f ? 0.f : t;  // (samples of landmarks off the cloud may leave the box: clamped, order only)
+      const float top = (float)((1u << BITS) - 1u);
+      t = t > top ? top : t;
+      const uint32_t q = (uint32_t)t;
+#pragma unroll
+      for (int b = 0; b < BITS; ++b) code |= ((q >> b) & 1u) << (b * DIM + k);
+    }
+    keys[i] = code;
+  }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void sweep_sorted_kernel(
+    const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
+    const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
+    int64_t n_samples, const uint32_t* __restrict__ order, int32_t* __restrict__ queue,
+    uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct) {
+  constexpr int DP = padded_dim(DIM);
+  __shared__ float s_lb[4][MAXL][FAN];
+  __shared__ int64_t s_grp[4][MAXL];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int64_t n_tiles = (n_samples + 63) >> 6;
+  const int top = lv.n_levels - 1;
+  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
+
+  for (;;) {
+    int g32 = 0;
+    if (lane == 0) g32 = atomicAdd(queue, 1);
+    const int64_t g = (int64_t)wave_uniform(g32);
+    if (g >= n_tiles) break;
+    const unsigned long long tests_before = n_leaf_test + n_node_test;
+    const int64_t pos = g * 64 + lane;
+    const bool live = pos < n_samples;
+    const uint32_t id = order[live ? pos : n_samples - 1];  // (dead lanes repeat the last sample, never stored)
+    const uint32_t s = id / (uint32_t)R;
+    const uint32_t r = id - s * (uint32_t)R;
+
+    // ---- this lane's sample: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
+    float p[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) p[k] = 0.f;
+    {
+      const float* vs = verts + (int64_t)s * k1 * DIM;
+      const float* ws = weights + (int64_t)r * k1;
+      for (int j = 0; j < k1; ++j) {
+        const float w = ws[j];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(w, vs[j * DIM + k], p[k]);
+      }
+    }
+    float best = __builtin_inff();
+    float tlo[DIM], thi[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      tlo[k] = wave_min_f32(p[k]);
+      thi[k] = wave_max_f32(p[k]);
+    }
+    float M = __builtin_inff();  // largest running minimum of the tile (wave-uniform)
+
+    float c_lo[DIM], c_hi[DIM];
+    auto child_bounds = [&](int lvl, int64_t grp) -> float {
+      const int64_t idx = grp * FAN + lane;
+      float lb = __builtin_inff();
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) { c_lo[k] = __builtin_inff(); c_hi[k] = -__builtin_inff(); }
+      if (idx < lv.count[lvl]) {
+        float lo[DP], hi[DP];
+        const float* nb = nodes + (lv.off[lvl] + idx) * 2 * DP;
+        load_row<DP>(nb, lo);
+        load_row<DP>(nb + DP, hi);
+        lb = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          c_lo[k] = lo[k];
+          c_hi[k] = hi[k];
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(lo[k] - thi[k], tlo[k] - hi[k]), 0.f);
+          lb = __builtin_fmaf(gap, gap, lb);
+        }
+      }
+      return lb;
+    };
+
+    int lvl = top;
+    float lb0 = child_bounds(top, 0);
+    int64_t grp0 = 0;
+    ++n_node_test;
+    if (top > 0) {
+      s_lb[wv][top][lane] = lb0;
+      if (lane == 0) s_grp[wv][top] = 0;
+    }
+    for (;;) {
+      if (lvl > 0) {
+        const float lbv = s_lb[wv][lvl][lane];
+        const float mn = wave_min_f32(lbv);
+        if (!(mn * SAFE < M)) {  // nothing left at this level can improve any sample of the tile
+          if (++lvl > top) break;
+          continue;
+        }
+        const int j = __builtin_ctzll(__ballot(lbv == mn));
+        if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
+        const int64_t c = s_grp[wv][lvl] * FAN + j;
+        --lvl;
+        const float lb = child_bounds(lvl, c);
+        ++n_node_test;
+        if (lvl > 0) {
+          s_lb[wv][lvl][lane] = lb;
+          if (lane == 0) s_grp[wv][lvl] = c;
+        } else {
+          lb0 = lb;
+          grp0 = c;
+          // ---- transposed refine: the 64 leaf boxes of the group (one per lane) against every sample of the tile
+          // (one lane's sample broadcast at a time); a leaf no sample can improve on is dropped here, in 1/64 of a
+          // per-leaf test, before the nearest-first loop pops it.  Worth it when the per-leaf tests it replaces
+          // cost more than one pass over the 64 samples.
+          const bool cand = lb * SAFE < M;
+          constexpr int PER_LEAF = 4 * DIM + 40, PER_GROUP = 64 * (4 * DIM + 3);
+          if ((int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 > (int64_t)PER_GROUP * refine_pct) {
+            bool need = false;
+#pragma unroll 2
+            for (int src = 0; src < 64; ++src) {
+              float lbp = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[k]), src));
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
+                lbp = __builtin_fmaf(gap, gap, lbp);
+              }
+              const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), src));
+              need = need || (lbp * SAFE < bi);
+            }
+            if (!(cand && need)) lb0 = __builtin_inff();
+          }
+        }
+        continue;
+      }
+      // ---- leaf level: nearest unvisited leaf of the current group
+      const float mn = wave_min_f32(lb0);
+      if (!(mn * SAFE < M)) {
+        if (++lvl > top) break;
+        continue;
+      }
+      const int j = __builtin_ctzll(__ballot(lb0 == mn));
+      if (lane == j) lb0 = __builtin_inff();  // visited
+      const int64_t c = grp0 * FAN + j;
+      ++n_leaf_test;
+      // can any lane's sample still improve against leaf c?  (its box comes from lane j)
+      float lbp = 0.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const float blo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
+        const float bhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
+        const float gap = __builtin_fmaxf(__builtin_fmaxf(blo - p[k], p[k] - bhi), 0.f);
+        lbp = __builtin_fmaf(gap, gap, lbp);
+      }
+      if (__ballot(lbp * SAFE < best) == 0ull) continue;
+      ++n_leaf_eval;
+      const float* cp = pts + c * (int64_t)LEAF * DP;
+#pragma unroll
+      for (int h = 0; h < LEAF; h += 8) {
+        typename RowVec<DP>::type cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          float da, db;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float ta = p[k] - cc[u][k];
+            const float tb = p[k] - cc[u + 1][k];
+            if (k == 0) {
+              da = ta * ta;
+              db = tb * tb;
+            } else {
+              da = __builtin_fmaf(ta, ta, da);
+              db = __builtin_fmaf(tb, tb, db);
+            }
+          }
+          best = __builtin_fminf(best, __builtin_fminf(da, db));
+        }
+      }
+      M = wave_max_f32(best);
+    }
+    if (live) out_d2[id] = __float_as_uint(best);
+    const unsigned long long item_tests = n_leaf_test + n_node_test - tests_before;
+    max_item_tests = item_tests > max_item_tests ? item_tests : max_item_tests;
+  }
+  if (stats && lane == 0 && (n_node_test | n_leaf_test) != 0ull) {
+    atomicMax(&stats[3], max_item_tests);
+    atomicAdd(&stats[0], n_leaf_eval);
+    atomicAdd(&stats[1], n_leaf_test);
+    atomicAdd(&stats[2], n_node_test);
+  }
+}
+
+template <int DIM>
+struct SampleKeysOp {
+  static int run(const float* verts, const float* weights, int k1, int R, int64_t n_samples, const float* box,
+                 uint32_t* keys, hipStream_t st) {
+    int64_t blocks = (n_samples + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((sample_keys_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, verts, weights, k1, R,
+                       n_samples, box, keys);
+    return check_launch("sample_keys");
+  }
+};
+
+template <int DIM>
+struct SweepSortedOp {
+  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
+                 int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
+                 unsigned long long* stats, hipStream_t st) {
+    hipLaunchKernelGGL((sweep_sorted_kernel<DIM>), dim3(g_bvh_grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
+                       k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct);
+    return check_launch("sweep_sorted");
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int flooder_sample_key_bits(int dim) {
+  if (dim < 1 || dim > FLOODER_MAX_DIM) return 0;
+  const int b = 32 / dim > 10 ? 10 : 32 / dim;
+  return b * dim;
+}
+
+int flooder_sample_keys_f32(const float* verts, const float* weights, int k1, int R, int64_t n_simplices, int dim,
+                            const float* box, uint32_t* keys, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!verts || !weights || !box || !keys || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || n_simplices < 0 ||
+      n_simplices * (int64_t)R > 0xfffffffeLL)
+    return fail(FLOODER_E_ARG, "flooder_sample_keys_f32: bad argument (or more than 2^32 - 2 samples)");
+  return dispatch_dim<SampleKeysOp>(dim, verts, weights, k1, R, n_simplices * (int64_t)R, box, keys,
+                                    (hipStream_t)stream);
+}
+
+int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                 const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                 const int32_t* sample_order, int32_t* queue, uint32_t* out_d2, uint64_t* stats,
+                                 void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !sample_order || !queue || !out_d2 || n_pts < 1 || k1 < 1 ||
+      k1 > FLOODER_MAX_VERTS || R < 0 || n_simplices * (int64_t)R > 0xfffffffeLL)
+    return fail(FLOODER_E_ARG, "flooder_sweep_bvh_sorted_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
+                                     reinterpret_cast<const uint32_t*>(sample_order), queue, out_d2,
+                                     reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
+}
+
+}  // extern "C"

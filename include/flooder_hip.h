@@ -194,6 +194,24 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
                           const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                           int32_t* queue, uint32_t* out_d2, uint64_t* stats, void* stream);
 
+/* Tree sweep over spatially sorted samples (default of flood_complex above 3 dimensions).  Same result in the same
+ * (S, R) buffer as flooder_sweep_bvh_f32 - out_d2[s, r] = bits(min over ALL points), bit for bit - but a wave takes 64
+ * consecutive samples of a Z-order of ALL (simplex, sample) pairs instead of the samples of one simplex: tight tile
+ * boxes whatever the size of the simplices (coarse lattices on large simplices in 6D: 6x fewer box tests).
+ *   flooder_sample_key_bits(dim)   bits of a sample key (floor(32 / dim) per axis, at most 10)
+ *   flooder_sample_keys_f32        keys[s * R + r] = Morton code of sample (s, r) inside box (16 floats, [0:dim] = min,
+ *                                  [8:8+dim] = max: the cloud's box from flooder_bbox_f32); n_simplices * R < 2^32 - 1
+ *   (sort)                         flooder_index_sort(keys, n_simplices * R, key bits, ...) -> sample_order
+ *   flooder_sweep_bvh_sorted_f32   the sweep; queue = one zeroed int32; stats as flooder_sweep_bvh_f32.
+ * Replaces compute_mask + nonzero + compute_filtration (core.py:210-226) like the other sweeps. */
+int flooder_sample_key_bits(int dim);
+int flooder_sample_keys_f32(const float* verts, const float* weights, int k1, int R, int64_t n_simplices, int dim,
+                            const float* box, uint32_t* keys, void* stream);
+int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                 const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                 const int32_t* sample_order, int32_t* queue, uint32_t* out_d2, uint64_t* stats,
+                                 void* stream);
+
 /* Same sweep restricted to an explicit work list and SEEDED with the minima already in out_d2 (upper
  * bounds from an earlier pass): item_list[i] = simplex * ceil(R/64) + tile, tiles are 64 consecutive
  * samples; *n_items (device int32) entries.  Finishes what flooder_sweep_cell_f32 could not verify.

@@ -50,3 +50,45 @@ def load_e2e(name):
 
 def dict_values(fc, keys):
     return np.array([fc[k] for k in keys], dtype=np.float64)
+
+
+def kdtree_face_values(tree, landmarks, simplices, points_per_edge, d, chunk_queries=4_000_000, dtype=np.float32):
+    """Reference values of all dimension-``d`` simplices (rows of landmark ids): the reference's CPU computation
+    (``core.py:188, 197-199, 251-257``) - barycentric lattice of ``points_per_edge`` per edge on the simplex itself,
+    nearest neighbour of every sample by ``tree.query`` on all host cores, maximum over the samples.  Queried in
+    chunks so that the (queries, dim) float64 copy scipy makes stays below a few hundred MB."""
+    from oracle import flood_oracle as fo
+
+    w, _, _ = fo.generate_grid(points_per_edge, d, dtype)
+    R = w.shape[0]
+    per = max(1, chunk_queries // R)
+    out = np.empty(len(simplices), dtype=np.float64)
+    for b in range(0, len(simplices), per):
+        verts = landmarks[simplices[b:b + per]]
+        samples = np.matmul(w[None], verts).astype(dtype)
+        dist, _ = tree.query(samples, workers=-1)
+        out[b:b + per] = dist.max(axis=1)
+    return out
+
+
+def assert_tree_matches_kdtree(st, points, landmarks, points_per_edge, top, what, pick_top=None, lower=True):
+    """Every simplex of dimension ``top`` of the simplex tree ``st`` (or the rows ``pick_top`` of that table), and
+    - ``lower`` - every simplex of the dimensions below, against the kd-tree over ALL ``points``: a face of a swept
+    simplex carries the maximum over ITS OWN lattice samples (the zero weights of the parent's lattice rows contribute
+    exact zeros), so each table is checked with the lattice of its own dimension.  Returns the number of values
+    checked."""
+    from scipy.spatial import cKDTree
+
+    tree = cKDTree(points, balanced_tree=False, compact_nodes=False)
+    n = 0
+    for d in range(top, 0, -1):
+        rows = st.simplices_of_dimension(d)
+        vals = st.filtrations_of_dimension(d)
+        if d == top and pick_top is not None:
+            rows, vals = rows[pick_top], vals[pick_top]
+        ref = kdtree_face_values(tree, landmarks, rows, points_per_edge, d, dtype=points.dtype.type)
+        assert_close_filtration(vals, ref, points, f"{what}: dimension {d}")
+        n += len(rows)
+        if not lower:
+            break
+    return n

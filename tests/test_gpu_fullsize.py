@@ -11,7 +11,7 @@ import torch
 import flooder_amd as fa
 from flooder_amd import _native, core
 from oracle import flood_oracle as fo
-from helpers import assert_close_filtration
+from helpers import assert_close_filtration, assert_tree_matches_kdtree, kdtree_face_values
 
 pytestmark = pytest.mark.gpu
 
@@ -73,8 +73,8 @@ def test_cfg5_fps_16m_4k(cheese16m):
 
 def test_cfg5_full_size_16m_cheese(cheese16m, dev):
     """BASELINE cfg 5 at full size: 16 M swiss-cheese points (five-level box tree, 256 MB cloud), 4000
-    landmarks, points_per_edge 30.  The tetrahedra reaching deepest into the voids plus a random sample are
-    compared with scipy's kd-tree over all 16 M points."""
+    landmarks, points_per_edge 30.  The 200 tetrahedra reaching deepest into the voids plus 2000 random ones
+    (10 M samples) are compared with scipy's kd-tree over all 16 M points."""
     from scipy.spatial import cKDTree
     pts, tp, idx = cheese16m
     lms = tp[idx]
@@ -84,14 +84,11 @@ def test_cfg5_full_size_16m_cheese(cheese16m, dev):
     assert len(tets) > 20_000 and np.isfinite(vals).all()
     assert all(st.filtration([i]) == 0.0 for i in range(0, 4000, 97))
     P, L = pts.numpy(), lms.cpu().numpy()
-    tree = cKDTree(P, balanced_tree=False, compact_nodes=False)
-    w, _, _ = fo.generate_grid(30, 3)
     rng = np.random.default_rng(1)
-    big = np.argsort(-vals)[:15]
-    pick = np.unique(np.concatenate([big, rng.choice(len(tets), size=40, replace=False)]))
-    samples = np.matmul(w[None], L[tets[pick]])
-    dist, _ = tree.query(samples, workers=-1)
-    assert_close_filtration(vals[pick], dist.max(axis=1), P, "cfg5 tetrahedra sample")
+    big = np.argsort(-vals)[:200]                     # the 200 tetrahedra reaching deepest into the voids ...
+    pick = np.unique(np.concatenate([big, rng.choice(len(tets), size=2000, replace=False)]))   # ... + 2000 random ones
+    n = assert_tree_matches_kdtree(st, P, L, 30, 3, "cfg5 tetrahedra", pick_top=pick, lower=False)
+    assert n >= 2000
     assert float(vals[big].min()) > 5 * float(np.median(vals))
     for d in (1, 2, 3):  # monotone: faces never above cofaces (tests/test_flooder.py:207-211)
         rows = st.simplices_of_dimension(d)
@@ -103,8 +100,9 @@ def test_cfg5_full_size_16m_cheese(cheese16m, dev):
 
 def test_cfg4_full_size_2m_6d(dev):
     """BASELINE cfg 4 at full size: 2 M Gaussian points in 6D, 2000 landmarks, max_dimension 2,
-    points_per_edge 8 (the tractable setting).  A sample of triangles is compared with a 6-D
-    kd-tree; edges and vertices through the monotone rule; all assigned values finite."""
+    points_per_edge 8 (the tractable setting).  The 100 largest triangles plus 2000 random ones and
+    3000 random edges are compared with a 6-D kd-tree over all points; all triangles through the monotone rule; all
+    assigned values finite."""
     from scipy.spatial import cKDTree
     torch.manual_seed(42)
     pts = torch.randn(2_000_000, 6)
@@ -119,12 +117,10 @@ def test_cfg4_full_size_2m_6d(dev):
     assert len(tris) > 500_000 and np.isfinite(vals).all()
     L = lms.cpu().numpy()
     tree = cKDTree(P)
-    w, _, _ = fo.generate_grid(8, 2)
     rng = np.random.default_rng(2)
-    pick = np.unique(np.concatenate([np.argsort(-vals)[:10], rng.choice(len(tris), size=60, replace=False)]))
-    samples = np.matmul(w[None], L[tris[pick]])          # (n, 36, 6)
-    dist, _ = tree.query(samples, workers=-1)
-    assert_close_filtration(vals[pick], dist.max(axis=1), P, "cfg4 triangle sample")
+    pick = np.unique(np.concatenate([np.argsort(-vals)[:100], rng.choice(len(tris), size=2000, replace=False)]))
+    ref = kdtree_face_values(tree, L, tris[pick], 8, 2)          # (n, 36) samples each, 6-D kd-tree, all host cores
+    assert_close_filtration(vals[pick], ref, P, "cfg4 triangle sample")
     e = st.simplices_of_dimension(1)
     ev = st.filtrations_of_dimension(1)
     assert np.isfinite(ev).all() and (st.filtrations_of_dimension(0) == 0.0).all()
@@ -132,11 +128,8 @@ def test_cfg4_full_size_2m_6d(dev):
         loc = st._locate(1, np.delete(tris, j, axis=1))
         assert (loc >= 0).all() and (ev[loc] <= vals).all()
     # edges: their own samples (the 8 lattice points of the edge) against the kd-tree
-    pe = rng.choice(len(e), size=80, replace=False)
-    w1 = np.linspace(0.0, 1.0, 8, dtype=np.float32)
-    seg = (1 - w1)[None, :, None] * L[e[pe, 1]][:, None, :] + w1[None, :, None] * L[e[pe, 0]][:, None, :]
-    d1, _ = tree.query(seg, workers=-1)
-    assert_close_filtration(ev[pe], d1.max(axis=1), P, "cfg4 edge sample")
+    pe = rng.choice(len(e), size=3000, replace=False)
+    assert_close_filtration(ev[pe], kdtree_face_values(tree, L, e[pe], 8, 1), P, "cfg4 edge sample")
 
 
 @pytest.mark.parametrize("case", ["gauss1m", "torus300k", "eight2d", "line1d", "dups"])

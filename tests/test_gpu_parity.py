@@ -9,7 +9,7 @@ import torch
 import flooder_amd as fa
 from flooder_amd import _native, core
 from oracle import flood_oracle as fo
-from helpers import GOLDEN, assert_close_filtration, e2e_cases, load_e2e, dict_values
+from helpers import assert_tree_matches_kdtree, GOLDEN, assert_close_filtration, e2e_cases, load_e2e, dict_values
 
 pytestmark = pytest.mark.gpu
 
@@ -118,6 +118,44 @@ def test_culled_sweep_is_bit_identical_to_ball_sweep(name, dev):
         torch.manual_seed(1)
         c = fa.flood_complex(pts, lms, method="cell", **kw)
         assert a == c
+
+
+@pytest.mark.parametrize("name", ["torus3d_grid30", "eight2d_rand", "gauss6d_maxdim2"])
+def test_sorted_sample_sweep_is_bit_identical(name, dev, monkeypatch):
+    """The tree sweep over spatially sorted samples (csrc/flood_sorted.hip: tiles of 64 consecutive samples of a
+    Z-order of ALL (simplex, sample) pairs, default above 3D) against the per-simplex tree sweep and, on the golden
+    inputs, against the reference's values: not a bit may differ."""
+    z, kw, keys = load_e2e(name)
+    pts, lms = torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev)
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(core, "BVH_SORTED_SAMPLES", mode)
+        torch.manual_seed(int(z["weight_seed"]))
+        res[mode] = fa.flood_complex(pts, lms, method="bvh", **kw)
+    assert res[True] == res[False]
+    assert_close_filtration(dict_values(res[True], keys), z["filtration_f32"], z["points"], name)
+
+
+def test_sorted_sample_sweep_random_dimensions(dev, monkeypatch):
+    """Dimensions 4, 5, 7 and 8 (one key width each), ragged sample counts (R not a multiple of 64, last tile partly
+    dead), duplicated points: sorted-sample sweep == per-simplex tree sweep == kd-tree."""
+    from scipy.spatial import cKDTree
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    rng = np.random.default_rng(11)
+    for dim, n, k, ppe in ((4, 30_000, 40, 5), (5, 20_000, 30, 4), (7, 8_000, 14, 3), (8, 6_000, 12, 3)):
+        P = rng.normal(size=(n, dim)).astype(np.float32)
+        P[n // 2: n // 2 + 500] = P[:500]                 # exact duplicates
+        L = P[fo.exact_fps(P, k, 0)]
+        tp, tl = torch.as_tensor(P, device=dev), torch.as_tensor(L, device=dev)
+        out = {}
+        for mode in (True, False):
+            monkeypatch.setattr(core, "BVH_SORTED_SAMPLES", mode)
+            out[mode] = fa.flood_complex(tp, tl, max_dimension=2, points_per_edge=ppe, return_simplex_tree=True)
+        a, b = out[True], out[False]
+        for d in (1, 2):
+            assert np.array_equal(a.filtrations_of_dimension(d), b.filtrations_of_dimension(d)), (dim, d)
+        assert_tree_matches_kdtree(a, P, L, ppe, 2, f"sorted sweep dim {dim}")
 
 
 def test_landmarks_outside_cloud_match_cpu_path(dev):
@@ -341,15 +379,15 @@ def test_fuzz_methods_agree(dev):
 
 
 def test_full_size_properties_1m_gaussian(dev):
-    """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero
-    vertices, and a random sample of tetrahedra checked against the kd-tree oracle."""
+    """BASELINE cfg 2 (1 M Gaussian 3D, 1 k landmarks, ppe 30): monotone filtration, exact-zero vertices, and EVERY
+    tetrahedron, triangle and edge against the kd-tree oracle over all points (the reference's own full-size check
+    is the cross-path agreement of ``tests/test_flooder.py:119-157``; 30 M queries take seconds on the host's cores)."""
     torch.manual_seed(42)
     pts = torch.randn(1_000_000, 3)
     tp = pts.to(dev)
     lms = fa.generate_landmarks(tp, 1000, start_idx=0)
     st = fa.flood_complex(tp, lms, return_simplex_tree=True)
-    assert all(st.filtration([i]) == 0.0 for i in range(0, 1000, 37))
-    tets = st.simplices_of_dimension(3)
+    assert all(st.filtration([i]) == 0.0 for i in range(1000))
     vals = st.filtrations_of_dimension(3)
     assert np.isfinite(vals).all()
     for d in (1, 2, 3):  # faces never above cofaces
@@ -358,27 +396,15 @@ def test_full_size_properties_1m_gaussian(dev):
         for j in range(d + 1):
             idx = st._locate(d - 1, np.delete(rows, j, axis=1))
             assert (st.filtrations_of_dimension(d - 1)[idx] <= own).all()
-    # oracle on a sample of tetrahedra: their own value before monotonisation can only be lower, so
-    # compare max(own sweep value, faces) == tree value through the same rule
-    from scipy.spatial import KDTree
-    P = pts.numpy()
-    L = lms.cpu().numpy()
-    tree = KDTree(P)
-    w, v_idx, f_idx = fo.generate_grid(30, 3)
-    rng = np.random.default_rng(0)
-    pick = rng.choice(len(tets), size=40, replace=False)
-    samples = np.matmul(w[None], L[tets[pick]])
-    dist, _ = tree.query(samples)
-    ref = dist.max(axis=1)
-    assert_close_filtration(vals[pick], ref, P, "1M gaussian tetrahedra sample")
+    n = assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, "cfg2 1M gaussian")
+    assert n == sum(len(st.simplices_of_dimension(d)) for d in (1, 2, 3)) and n > 25_000
 
 
 @pytest.mark.parametrize("cloud", ["torus", "cheese"])
 def test_full_size_far_field_clouds_match_oracle_sample(dev, cloud):
     """BASELINE cfg 3 (1 M noisy torus) and a 2 M-point slice of cfg 5 (swiss cheese): samples inside the tube /
-    the voids lie far from every point, so most of their tiles take the exact tree finish.  A random sample of
-    tetrahedra is checked against the kd-tree oracle, tetrahedra crossing the empty regions included."""
-    from scipy.spatial import KDTree
+    the voids lie far from every point, so most of their tiles take the exact tree finish.  EVERY tetrahedron,
+    triangle and edge is checked against the kd-tree oracle, the ones crossing the empty regions included."""
     if cloud == "torus":
         pts = fa.generate_noisy_torus_points_3d(1_000_000, seed=42)
         n_lms = 1000
@@ -388,19 +414,11 @@ def test_full_size_far_field_clouds_match_oracle_sample(dev, cloud):
     tp = pts.to(dev)
     lms = fa.generate_landmarks(tp, n_lms, start_idx=0)
     st = fa.flood_complex(tp, lms, return_simplex_tree=True)
-    tets = st.simplices_of_dimension(3)
     vals = st.filtrations_of_dimension(3)
     assert np.isfinite(vals).all()
-    P, L = pts.numpy(), lms.cpu().numpy()
-    tree = KDTree(P)
-    w, _, _ = fo.generate_grid(30, 3)
-    rng = np.random.default_rng(1)
+    assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, f"{cloud} full check")
     big = np.argsort(-vals)[:15]                      # the farthest-reaching tetrahedra: tube interior / voids
-    pick = np.unique(np.concatenate([big, rng.choice(len(tets), size=25, replace=False)]))
-    samples = np.matmul(w[None], L[tets[pick]])
-    dist, _ = tree.query(samples)
-    assert_close_filtration(vals[pick], dist.max(axis=1), P, f"{cloud} tetrahedra sample")
-    assert float(vals[big].min()) > 5 * float(np.median(vals))    # the sample really contains far-field tetrahedra
+    assert float(vals[big].min()) > 5 * float(np.median(vals))    # the complex really contains far-field tetrahedra
 
 
 def test_degenerate_density_clouds_gpu(dev):

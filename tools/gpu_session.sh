@@ -31,18 +31,53 @@ for s in $STEPS; do
             cat $OUT/phase_timers.txt; head -20 $OUT/chunk_times_1.txt; cat $OUT/bvh_phase_cfg3.txt ;;
     ab:*)   # ab:<workload>:<name>:<flags with , for space>   one bench line per variant
             IFS=: read -r _ wl name flags <<< "$s"
-            timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 ${flags//,/ } > $OUT/ab_${wl}_${name}.json 2> $OUT/ab_${wl}_${name}.err
+            timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 --no-cold ${flags//,/ } > $OUT/ab_${wl}_${name}.json 2> $OUT/ab_${wl}_${name}.err
             python - "$OUT/ab_${wl}_${name}.json" "$wl $name" <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     st = d["config"]["sweep_stats_rank0"] or {}
     print(sys.argv[2], "ms/step", d["ms_per_step"], "+-", d["ms_per_step_std"], {k: v["ms_per_step"] for k, v in d["kernels"].items()},
-          {k: st.get(k) for k in ("tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds", "deferred_chunks", "chunks_total", "finish_shared_rounds")})
+          {k: st.get(k) for k in ("leaves_evaluated_per_tile", "leaves_tested_per_tile", "nodes_expanded_per_tile", "tiles_flagged", "fallback_leaves_evaluated", "fallback_nodes_expanded", "finish_tiles_dropped_on_arrival", "finish_samples_live_on_arrival", "finish_focus_rounds", "exhaustive_rounds", "deferred_chunks", "chunks_total", "finish_shared_rounds")})
 except Exception as e:
     print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-600:])
 PY
             ;;
+    var:*)  # var:<lib in gpurun_in/ without .so | product>:<workload>:<name>[:<flags with , for space>]  bench line of a library variant
+            IFS=: read -r _ lib wl name flags <<< "$s"
+            if [ "$lib" != product ]; then export FLOODER_HIP_LIB=$R/gpurun_in/$lib.so; fi
+            timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 --no-cold ${flags//,/ } > $OUT/var_${wl}_${name}.json 2> $OUT/var_${wl}_${name}.err
+            unset FLOODER_HIP_LIB
+            python - "$OUT/var_${wl}_${name}.json" "$wl $name" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(sys.argv[2], "ms/step", d["ms_per_step"], "+-", d["ms_per_step_std"], "min", d["ms_per_step_min"], {k: v["ms_per_step"] for k, v in d["kernels"].items()})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-600:])
+PY
+            ;;
+    lds:*)  # LDS counters of the sweep kernels: bank conflicts, LDS-array cycles
+            wl=${s#lds:}
+            ( cd /tmp && export TMPDIR=/tmp
+              timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_lds_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-cold > $OUT/lds_$wl.json 2> $OUT/lds_$wl.err )
+            python - $OUT $wl > $OUT/lds_summary_$wl.txt <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(f"{sys.argv[1]}/pmc_lds_{sys.argv[2]}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "anonymous namespace" not in k: continue
+        k = k.split("(anonymous namespace)::")[1].split("(")[0]
+        a = acc[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+last = None
+for (k, c) in sorted(acc):
+    v, n = acc[(k, c)]
+    if k != last: print(k); last = k
+    print(f"    {c:32s} {v / n:14.4g} per launch ({n} launches)")
+PY
+            grep -A8 "cell_sweep\|finish_faces\|sweep_bvh\|sweep_sorted" $OUT/lds_summary_$wl.txt
+            rm -rf $OUT/pmc_lds_$wl ;;
     pytest:*) k="${s#pytest:}"; timeout 1200 python -m pytest tests -m gpu -x -q -k "${k//,/ }" > $OUT/pytest_k.txt 2>&1; tail -8 $OUT/pytest_k.txt ;;
     trace:*) # per-dispatch durations of the finish passes (probe, top, rest) from a kernel trace
             wl=${s#trace:}
@@ -92,7 +127,7 @@ PY
             ( cd /tmp && export TMPDIR=/tmp
               timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_icache_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-cold > $OUT/icache_$wl.json 2> $OUT/icache_$wl.err
               timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_inst_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-cold > $OUT/inst_$wl.json 2>> $OUT/icache_$wl.err )
-            python - $OUT $wl <<'PY'
+            python - $OUT $wl > $OUT/icache_summary_$wl.txt <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(f"{sys.argv[1]}/pmc_i*_{sys.argv[2]}/**/*counter_collection.csv", recursive=True):
@@ -108,7 +143,8 @@ for (k, c) in sorted(acc):
     if k != last: print(k); last = k
     print(f"    {c:32s} {v / n:14.4g} per launch ({n} launches)")
 PY
-            find $OUT -name "*.csv" -size +4M -delete ;;
+            grep -A17 "cell_sweep\|finish_faces\|sweep_bvh" $OUT/icache_summary_$wl.txt
+            rm -rf $OUT/pmc_icache_$wl $OUT/pmc_inst_$wl ;;
     tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
   esac
