@@ -60,7 +60,7 @@ WORKLOADS = {
                     cpu_sample=400),
 }
 
-KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "sweep_bvh": "sweep_bvh_kernel", "sweep_ball": "sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
+KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "sweep_bvh": "sweep_bvh_kernel / sample_keys + radix sort + sweep_sorted_kernel", "sweep_ball": "sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
                   "face_max": "face_values_kernel", "reduce": "all_reduce(MIN)",
                   "index": "index build (bbox, curve codes, rocprim radix sort, gather, box tree)",
                   "ball_count": "ball_scan_kernel<count>", "ball_fill": "ball_scan_kernel<fill>"}
@@ -428,13 +428,17 @@ def main():
     if args.method == "bvh":
         sh = stats.cpu().tolist()
         ks = 2 if R > 64 else 1
-        per_kernel[sweep_span] = dict(pairs=sh[0] * 16 * min(64 * ks, R), share=1.0)
-        n_tiles = S * ((R + 64 * ks - 1) // (64 * ks))
+        sorted_tiles = core.bvh_sorts_samples(w["dim"], S, R)   # tiles of 64 consecutive samples of ALL simplices
+        per_tile = 64 if sorted_tiles else min(64 * ks, R)
+        per_kernel[sweep_span] = dict(pairs=sh[0] * 16 * per_tile, share=1.0)
+        n_tiles = (S * R + 63) // 64 if sorted_tiles else S * ((R + 64 * ks - 1) // (64 * ks))
         st_h = {"leaves_evaluated": sh[0], "leaves_tested": sh[1], "nodes_expanded": sh[2], "tiles_total": n_tiles,
                 "leaves_evaluated_per_tile": round(sh[0] / max(n_tiles, 1), 2),
                 "leaves_tested_per_tile": round(sh[1] / max(n_tiles, 1), 2),
                 "nodes_expanded_per_tile": round(sh[2] / max(n_tiles, 1), 2),
-                "max_tests_one_tile": sh[3], "samples_per_tile": min(64 * ks, R), "lanes_per_tile": 64}
+                "max_tests_one_tile": sh[3], "samples_per_tile": per_tile, "lanes_per_tile": 64,
+                "tiles": "64 consecutive samples of a Z-order of all (simplex, sample) pairs" if sorted_tiles
+                         else "samples of one simplex"}
     elif args.method == "cell":
         sh = stats.cpu().tolist()
         tiles_total = S * ((R + 63) // 64)

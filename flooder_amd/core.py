@@ -658,6 +658,12 @@ def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: t
     return out_face, out_dist
 
 
+def bvh_sorts_samples(dim: int, S: int, R: int) -> bool:
+    """Does the tree sweep of S simplices x R samples in ``dim`` dimensions run over spatially sorted samples?"""
+    want = BVH_SORTED_SAMPLES if BVH_SORTED_SAMPLES is not None else dim > 3
+    return bool(want) and BVH_SORTED_MIN_SAMPLES <= S * R < (1 << 32) - 2
+
+
 def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
                          reduce_hook: Optional[Callable[[torch.Tensor], None]],
                          want_dist: bool = False, timer: Optional[_KernelTimer] = None,
@@ -679,8 +685,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     queue = torch.zeros(1, dtype=torch.int32, device=dev)
-    sorted_samples = (BVH_SORTED_SAMPLES if BVH_SORTED_SAMPLES is not None else index.dim > 3) \
-        and BVH_SORTED_MIN_SAMPLES <= S * R < (1 << 32) - 2
+    sorted_samples = bvh_sorts_samples(index.dim, S, R)
     with _span(timer, "sweep"):
         if sorted_samples:
             # tiles of 64 spatially consecutive samples of ALL simplices (Z-order keys, one radix sort) instead of

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
         }
         const int j = __builtin_ctzll(__ballot(lbv == mn));
         if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
-        const int64_t c = s_grp[wv][lvl] * FAN + j;
+        const int64_t c = wave_uniform64(s_grp[wv][lvl]) * FAN + j;  // (readfirstlane: keeps the leaf address scalar, rows in SGPRs)
         --lvl;
         const float lb = child_bounds(lvl, c);
         ++n_node_test;

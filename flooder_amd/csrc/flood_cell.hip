@@ -68,12 +68,14 @@ __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint
   load_row<DP>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)byte_off), out);
 }
 
-// One staged point (x, y, z, -) from LDS.  The fourth word is not needed, and left to itself the compiler reads 12
-// bytes: ds_read_b96 takes 8 LDS cycles per wave instruction where ds_read_b128 takes 4 (MI355X_MICROARCH.md, LDS
-// table) - keeping .w "used" (an empty asm statement, no instruction) makes it the 16-byte read.
+// One staged point (x, y, z, -) from LDS.  The fourth word is not needed and the compiler reads 12 bytes
+// (ds_read_b96).  Forcing the 16-byte read (-DFLOODER_LDS_B128: .w kept "used" by an empty asm statement) halves the
+// LDS cycles per instruction on paper and measured SLOWER: sweep 1.46 vs 1.38 ms (cfg 2), 2.54 vs 2.48 (cfg 3), 8.93
+// vs 8.61 (cfg 5) - the LDS array is busy 14 % of the kernel (SQ_LDS_IDX_ACTIVE), the query waits on latency, not on
+// LDS bandwidth, and the extra live register per point in flight costs more than the cycles save.
 __device__ __forceinline__ float4 lds_point(const float4* p) {
   const float4 v = *p;
-#ifndef FLOODER_LDS_B96
+#ifdef FLOODER_LDS_B128
   asm volatile("" ::"v"(v.w));
 #endif
   return v;

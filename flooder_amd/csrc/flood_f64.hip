@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_f64_kernel(
         }
         const int j = __builtin_ctzll(__ballot(lbv == mn));
         if (lane == j) s_lb[wv][lvl][lane] = INF;  // visited
-        const int64_t c = s_grp[wv][lvl] * FAN + j;
+        const int64_t c = wave_uniform64(s_grp[wv][lvl]) * FAN + j;  // (readfirstlane: keeps the leaf address scalar, rows in SGPRs)
         --lvl;
         const double lb = child_bounds(lvl, c);
         if (lvl > 0) {

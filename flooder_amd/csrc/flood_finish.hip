@@ -27,7 +27,13 @@ namespace {
 
 constexpr float SAFE = 0.99999f;
 constexpr int SHORT_LIST = 1024;
-constexpr int TOP_NODES = 1024;  // nodes of the two top tree levels kept in LDS (32 KB in 3D)
+#ifndef FLOODER_TOP_NODES
+#define FLOODER_TOP_NODES 1024
+#endif
+#ifndef FLOODER_FINISH_WAVES
+#define FLOODER_FINISH_WAVES 4
+#endif
+constexpr int TOP_NODES = FLOODER_TOP_NODES;  // nodes of the two top tree levels kept in LDS (32 KB in 3D)
 
 // Hard tiles.  A sample near the medial axis of the cloud is almost equidistant to thousands of leaves, and a tile of
 // such samples keeps ONE wave busy for milliseconds while the rest of the chip idles at the end of the pass (and on
@@ -53,7 +59,7 @@ struct HardLists {
 constexpr int TEAM_WAVES = 16;
 
 template <int DIM, bool TEAM>
-__global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, 4) void finish_faces_kernel(
+__global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FINISH_WAVES) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_sorted,
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, 4) void finish_faces_
           }
           const int j = __builtin_ctzll(__ballot(lbv == mn));
           if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
-          const int64_t c = s_grp[wv][lvl] * FAN + j;
+          const int64_t c = wave_uniform64(s_grp[wv][lvl]) * FAN + j;  // (readfirstlane: keeps the leaf address scalar, rows in SGPRs)
           --lvl;
           const float lb = child_bounds(lvl, c);
           ++n_node_test;

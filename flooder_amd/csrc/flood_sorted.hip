@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
         }
         const int j = __builtin_ctzll(__ballot(lbv == mn));
         if (lane == j) s_lb[wv][lvl][lane] = __builtin_inff();  // visited
-        const int64_t c = s_grp[wv][lvl] * FAN + j;
+        // (the group index comes back from LDS in a VGPR: without the readfirstlane the compiler cannot know the
+        // leaf address below is wave-uniform and loads the 16 rows of a leaf into VGPRs instead of SGPRs)
+        const int64_t c = wave_uniform64(s_grp[wv][lvl]) * FAN + j;
         --lvl;
         const float lb = child_bounds(lvl, c);
         ++n_node_test;
@@ -211,13 +213,16 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       if (__ballot(lbp * SAFE < best) == 0ull) continue;
       ++n_leaf_eval;
       const float* cp = pts + c * (int64_t)LEAF * DP;
+      // rows stream through SGPRs (scalar loads), UB at a time: 8 rows of 8 floats would need 64 SGPRs on top of the
+      // traversal's own and spill into VGPRs (110 VGPRs = 4 waves per SIMD in 6D); 4 rows keep the kernel at 8 waves
+      constexpr int UB = DP == 8 ? 4 : 8;
 #pragma unroll
-      for (int h = 0; h < LEAF; h += 8) {
-        typename RowVec<DP>::type cc[8];
+      for (int h = 0; h < LEAF; h += UB) {
+        typename RowVec<DP>::type cc[UB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
+        for (int u = 0; u < UB; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
+        for (int u = 0; u < UB; u += 2) {
           float da, db;
 #pragma unroll
           for (int k = 0; k < DIM; ++k) {
@@ -265,7 +270,17 @@ struct SweepSortedOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                  int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
                  unsigned long long* stats, hipStream_t st) {
-    hipLaunchKernelGGL((sweep_sorted_kernel<DIM>), dim3(g_bvh_grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
+    // persistent blocks of 4 independent waves, as many as the registers let a CU hold (asked once per dimension)
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+      blocks_per_cu = nb > 8 ? 8 : nb;
+    }
+    const int64_t n_tiles = (n_samples + 63) / 64;
+    int64_t grid = (int64_t)blocks_per_cu * 256;
+    if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
+    hipLaunchKernelGGL((sweep_sorted_kernel<DIM>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
                        k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct);
     return check_launch("sweep_sorted");
   }
