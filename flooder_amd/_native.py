@@ -74,6 +74,9 @@ SIGNATURES = {
     "flooder_fps_bucket_count": (c_int64, [c_int64]),
     "flooder_fps_indexed_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_fps_batched_slot_words": (c_int64, [c_int]),
+    "flooder_fps_batched_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
 }

@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
 
-HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip"]
+HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip"]
 HOST_SOURCES = ["persistence.cpp"]
 
 

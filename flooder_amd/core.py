@@ -133,16 +133,19 @@ def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int]
 
 FPS_METHOD = "auto"   # "bucket" (dim <= 3: bucketed over the curve-sorted cloud), "brute" (one full sweep per landmark)
 FPS_BUCKET_MIN_POINTS = 200_000   # below this a brute-force step costs no more than its launch
-FPS_BUCKET_MAX_DIM = 3            # ambient dimensions the bucketed selection supports
+FPS_BUCKET_MAX_DIM = 8            # ambient dimensions the bucketed selection supports
+FPS_BATCHED = True                # several landmarks per launch (flooder_fps_batched_f32); False: one per launch, dim <= 3
+LAST_FPS_LAUNCHES = 0             # kernel launches of the last batched selection (diagnostic)
 
 
 def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Optional[str] = None,
                 index: Optional["PointIndex"] = None) -> torch.Tensor:
     """Indices of the exact FPS order starting at ``start_idx`` (int64, on ``points.device``).
 
-    ROCm tensors: ``method="bucket"`` (default for dim <= 3 and large clouds) runs ``flooder_fps_indexed_f32`` over
-    the Hilbert-sorted copy of the cloud (``index``: a ``PointIndex`` of ``points`` to reuse, else built here);
-    ``method="brute"`` runs ``flooder_fps_f32``.  Both give the same indices."""
+    ROCm tensors: ``method="bucket"`` (default for large clouds) runs ``flooder_fps_batched_f32`` - exact FPS over
+    buckets of the curve-sorted copy of the cloud, several landmarks per launch (``FPS_BATCHED = False``: one per
+    launch, ``flooder_fps_indexed_f32``, dim <= 3) - (``index``: a ``PointIndex`` of ``points`` to reuse, else built
+    here); ``method="brute"`` runs ``flooder_fps_f32``.  All give the same indices."""
     if points.is_cuda:
         lib = _native.load()
         dim = points.shape[1]
@@ -159,6 +162,29 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
         if method == "bucket" and dim > FPS_BUCKET_MAX_DIM:
             raise ValueError(f"bucketed FPS supports ambient dimension <= {FPS_BUCKET_MAX_DIM}")
         out_idx = torch.empty(n_lms, dtype=torch.int64, device=pts.device)
+        if method == "bucket" and (FPS_BATCHED or dim > 3):
+            global LAST_FPS_LAUNCHES
+            import ctypes
+            index = index if index is not None else PointIndex(pts)
+            nb = int(lib.flooder_fps_bucket_count(n))
+            dp = index.dp
+            minsq = torch.empty(n, dtype=torch.float32, device=pts.device)
+            box = torch.empty(2 * dp * nb, dtype=torch.float32, device=pts.device)
+            keys = torch.empty(2 * nb, dtype=torch.int64, device=pts.device)
+            n_slot = int(lib.flooder_fps_batched_slot_words(n_lms))
+            zeroed = torch.zeros(64 * n_lms + n_slot + (n_lms + 4 + 1) // 2, dtype=torch.int64, device=pts.device)
+            work_best, work_slots = zeroed[:64 * n_lms], zeroed[64 * n_lms:64 * n_lms + n_slot]
+            work_ctr = zeroed[64 * n_lms + n_slot:].view(torch.int32)
+            launches = ctypes.c_int32(0)
+            with torch.cuda.device(pts.device):
+                st = _native.current_stream_ptr(pts.device)
+                _native.check(lib.flooder_fps_batched_f32(
+                    _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
+                    int(start_idx), _native.ptr(out_idx), _native.ptr(minsq), _native.ptr(box), _native.ptr(keys),
+                    _native.ptr(work_best), _native.ptr(work_slots), _native.ptr(work_ctr),
+                    ctypes.addressof(launches), st), "flooder_fps_batched_f32")
+            LAST_FPS_LAUNCHES = int(launches.value)
+            return out_idx
         if method == "bucket":
             index = index if index is not None else PointIndex(pts)
             nb = int(lib.flooder_fps_bucket_count(n))
