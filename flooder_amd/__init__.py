@@ -6,7 +6,8 @@ script is ``python -m flooder_amd.cli``.  ROCm tensors run hand-written HIP kern
 (``libflooder_hip.so``, C ABI in ``include/flooder_hip.h``); see DESIGN.md.
 """
 
-from .core import flood_complex, generate_landmarks, generate_grid, generate_uniform_weights
+from .core import (flood_complex, generate_landmarks, generate_grid, generate_uniform_weights, PointIndex,
+                   index_from_host)
 from .simplex_tree import SimplexTree, DelaunayComplex
 from .io import save_to_disk
 from .synthetic import (
@@ -23,6 +24,8 @@ __all__ = [
     "generate_landmarks",
     "generate_grid",
     "generate_uniform_weights",
+    "PointIndex",
+    "index_from_host",
     "SimplexTree",
     "DelaunayComplex",
     "save_to_disk",

@@ -35,6 +35,8 @@ SIGNATURES = {
     "flooder_face_max_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p]),
     "flooder_bbox_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_bbox_chunk_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "flooder_bbox_reduce_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_curve_key_bits": (c_int, [c_int]),
     "flooder_index_sort_bytes": (c_int64, [c_int64]),

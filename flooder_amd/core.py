@@ -41,7 +41,7 @@ from . import _native
 from .simplex_tree import HAS_GUDHI, SimplexTree, delaunay_cells, delaunay_simplices
 
 __all__ = ["flood_complex", "generate_landmarks", "generate_grid", "generate_uniform_weights",
-           "SUPPORTED_DTYPES", "HAS_HIP_KERNELS"]
+           "SUPPORTED_DTYPES", "HAS_HIP_KERNELS", "PointIndex", "index_from_host"]
 
 # dtype whitelist of the reference (``tl_dtypes_dict``, triton_kernels.py:226-229)
 SUPPORTED_DTYPES = (torch.float32, torch.float64)
@@ -494,7 +494,7 @@ class PointIndex:
               one level per factor 64, every level padded to a multiple of 64 nodes
     """
 
-    def __init__(self, points: torch.Tensor, timer: Optional[_KernelTimer] = None):
+    def __init__(self, points: torch.Tensor, timer: Optional[_KernelTimer] = None, box: Optional[torch.Tensor] = None):
         lib = _native.load()
         dev = points.device
         st = _native.current_stream_ptr(dev)
@@ -502,7 +502,7 @@ class PointIndex:
         n, dim = pts32.shape
         self.n, self.dim = n, dim
         self.dp = lib.flooder_padded_dim(dim)
-        self.box = cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
+        self.box = box if box is not None else cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
         codes = torch.empty(n, dtype=torch.int64, device=dev)
         with _span(timer, "morton"):
             _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
@@ -526,6 +526,65 @@ class PointIndex:
             _native.check(lib.flooder_index_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
                                                      _native.ptr(self.pts), n_pad, _native.ptr(self.nodes), st),
                           "flooder_index_rows_f32")
+
+
+def index_from_host(points_cpu: torch.Tensor, device, chunk_rows: int = 1 << 21):
+    """``PointIndex`` of a cloud that lives in HOST memory, streamed to the GPU in chunks (BASELINE.json configs[4]:
+    "chunked point streaming from host pinned memory"; the reference bounds its device working set with
+    ``batch_size`` slabs instead, ``core.py:193-217``).  The cloud is copied chunk by chunk from pinned memory on a
+    copy stream (``points_cpu`` is pinned first if it is not: one extra host copy) while the bounding-box reduction of
+    the chunks already landed runs on the compute stream; the curve codes need the box of the WHOLE cloud, so the
+    sort starts when the last chunk is in.  Returns ``(index, points_dev)``: pass both on -
+    ``flood_complex(points_dev, landmarks, index=index)``.  ``h2d_ms_of(index)`` = time from the first copy to
+    the box being known (events on the compute stream)."""
+    lib = _native.load()
+    dev = torch.device(device)
+    src = points_cpu.detach().to(torch.float32).contiguous()
+    if src.device.type != "cpu":
+        raise ValueError("index_from_host: points_cpu must be a CPU tensor")
+    if not src.is_pinned():
+        src = src.pin_memory()
+    n, dim = src.shape
+    if dim > 8 or n < 1:
+        raise RuntimeError("flooder_amd: index_from_host needs 1 <= dim <= 8 and at least one point")
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        copy = torch.cuda.Stream(dev)
+        raw = torch.empty((n, dim), dtype=torch.float32, device=dev)
+        n_chunks = (n + chunk_rows - 1) // chunk_rows
+        blocks = 64
+        partial = torch.empty(n_chunks * blocks * 16, dtype=torch.float32, device=dev)
+        box = torch.empty(16, dtype=torch.float32, device=dev)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(main)
+        copy.wait_stream(main)
+        for c in range(n_chunks):
+            a, b = c * chunk_rows, min(n, (c + 1) * chunk_rows)
+            with torch.cuda.stream(copy):
+                raw[a:b].copy_(src[a:b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            main.wait_event(ev)
+            _native.check(lib.flooder_bbox_chunk_f32(raw[a:b].data_ptr(), b - a, dim, dim,
+                                                     partial[c * blocks * 16:].data_ptr(), blocks, main.cuda_stream),
+                          "flooder_bbox_chunk_f32")
+        _native.check(lib.flooder_bbox_reduce_f32(_native.ptr(partial), n_chunks * blocks, dim, _native.ptr(box),
+                                                  main.cuda_stream), "flooder_bbox_reduce_f32")
+        t1.record(main)
+        index = PointIndex(raw, box=box)
+        raw.record_stream(copy)
+        index._h2d_events = (t0, t1)
+    return index, raw
+
+
+def h2d_ms_of(index: "PointIndex") -> Optional[float]:
+    """Milliseconds from the first chunk's copy to the bounding box of a cloud streamed by ``index_from_host``
+    (synchronises the device)."""
+    ev = getattr(index, "_h2d_events", None)
+    if ev is None:
+        return None
+    torch.cuda.synchronize()
+    return float(ev[0].elapsed_time(ev[1]))
 
 
 def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.ndarray], device):

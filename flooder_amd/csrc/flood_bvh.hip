@@ -724,6 +724,24 @@ struct BboxOp {
   }
 };
 
+// the two stages of BboxOp on their own: a cloud that arrives in chunks (host -> device copies on another stream)
+// has every chunk reduced as soon as it lands, into its own rows of `partial`
+template <int DIM>
+struct BboxChunkOp {
+  static int run(const float* pts, int64_t n, int ld, float* partial, int n_blocks, hipStream_t st) {
+    hipLaunchKernelGGL((bbox_partial_kernel<DIM>), dim3(n_blocks), dim3(256), 0, st, pts, n, ld, partial);
+    return check_launch("bbox_chunk");
+  }
+};
+
+template <int DIM>
+struct BboxReduceOp {
+  static int run(const float* partial, int n_partial, float* box, hipStream_t st) {
+    hipLaunchKernelGGL((bbox_final_kernel<DIM>), dim3(1), dim3(256), 0, st, partial, n_partial, box);
+    return check_launch("bbox_reduce");
+  }
+};
+
 template <int DIM>
 struct BuildOp {
   static int run(const float* pts, int64_t n_pts, const Levels& lv, float* nodes, hipStream_t st) {
@@ -816,6 +834,19 @@ int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* bo
   if (!pts || !box || !partial || n_pts < 1 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
     return fail(FLOODER_E_ARG, "flooder_bbox_f32: bad argument");
   return dispatch_dim<BboxOp>(dim, pts, n_pts, ld, box, partial, (hipStream_t)stream);
+}
+
+int flooder_bbox_chunk_f32(const float* pts, int64_t n_rows, int dim, int ld, float* partial, int n_blocks,
+                           void* stream) {
+  if (!pts || !partial || n_rows < 1 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM || n_blocks < 1 || n_blocks > 65535)
+    return fail(FLOODER_E_ARG, "flooder_bbox_chunk_f32: bad argument");
+  return dispatch_dim<BboxChunkOp>(dim, pts, n_rows, ld, partial, n_blocks, (hipStream_t)stream);
+}
+
+int flooder_bbox_reduce_f32(const float* partial, int n_partial, int dim, float* box, void* stream) {
+  if (!partial || !box || n_partial < 1 || dim < 1 || dim > FLOODER_MAX_DIM)
+    return fail(FLOODER_E_ARG, "flooder_bbox_reduce_f32: bad argument");
+  return dispatch_dim<BboxReduceOp>(dim, partial, n_partial, box, (hipStream_t)stream);
 }
 
 int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,

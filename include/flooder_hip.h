@@ -149,6 +149,15 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
  * of core.py:140-142 without a host round trip. */
 int flooder_bbox_f32(const float* pts, int64_t n_pts, int dim, int ld, float* box, float* partial, void* stream);
 
+/* The two stages of flooder_bbox_f32 on their own, for a cloud that arrives in chunks (BASELINE.json configs[4]:
+ * points streamed from pinned host memory; the reference's counterpart is its batch-bounded slabs, core.py:193-217):
+ * flooder_bbox_chunk_f32 reduces the n_rows rows of one chunk with n_blocks blocks into partial[0 : 16 * n_blocks]
+ * as soon as the chunk's copy has landed (enqueue it behind the copy's event), flooder_bbox_reduce_f32 folds the
+ * n_partial rows of all chunks into box.  flooder_amd.PointIndex.from_host is the caller. */
+int flooder_bbox_chunk_f32(const float* pts, int64_t n_rows, int dim, int ld, float* partial, int n_blocks,
+                           void* stream);
+int flooder_bbox_reduce_f32(const float* partial, int n_partial, int dim, float* box, void* stream);
+
 /* 64-bit space-filling-curve codes of the points relative to `box` (DEVICE, layout of flooder_bbox_f32);
  * floor(63/dim) (max 21) bits per axis.  The caller sorts the cloud by these codes.  Hilbert codes by
  * default (option "curve" = 1; 0 = Morton / Z-order): consecutive points are neighbours in space, so the

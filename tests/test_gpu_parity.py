@@ -158,6 +158,30 @@ def test_sorted_sample_sweep_random_dimensions(dev, monkeypatch):
         assert_tree_matches_kdtree(a, P, L, ppe, 2, f"sorted sweep dim {dim}")
 
 
+def test_index_from_host_streams_the_cloud_and_index_kwarg_reuses_it(dev):
+    """BASELINE cfg 5's "chunked point streaming from host pinned memory" (``core.index_from_host``): the index built
+    from chunked pinned-memory copies equals the index of the resident cloud bit for bit, and
+    ``flood_complex(..., index=...)`` returns what a call without it returns (3D: cell sweep; 6D: tree sweep)."""
+    rng = np.random.default_rng(3)
+    for dim, n, k, kw in ((3, 300_000, 120, dict(points_per_edge=12)), (6, 50_000, 20, dict(max_dimension=2, points_per_edge=5))):
+        P = rng.normal(size=(n, dim)).astype(np.float32)
+        L = P[fo.exact_fps(P, k, 0)]
+        tp, tl = torch.as_tensor(P, device=dev), torch.as_tensor(L, device=dev)
+        idx_s, raw = core.index_from_host(torch.as_tensor(P), dev, chunk_rows=70_001)   # ragged last chunk
+        idx_r = core.PointIndex(tp)
+        assert torch.equal(raw, tp) and torch.equal(idx_s.box, idx_r.box)
+        assert torch.equal(idx_s.pts, idx_r.pts) and torch.equal(idx_s.order32, idx_r.order32)
+        assert torch.equal(idx_s.nodes, idx_r.nodes)
+        assert core.h2d_ms_of(idx_s) > 0.0
+        a = fa.flood_complex(raw, tl, index=idx_s, **kw)
+        b = fa.flood_complex(tp, tl, **kw)
+        assert a == b
+        with pytest.raises(ValueError):
+            fa.flood_complex(tp[:1000], tl, index=idx_s, **kw)
+    got = fa.flood_complex(raw, 20, index=idx_s, max_dimension=1, points_per_edge=4)     # landmarks by count + index
+    assert got == fa.flood_complex(tp, 20, max_dimension=1, points_per_edge=4)
+
+
 def test_landmarks_outside_cloud_match_cpu_path(dev):
     """Landmarks that are NOT points of the cloud: the culled sweep still returns the exact value of
     the reference CPU path (the reference's own GPU path is only a bound there)."""
