@@ -324,6 +324,7 @@ class SweepStats:
         self.slab_points = 0         # ball tests
         self.groups = 0
         self.deferred_chunks = 0     # chunks the run-of-four launch handed to the per-chunk launch
+        self.dense_tiles = 0         # tiles of 64 samples the per-chunk launch handed to the tile launch
         self.hard_entries = (0, 0)   # tiles the finish gave to a whole workgroup (top pass, rest pass)
 
 
@@ -884,8 +885,9 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
         flags = torch.empty((3, S * tiles), dtype=torch.int32, device=dev)  # flagged tiles, their bounds, ordered
         chunks = (R + 255) // 256
-        defer_list = torch.empty(S * chunks, dtype=torch.int32, device=dev) if CELL_SUPER else None
-        defer_c = torch.empty(S * chunks, dtype=torch.float32, device=dev) if CELL_SUPER else None
+        # (chunk entries, then up to four tile entries per chunk: dense chunks hand their tiles to a third launch)
+        defer_list = torch.empty(5 * S * chunks, dtype=torch.int32, device=dev) if CELL_SUPER else None
+        defer_c = torch.empty(5 * S * chunks, dtype=torch.float32, device=dev) if CELL_SUPER else None
         wgt = None
         split = torch.empty((2, S), dtype=torch.int32, device=dev) if CELL_SUPER else None  # light / heavy simplices
         if CELL_SUPER:  # rough point count per simplex box: dense simplices skip the run-of-four launch
@@ -914,6 +916,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
+            LAST_STATS.dense_tiles = int(ctl[18].item())
             c_h = ctl[24:48].tolist()
             LAST_STATS.hard_entries = (int(c_h[5]), int(c_h[7]))
         out_face = torch.empty(n_slots if face_slots is not None else (S, F), dtype=torch.float32, device=dev)

@@ -28,8 +28,7 @@ using namespace flooder;
 
 namespace {
 
-constexpr int CHUNK = 256;        // samples per wave item
-constexpr int SPL = CHUNK / 64;   // samples per lane
+constexpr int SPL_CHUNK = 4;      // samples per lane of a chunk item (256 samples per wave)
 constexpr int CAPW = 480;         // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
 constexpr int MAXLEAF = 896;      // leaves gathered per wave item (14 K points before filtering)
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
@@ -106,6 +105,12 @@ struct DeferList {
   const int32_t* heavy;
   const int32_t* split;
   int n0_limit;         // a run with more points than this inside its box is not staged either
+  // dense chunks: a per-chunk item whose kept points overflow the LDS stage hands its open tiles of 64 samples on to
+  // a third launch (SPLV = 1: one sample per lane, a re-centred region a quarter the size, which mostly fits the stage)
+  // instead of evaluating every kept point against every sample.  entry = (simplex * tiles + tile) << 1 | seeded.
+  int32_t* tile_list = nullptr;
+  float* tile_c = nullptr;
+  int32_t* tile_count = nullptr;
 };
 
 // SUPER = true: a work item is a run of GS consecutive chunks of one simplex (1024 samples: with the bisection order
@@ -114,7 +119,7 @@ struct DeferList {
 // per-chunk cost of tree walks and classification, half of a chunk's instructions, is shared by four chunks.  Runs
 // whose neighbourhood does not fit the stage, and chunks that keep open samples (they would need a larger cell
 // size, i.e. a new stage), are appended to a deferred list that a SUPER = false launch works off chunk by chunk.
-template <int DIM, bool SUPER>
+template <int DIM, bool SUPER, int SPLV>
 __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
    
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
@@ -123,6 +128,10 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl) {
   constexpr int DP = padded_dim(DIM);
+  constexpr int SPL = SPLV;          // samples per lane
+  constexpr int CHUNK = 64 * SPL;    // samples per wave item (SPLV = 1: the tile launch)
+  constexpr bool TILES = SPLV == 1;
+  static_assert(!(SUPER && TILES), "runs of four are made of chunks");
   constexpr int GS = SUPER ? 4 : 1;  // chunks per work item
   constexpr int G = CellCfg<DIM>::G;
   constexpr int NC = CellCfg<DIM>::NC;
@@ -157,10 +166,13 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
   const int supers = (chunks + GS - 1) / GS;
   // (split[2] == 0: the split kernel found the cloud too dense for runs of four - the SUPER launch has no items and
   // this one takes every chunk of every simplex in plain order, no lists)
-  const bool use_lists = !SUPER && dl.list && (!dl.split || dl.split[2] != 0);
-  const int64_t n_heavy_items = (use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
-  const int64_t n_items = SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
-                                : (use_lists ? n_heavy_items + (int64_t)dl.count[0] : n_simplices * chunks);
+  const bool use_lists = TILES || (!SUPER && dl.list && (!dl.split || dl.split[2] != 0));
+  const int64_t n_heavy_items = (!TILES && use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
+  const int32_t* item_list = TILES ? dl.tile_list : dl.list;
+  const float* item_c = TILES ? dl.tile_c : dl.c;
+  const int64_t n_items = TILES ? (int64_t)dl.tile_count[0]
+                          : SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
+                                  : (use_lists ? n_heavy_items + (int64_t)dl.count[0] : n_simplices * chunks);
   if (n_items == 0) return;  // (nothing for this launch: no need for 3072 waves to pop an empty queue)
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
 #ifdef FLOODER_PHASE_TIMERS
@@ -198,9 +210,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       q = (int)(g - s * chunks);
       s = dl.heavy[s];
     } else if (use_lists) {
-      const int e = dl.list[g - n_heavy_items];
+      const int e = item_list[g - n_heavy_items];
       seeded = (e & 1) != 0;
-      c_seed = dl.c[g - n_heavy_items];
+      c_seed = item_c[g - n_heavy_items];
       s = (int64_t)(e >> 1) / chunks;
       q = (int)((e >> 1) - s * chunks);
     } else {
@@ -641,6 +653,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       if (any) defer(q, 1, 2.f * c_now);
     };
     bool sc_done = false;
+    bool to_tiles = false;  // per-chunk launch: the chunk was handed to the tile launch
     // SUPER: the stage is built once for the whole run of chunks; anything that does not work out is deferred
     auto defer_all_fresh = [&]() {
       for (int sub = 0; sub < n_sub; ++sub) defer(q_first + sub, 0, 0.f);
@@ -760,6 +773,28 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       // of points); when they form a distant shell around an empty chunk the tree sweep's culling is cheaper.
       if constexpr (SUPER) {
         if (n_keep > CAPW) break;  // the neighbourhood of the whole run does not fit the stage: chunk by chunk
+      }
+      if constexpr (!SUPER && !TILES) {
+        if (n_keep > CAPW && dl.tile_list) {
+          // dense chunk: its open tiles of 64 samples go to the tile launch (a quarter of the region each: most fit the
+          // stage there) instead of an exhaustive evaluation of every kept point against all 256 samples.  A chunk
+          // that already holds minima (seeded, or a second attempt) parks them first, as a run of four does.
+          const bool fresh = attempt == 0 && !seeded;
+          if (!fresh) finalize(true);
+#pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            if (q * CHUNK + i * 64 < n_live && __ballot(open[i]) != 0ull) {  // (wave-uniform)
+              if (lane == 0) {
+                const int pos = atomicAdd(dl.tile_count, 1);
+                dl.tile_list[pos] = (int)(((s * tiles64 + q * SPL + i) << 1) | (fresh ? 0 : 1));
+                dl.tile_c[pos] = fresh ? 0.f : c;
+              }
+            }
+          }
+          to_tiles = true;
+          ++g_brute;
+          break;
+        }
       }
       if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) { give_up = true; ++g_cap; break; }
       if (n_keep <= brute_max) {
@@ -1079,6 +1114,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       PHASE(10);
       continue;
     }
+    if (to_tiles) continue;
     finalize(false);
     PHASE(10);
 #ifdef FLOODER_PHASE_TIMERS
@@ -1129,31 +1165,38 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 FaceAcc acc, DeferList dl, int32_t* queue2, hipStream_t st) {
+                 FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
+      constexpr int CHUNK = 64 * SPL_CHUNK;
       const int64_t n_chunks = ns * ((R + CHUNK - 1) / CHUNK);
       int64_t want = n_chunks / 48;
       want = want < 384 ? 384 : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       const int brute_max = g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP;
       // (a short queue - a rank's share of a multi-GPU run - is balanced better chunk by chunk than in runs of four)
-      if (dl.list && n_chunks < (int64_t)g_cell_super_min_chunks) dl = DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      if (dl.list && n_chunks < (int64_t)g_cell_super_min_chunks) {
+        DeferList d2{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        d2.tile_list = dl.tile_list; d2.tile_c = dl.tile_c; d2.tile_count = dl.tile_count;
+        dl = d2;
+      }
+      if (!g_cell_tiles) { dl.tile_list = nullptr; dl.tile_c = nullptr; dl.tile_count = nullptr; }
+#define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
+  hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, \
+                     k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \
+                     g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl)
       if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
-        hipLaunchKernelGGL((cell_sweep_kernel<DIM, true>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
-                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list, flag_count, stats, acc, dl);
-        hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
-                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue2, out, flag_list, flag_count, stats, acc, dl);
+        FLOODER_CELL_LAUNCH(true, SPL_CHUNK, queue);
+        FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue2);
       } else {
-        hipLaunchKernelGGL((cell_sweep_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
-                           k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries,
-                           g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list, flag_count, stats, acc, dl);
+        FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue);
       }
+      // ... and the tiles of the chunks whose neighbourhood overflowed the stage, one sample per lane
+      if (dl.tile_list) FLOODER_CELL_LAUNCH(false, 1, queue3);
+#undef FLOODER_CELL_LAUNCH
       return check_launch("cell_sweep");
     } else {
       return fail(FLOODER_E_ARG, "flooder_sweep_cell_f32: only dim 2 and 3");
@@ -1214,7 +1257,7 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
-                     DeferList dl, int32_t* queue2, void* stream, const char* who) {
+                     DeferList dl, int32_t* queue2, int32_t* queue3, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
       n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
@@ -1229,7 +1272,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), acc,
-                              dl, queue2, (hipStream_t)stream);
+                              dl, queue2, queue3, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -1242,7 +1285,7 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
                            uint64_t* stats, void* stream) {
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           flag_list, flag_count, stats, FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
-                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, stream,
+                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr, stream,
                           "flooder_sweep_cell_f32: bad argument");
 }
 
@@ -1265,13 +1308,19 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                        (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
                        defer_ctl + 2);
   }
+  DeferList dl{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
+               light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0};
+  if (defer_list) {  // the tile list lives behind the chunk list (the caller sizes both buffers for 5 x S x chunks)
+    const int64_t n_chunk_slots = n_simplices * (int64_t)((R + 255) / 256);
+    dl.tile_list = defer_list + n_chunk_slots;
+    dl.tile_c = defer_c + n_chunk_slots;
+    dl.tile_count = defer_ctl + 6;
+  }
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot, flag_key, flag_hist},
-                          DeferList{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
-                                    light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0},
-                          defer_list ? defer_ctl + 1 : nullptr,
+                          dl, defer_list ? defer_ctl + 1 : nullptr, defer_list ? defer_ctl + 7 : nullptr,
                           stream, "flooder_sweep_cell_faces_f32: bad argument");
 }
 

@@ -262,10 +262,13 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * top / top_list / top_count (all NULL, or n_simplices zeroed uint64 / n_simplices int32 / one zeroed int32): the
  * probe of the finish folded into the sweep - every flagged tile gets one greedy tree descent for its open samples
  * (finite upper bounds) while they are still in registers, and top[s] = (largest such bound << 32 | tile id).
- * defer_list / defer_c / defer_ctl (all NULL, or n_simplices * ceil(R / 256) int32 / as many float32 / eight zeroed
- * int32): two launches instead of one - first every run of four consecutive chunks (1024 samples) is gathered,
- * filtered and staged ONCE and its chunks are queried against that stage; runs that do not fit the stage and chunks
- * that keep open samples are appended to defer_list and worked off chunk by chunk by the second launch.
+ * defer_list / defer_c / defer_ctl (all NULL, or 5 * n_simplices * ceil(R / 256) int32 / as many float32 / eight
+ * zeroed int32): three launches instead of one - first every run of four consecutive chunks (1024 samples) is
+ * gathered, filtered and staged ONCE and its chunks are queried against that stage; runs that do not fit the stage and
+ * chunks that keep open samples are appended to defer_list and worked off chunk by chunk by the second launch; a chunk
+ * whose kept points overflow the stage there (a dense or a surface cloud) hands its open tiles of 64 samples on to
+ * the third launch (entries behind the first n_simplices * ceil(R / 256) of both buffers), one sample per lane and
+ * a region a quarter the size, instead of evaluating every kept point against all 256 samples (option "cell_tiles").
  * simplex_weight (NULL or n_simplices floats of flooder_simplex_weight_f32) with light_list / heavy_list
  * (n_simplices int32 scratch each): simplices heavier than option "cell_super_weight" (3000) skip the first launch -
  * in a dense region no run of four chunks fits the stage - and are worked off chunk by chunk by the second.  When
