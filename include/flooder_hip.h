@@ -268,7 +268,9 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * chunks that keep open samples are appended to defer_list and worked off chunk by chunk by the second launch; a chunk
  * whose kept points overflow the stage there (a dense or a surface cloud) hands its open tiles of 64 samples on to
  * the third launch (entries behind the first n_simplices * ceil(R / 256) of both buffers), one sample per lane and
- * a region a quarter the size, instead of evaluating every kept point against all 256 samples (option "cell_tiles").
+ * a region a quarter the size, instead of evaluating every kept point against all 256 samples - only with option
+ * "cell_tiles" 1; off by default: four re-centred gathers and classifications cost more than the exhaustive loop they
+ * replace (cfg 3 sweep 3.95 vs 2.55 ms).
  * simplex_weight (NULL or n_simplices floats of flooder_simplex_weight_f32) with light_list / heavy_list
  * (n_simplices int32 scratch each): simplices heavier than option "cell_super_weight" (3000) skip the first launch -
  * in a dense region no run of four chunks fits the stage - and are worked off chunk by chunk by the second.  When

@@ -167,3 +167,50 @@ def test_bucketed_fps_16m_equals_brute_force(cheese16m):
     pts, tp, idx = cheese16m            # (the fixture's selection runs the default = bucketed path)
     brute = core.fps_indices(tp, 600, 0, method="brute").cpu().numpy()
     assert np.array_equal(idx.cpu().numpy()[:600], brute)
+
+
+@pytest.mark.parametrize("case", ["lattice_ties", "two_clusters", "dim5", "dim8", "all_points", "dups_of_start"])
+def test_batched_fps_hard_cases_equal_brute_force(dev, case, monkeypatch):
+    """flooder_fps_batched_f32 selects several landmarks per launch when the runners-up of the arg-max provably stay
+    the next landmarks (csrc/flood_fps2.hip).  Inputs built to break a wrong rule: a regular lattice (thousands of
+    exactly equal running minima: only the index decides), two tight clusters (the runners-up are neighbours of the
+    winner: the batch must stop), dimensions 5 and 8, as many landmarks as points (the minima reach zero), copies of
+    the start point.  Against the brute-force kernel (one full sweep per landmark) and, for the first picks, numpy."""
+    rng = np.random.default_rng(9)
+    if case == "lattice_ties":
+        g = np.arange(48, dtype=np.float32)
+        P = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+        P = P[rng.permutation(len(P))]
+        k, start = 700, 5
+    elif case == "two_clusters":
+        P = np.concatenate([rng.normal(0, 1e-3, (150_000, 3)), rng.normal(0, 1e-3, (150_000, 3)) + 1.0]).astype(np.float32)
+        k, start = 300, 0
+    elif case == "dim5":
+        P, k, start = rng.normal(size=(250_000, 5)).astype(np.float32), 500, 17
+    elif case == "dim8":
+        P, k, start = rng.random((220_000, 8)).astype(np.float32), 400, 0
+    elif case == "all_points":
+        P, k, start = rng.normal(size=(3000, 3)).astype(np.float32), 3000, 1
+    else:
+        base = rng.normal(size=(210_000, 3)).astype(np.float32)
+        base[1000:1400] = base[7]
+        P, k, start = base, 450, 7
+    tp = torch.as_tensor(P, device=dev)
+    monkeypatch.setattr(core, "FPS_BUCKET_MIN_POINTS", 0)
+    a = core.fps_indices(tp, k, start, method="brute").cpu().numpy()
+    monkeypatch.setattr(core, "FPS_BATCHED", True)
+    b = core.fps_indices(tp, k, start, method="bucket").cpu().numpy()
+    assert np.array_equal(a, b), int(np.argmax(a != b))
+    assert core.LAST_FPS_LAUNCHES < k or case in ("two_clusters", "all_points")
+    assert np.array_equal(a[:40], fo.exact_fps(P, 40, start))
+    lib = _native.load()
+    for sw in (2, 7):   # switch to the batched steps almost at once
+        try:
+            assert lib.flooder_set_option(b"fps_switch", sw) == 0
+            c = core.fps_indices(tp, min(k, 250), start, method="bucket").cpu().numpy()
+        finally:
+            lib.flooder_set_option(b"fps_switch", 0)
+        assert np.array_equal(a[:len(c)], c), sw
+    if P.shape[1] <= 3:  # the one-landmark-per-launch kernels stay selectable
+        monkeypatch.setattr(core, "FPS_BATCHED", False)
+        assert np.array_equal(a, core.fps_indices(tp, k, start, method="bucket").cpu().numpy())

@@ -184,6 +184,24 @@ def test_index_from_host_streams_the_cloud_and_index_kwarg_reuses_it(dev):
     assert got == fa.flood_complex(tp, 20, max_dimension=1, points_per_edge=4)
 
 
+def test_dense_chunk_tile_launch_changes_nothing(dev):
+    """Option "cell_tiles": chunks whose kept points overflow the LDS stage hand their tiles of 64 samples to a third
+    launch (one sample per lane) instead of the exhaustive loop.  Off by default (slower); bit-identical when on: a
+    surface cloud (most chunks near the sheet overflow) and a dense Gaussian core."""
+    lib = _native.load()
+    for pts, n_l, ppe in ((fo.noisy_torus(400_000, seed=3), 150, 30),
+                          (np.random.default_rng(4).normal(size=(500_000, 3)).astype(np.float32) * 0.05, 40, 30)):
+        lms = pts[fo.exact_fps(pts, n_l, 0)]
+        tp, tl = torch.as_tensor(pts, device=dev), torch.as_tensor(lms, device=dev)
+        off = fa.flood_complex(tp, tl, points_per_edge=ppe)
+        try:
+            assert lib.flooder_set_option(b"cell_tiles", 1) == 0
+            on = fa.flood_complex(tp, tl, points_per_edge=ppe)
+        finally:
+            lib.flooder_set_option(b"cell_tiles", 0)
+        assert on == off
+
+
 def test_landmarks_outside_cloud_match_cpu_path(dev):
     """Landmarks that are NOT points of the cloud: the culled sweep still returns the exact value of
     the reference CPU path (the reference's own GPU path is only a bound there)."""

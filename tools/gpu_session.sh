@@ -17,6 +17,18 @@ for s in $STEPS; do
     bench4) timeout 1500 python bench.py --workload cfg4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; cut -c1-1500 $OUT/bench_cfg4.json; tail -3 $OUT/bench_cfg4.err ;;
     bench5) timeout 1500 python bench.py --workload cfg5 --cpu-sample 300 --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ;;
     bench2) timeout 600 python bench.py --gpus 2 --no-cpu-baseline > $OUT/bench_cfg2_2ranks.json 2> $OUT/bench_cfg2_2ranks.err; cut -c1-400 $OUT/bench_cfg2_2ranks.json; tail -3 $OUT/bench_cfg2_2ranks.err ;;
+    ranks2:*) # ranks2:<workload>:<shard mode>  two ranks on the ONE GPU (gloo): functional check of bench.py --gpus N
+            IFS=: read -r _ wl sh <<< "$s"
+            timeout 900 python bench.py --gpus 2 --workload $wl --shard $sh --no-cpu-baseline --steps 5 --warmup 1 > $OUT/ranks2_${wl}_${sh}.json 2> $OUT/ranks2_${wl}_${sh}.err
+            python - $OUT/ranks2_${wl}_${sh}.json "$wl $sh" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print("2 ranks / 1 GPU", sys.argv[2], d["config"]["parallelism"], "ms/step", d["ms_per_step"], {k: v["ms_per_step"] for k, v in d["kernels"].items()})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-800:])
+PY
+            ;;
     prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
             python tools/summarize_profiles.py ${s#prof:} r3_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
             mkdir -p $OUT/profiles && cp profiles/r3_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
