@@ -76,9 +76,11 @@ SIGNATURES = {
     "flooder_fps_bucket_count": (c_int64, [c_int64]),
     "flooder_fps_indexed_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "flooder_fps_batched_slot_words": (c_int64, [c_int]),
+    "flooder_fps_batched_max_points": (c_int64, []),
+    "flooder_fps_batched_rec_words": (c_int64, [c_int64, c_int, c_int]),
     "flooder_fps_batched_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
 }

@@ -162,6 +162,10 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
         if method == "bucket" and dim > FPS_BUCKET_MAX_DIM:
             raise ValueError(f"bucketed FPS supports ambient dimension <= {FPS_BUCKET_MAX_DIM}")
         out_idx = torch.empty(n_lms, dtype=torch.int64, device=pts.device)
+        if method == "bucket" and (FPS_BATCHED or dim > 3) and n > int(lib.flooder_fps_batched_max_points()):
+            method = "bucket" if dim <= 3 else "brute"     # (one landmark per launch / brute force beyond 16 M points)
+            if dim <= 3:
+                return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx)
         if method == "bucket" and (FPS_BATCHED or dim > 3):
             global LAST_FPS_LAUNCHES
             import ctypes
@@ -171,34 +175,23 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
             minsq = torch.empty(n, dtype=torch.float32, device=pts.device)
             box = torch.empty(2 * dp * nb, dtype=torch.float32, device=pts.device)
             keys = torch.empty(2 * nb, dtype=torch.int64, device=pts.device)
-            n_slot = int(lib.flooder_fps_batched_slot_words(n_lms))
-            zeroed = torch.zeros(64 * n_lms + n_slot + (n_lms + 4 + 1) // 2, dtype=torch.int64, device=pts.device)
-            work_best, work_slots = zeroed[:64 * n_lms], zeroed[64 * n_lms:64 * n_lms + n_slot]
-            work_ctr = zeroed[64 * n_lms + n_slot:].view(torch.int32)
+            bcoord = torch.empty(dp * nb, dtype=torch.float32, device=pts.device)
+            rec = torch.empty(int(lib.flooder_fps_batched_rec_words(n, dim, n_lms)), dtype=torch.int32, device=pts.device)
+            zeroed = torch.zeros(64 * n_lms + (n_lms + 4 + 1) // 2, dtype=torch.int64, device=pts.device)
+            work_best = zeroed[:64 * n_lms]
+            work_ctr = zeroed[64 * n_lms:].view(torch.int32)
             launches = ctypes.c_int32(0)
             with torch.cuda.device(pts.device):
                 st = _native.current_stream_ptr(pts.device)
                 _native.check(lib.flooder_fps_batched_f32(
                     _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
                     int(start_idx), _native.ptr(out_idx), _native.ptr(minsq), _native.ptr(box), _native.ptr(keys),
-                    _native.ptr(work_best), _native.ptr(work_slots), _native.ptr(work_ctr),
+                    _native.ptr(bcoord), _native.ptr(work_best), _native.ptr(rec), _native.ptr(work_ctr),
                     ctypes.addressof(launches), st), "flooder_fps_batched_f32")
             LAST_FPS_LAUNCHES = int(launches.value)
             return out_idx
         if method == "bucket":
-            index = index if index is not None else PointIndex(pts)
-            nb = int(lib.flooder_fps_bucket_count(n))
-            rows = torch.empty(4 * index.pts.shape[0], dtype=torch.float32, device=pts.device)
-            box = torch.empty(8 * nb, dtype=torch.float32, device=pts.device)
-            key = torch.empty(nb, dtype=torch.int64, device=pts.device)
-            work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
-            with torch.cuda.device(pts.device):
-                st = _native.current_stream_ptr(pts.device)
-                _native.check(lib.flooder_fps_indexed_f32(
-                    _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
-                    int(start_idx), _native.ptr(out_idx), _native.ptr(rows), _native.ptr(box), _native.ptr(key),
-                    _native.ptr(work_best), st), "flooder_fps_indexed_f32")
-            return out_idx
+            return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx)
         work_min = torch.empty(4 * n, dtype=torch.float32, device=pts.device)
         work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
         with torch.cuda.device(pts.device):
@@ -217,6 +210,23 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
         idx[i] = j
         np.minimum(d2, ((pts - pts[j]) ** 2).sum(axis=1, dtype=np.float32), out=d2)
     return torch.as_tensor(idx, device=points.device)
+
+
+def _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx):
+    """``flooder_fps_indexed_f32``: bucketed exact FPS, one launch per landmark (dim <= 3)."""
+    index = index if index is not None else PointIndex(pts)
+    nb = int(lib.flooder_fps_bucket_count(n))
+    rows = torch.empty(4 * index.pts.shape[0], dtype=torch.float32, device=pts.device)
+    box = torch.empty(8 * nb, dtype=torch.float32, device=pts.device)
+    key = torch.empty(nb, dtype=torch.int64, device=pts.device)
+    work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
+    with torch.cuda.device(pts.device):
+        st = _native.current_stream_ptr(pts.device)
+        _native.check(lib.flooder_fps_indexed_f32(
+            _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
+            int(start_idx), _native.ptr(out_idx), _native.ptr(rows), _native.ptr(box), _native.ptr(key),
+            _native.ptr(work_best), st), "flooder_fps_indexed_f32")
+    return out_idx
 
 
 # ------------------------------------------------------------------------------ complex

@@ -17,16 +17,19 @@
 // is the sequential selection, index for index (test_bucketed_fps_equals_brute_force); 1000 landmarks of a million
 // Gaussian points take ~240 launches instead of 1000.
 //
-// What the ranking needs - without sorting anything: every bucket keeps its best point key AND its second best
-// (k1, k2: (minimum bits << 32 | ~original index), unique per point); every wave owns 64 buckets and pushes
-// w1 = its best point and w2 = the best of everything else it owns (an upper bound of all its other points) into slot
-// (wave mod 256) of the NEXT launch's slot table, which keeps the top two of what it receives (two integer atomics:
-// a = max, b = max of the losers).  Then every slot's `a` is a true point, every other point of the cloud is <= B =
-// max over slots of b, and the points above B, in descending order, ARE the head of the ranking.
-// Slot tables and the landmark counter are indexed by launch number (zeroed by the caller), so no launch ever
-// clears or re-reads what a concurrent block still uses.  The host cannot know the number of launches: it enqueues
-// them in rounds and reads the counter (4 bytes) between rounds - the one entry point of this library that
-// synchronises its stream; surplus launches of a round see "done" and return at once.
+// What the ranking needs - without sorting anything: every bucket keeps its best point key, its second best (k1, k2:
+// (minimum bits << 32 | ~original index), unique per point) and the coordinates of its best point; every workgroup
+// (4 waves x 64 buckets) ends a launch by writing ONE record for the next launch - plain stores, no atomics: its best
+// point b1 with coordinates, the second-best point and the box of THAT point's bucket, and bo = the best of all its
+// other points (an upper bound).  Every wave of the next launch reads all records (<= 256) with its first loads: the
+// block winners above B = max bo, in descending order, are the head of the ranking, EXCEPT for the points hidden in a
+// winner's own bucket (in a dense cloud the runner-up of the arg-max is its neighbour).  Those are settled at
+// acceptance: once y_c is a landmark every point of its bucket is at most the farthest corner of the bucket's box away
+// from it, so candidate y_i is accepted only if its minimum also exceeds min(m(k2_c), farthest-corner d2) of every
+// accepted y_c.  Records and the landmark counter are indexed by launch number, so no launch re-reads what a
+// concurrent block still writes.  The host cannot know the number of launches: it enqueues them in rounds and reads
+// the counter (4 bytes) between rounds - the one entry point of this library that synchronises its stream; surplus
+// launches of a round see "done" and return at once.
 //
 // Rows: coordinates come from the curve-sorted padded rows of the PointIndex (the cloud is not copied again), the
 // running minima live in their own array.  Arithmetic per point as the brute-force kernels (direct differences, one
@@ -39,7 +42,6 @@ using namespace flooder;
 namespace {
 
 constexpr int BSLOTS = 64;    // arg-max slots per iteration of the brute-force phase
-constexpr int SLOTS2 = 256;   // (a, b) slot pairs per launch of the batched phase
 constexpr int KMAX = 8;       // landmarks per launch at most
 
 typedef unsigned long long u64;
@@ -127,19 +129,20 @@ __global__ __launch_bounds__(256) void fps2_sorted_step_kernel(const float* __re
   }
 }
 
-// ---- bucket b = RPL * 64 consecutive rows: box, best and second-best point key (one wave per bucket)
+// ---- bucket b = RPL * 64 consecutive rows: box, best and second-best point key, coordinates of the best point
 template <int DIM, int RPL>
 __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __restrict__ pts_sorted,
                                                                const float* __restrict__ minsq, int64_t n,
                                                                const int32_t* __restrict__ order, int64_t n_buckets,
-                                                               float* __restrict__ box, u64* __restrict__ keys) {
+                                                               float* __restrict__ box, u64* __restrict__ keys,
+                                                               float* __restrict__ bcoord) {
   constexpr int DP = padded_dim(DIM);
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= n_buckets) return;
-  float lo[DIM], hi[DIM];
+  float lo[DIM], hi[DIM], bx[DIM];
 #pragma unroll
-  for (int k = 0; k < DIM; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); }
+  for (int k = 0; k < DIM; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); bx[k] = 0.f; }
   u64 b1 = 0ull, b2 = 0ull;
 #pragma unroll
   for (int u = 0; u < RPL; ++u) {
@@ -153,37 +156,67 @@ __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __re
         hi[k] = __builtin_fmaxf(hi[k], x[k]);
       }
       const u64 k = make_key(minsq[j], (uint32_t)order[j]);
-      if (k > b1) { b2 = b1; b1 = k; } else if (k > b2) { b2 = k; }
+      if (k > b1) {
+        b2 = b1;
+        b1 = k;
+#pragma unroll
+        for (int kk = 0; kk < DIM; ++kk) bx[kk] = x[kk];
+      } else if (k > b2) {
+        b2 = k;
+      }
     }
   }
   const u64 k1 = wave_max_key(b1);
   const u64 k2 = wave_max_key(b1 == k1 ? b2 : b1);
+  const int bl = __builtin_ctzll(__ballot(b1 == k1));
 #pragma unroll
   for (int k = 0; k < DIM; ++k) {
     lo[k] = wave_min_f32(lo[k]);
     hi[k] = wave_max_f32(hi[k]);
+    bx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
   }
   if (lane == 0) {
     float* bb = box + b * 2 * DP;
+    float* bc = bcoord + b * DP;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) { bb[k] = k < DIM ? lo[k < DIM ? k : 0] : 0.f; bb[DP + k] = k < DIM ? hi[k < DIM ? k : 0] : 0.f; }
+    for (int k = 0; k < DP; ++k) {
+      bb[k] = k < DIM ? lo[k < DIM ? k : 0] : 0.f;
+      bb[DP + k] = k < DIM ? hi[k < DIM ? k : 0] : 0.f;
+      bc[k] = k < DIM ? bx[k < DIM ? k : 0] : 0.f;
+    }
     keys[2 * b] = k1;
     keys[2 * b + 1] = k2;
   }
 }
 
-// ---- one batched step (launch number L >= 1; L == 0 with init_only: only the slot pushes)
+// Block record of a launch (plain stores by the block that owns it, read by every wave of the next launch):
+//   b1 best point of the block's buckets | k2 second-best point of THAT point's bucket | bo best of every other point of
+//   the block (an upper bound) | coordinates of the b1 point | box of its bucket.  32-bit words:
+template <int DP>
+struct Rec {
+  static constexpr int B1 = 0, K2 = 2, BO = 4, C = 6, LO = 6 + DP, HI = 6 + 2 * DP, WORDS = 6 + 3 * DP;
+};
+constexpr int NREC = 4;  // records per lane: at most 256 blocks
+
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((u64)hi << 32) | (u64)lo;
+}
+
+// ---- one batched step (launch number L >= 1; L == 0 with init_only: only the block records)
 // lane l of wave w owns bucket l * n_waves + w (a landmark's neighbourhood spreads over the whole chip)
 template <int DIM, int RPL>
 __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     const float* __restrict__ pts_sorted, float* __restrict__ minsq, int64_t n, const int32_t* __restrict__ order,
-    const float* __restrict__ pts, int ld, int64_t n_buckets, const float* __restrict__ box,
-    u64* __restrict__ keys, int L, int n_lms, int32_t* __restrict__ ctr, u64* __restrict__ slots,
-    int64_t* __restrict__ out_idx, int init_only) {
+    int64_t n_buckets, const float* __restrict__ box, u64* __restrict__ keys, float* __restrict__ bcoord, int L,
+    int n_lms, int32_t* __restrict__ ctr, uint32_t* __restrict__ rec, int64_t* __restrict__ out_idx, int init_only) {
   constexpr int DP = padded_dim(DIM);
+  typedef Rec<DP> RC;
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * 4;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
   const int64_t b = (int64_t)lane * n_waves + w;
   const bool has = b < n_buckets;
   const int it = ctr[L];  // landmarks applied so far (written by launch L - 1; the same for every block)
@@ -191,78 +224,114 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     if (blockIdx.x == 0 && threadIdx.x == 0) ctr[L + 1] = it;
     return;
   }
-  float blo[DIM], bhi[DIM];
+  float blo[DIM], bhi[DIM], bc[DIM];
   u64 k1 = 0ull, k2 = 0ull;
 #pragma unroll
-  for (int k = 0; k < DIM; ++k) { blo[k] = 0.f; bhi[k] = 0.f; }
+  for (int k = 0; k < DIM; ++k) { blo[k] = 0.f; bhi[k] = 0.f; bc[k] = 0.f; }
   if (has) {
-    float r0[DP], r1[DP];
+    float r0[DP], r1[DP], r2[DP];
     load_row<DP>(box + b * 2 * DP, r0);
     load_row<DP>(box + b * 2 * DP + DP, r1);
+    load_row<DP>(bcoord + b * DP, r2);
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) { blo[k] = r0[k]; bhi[k] = r1[k]; }
+    for (int k = 0; k < DIM; ++k) { blo[k] = r0[k]; bhi[k] = r1[k]; bc[k] = r2[k]; }
     k1 = keys[2 * b];
     k2 = keys[2 * b + 1];
   }
   if (!init_only) {
-    // ---- head of the ranking: slot winners above B = the best of everything that is not a slot winner
-    const u64* sl = slots + (int64_t)L * (SLOTS2 * 2);
-    u64 a[SLOTS2 / 64], bb = 0ull;
+    // ---- head of the ranking: block winners above B = the best of every point that is neither a block winner nor
+    // hidden behind one (the second-best point of a winner's own bucket is accounted for at acceptance)
+    const uint32_t* rc = rec + (int64_t)L * gridDim.x * RC::WORDS;
+    u64 a[NREC], ak2[NREC];
+    float ac[NREC][DIM], alo[NREC][DIM], ahi[NREC][DIM];
+    u64 bo = 0ull;
 #pragma unroll
-    for (int t = 0; t < SLOTS2 / 64; ++t) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl + 2 * (lane + 64 * t));
-      a[t] = v.x;
-      bb = v.y > bb ? v.y : bb;
-    }
-    const u64 B = wave_max_key(bb);
-    u64 ck[KMAX];
-    int nc = 0;
+    for (int t = 0; t < NREC; ++t) {
+      const int idx = lane + 64 * t;
+      a[t] = 0ull;
+      ak2[t] = 0ull;
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      ck[i] = 0ull;
-      if (nc == i) {  // (wave-uniform)
-        u64 m = 0ull;
+      for (int k = 0; k < DIM; ++k) { ac[t][k] = 0.f; alo[t][k] = 0.f; ahi[t][k] = 0.f; }
+      if (idx < (int)gridDim.x) {
+        const uint32_t* r = rc + (int64_t)idx * RC::WORDS;
+        a[t] = *reinterpret_cast<const u64*>(r + RC::B1);
+        ak2[t] = *reinterpret_cast<const u64*>(r + RC::K2);
+        const u64 o = *reinterpret_cast<const u64*>(r + RC::BO);
+        bo = o > bo ? o : bo;
 #pragma unroll
-        for (int t = 0; t < SLOTS2 / 64; ++t) m = (a[t] > B && a[t] > m) ? a[t] : m;
-        const u64 wk = wave_max_key(m);
-        if (wk != 0ull) {
-          ck[i] = wk;
-          ++nc;
-#pragma unroll
-          for (int t = 0; t < SLOTS2 / 64; ++t) a[t] = a[t] == wk ? 0ull : a[t];
+        for (int k = 0; k < DIM; ++k) {
+          ac[t][k] = __uint_as_float(r[RC::C + k]);
+          alo[t][k] = __uint_as_float(r[RC::LO + k]);
+          ahi[t][k] = __uint_as_float(r[RC::HI + k]);
         }
       }
     }
-    // coordinates of the candidates: lane i fetches candidate i, then broadcasts
-    u64 myk = 0ull;
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) myk = lane == i ? ck[i] : myk;
-    float myc[DIM];
-#pragma unroll
-    for (int k = 0; k < DIM; ++k) myc[k] = 0.f;
-    if (lane < nc) {
-      const uint32_t q = 0xffffffffu - (uint32_t)myk;
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) myc[k] = pts[(int64_t)q * ld + k];
-    }
-    float cc[KMAX][DIM];
+    const u64 B = wave_max_key(bo);
+    u64 ck[KMAX];
+    float cc[KMAX][DIM];   // coordinates of the candidates
+    float chb[KMAX];       // bound of the hidden points of a candidate's bucket once the candidate is a landmark
+    int nc = 0;
+    u64 prev = ~0ull;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
+      ck[i] = 0ull;
+      chb[i] = 0.f;
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) cc[i][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myc[k]), i));
+      for (int k = 0; k < DIM; ++k) cc[i][k] = 0.f;
+      if (nc == i) {  // (wave-uniform)
+        u64 m = 0ull;
+        int tsel = 0;
+#pragma unroll
+        for (int t = 0; t < NREC; ++t)
+          if (a[t] > B && a[t] < prev && a[t] > m) { m = a[t]; tsel = t; }
+        const u64 wk = wave_max_key(m);
+        if (wk != 0ull) {
+          ck[i] = wk;
+          prev = wk;
+          ++nc;
+          // the lane that holds this record broadcasts its coordinates and the hidden-point bound of its bucket:
+          // min(second-best minimum of the bucket, farthest corner of the bucket's box from the candidate) - every
+          // point of the bucket is at most that far from the new landmark (same fma chain on |corner gap| >= |difference|)
+          float mc[DIM], hb = 0.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) mc[k] = 0.f;
+#pragma unroll
+          for (int t = 0; t < NREC; ++t) {
+            if (t == tsel) {
+              float far = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                mc[k] = ac[t][k];
+                const float g = __builtin_fmaxf(ac[t][k] - alo[t][k], ahi[t][k] - ac[t][k]);
+                far = __builtin_fmaf(g, g, far);
+              }
+              const float m2 = __uint_as_float((uint32_t)(ak2[t] >> 32));
+              hb = far < m2 ? far : m2;
+            }
+          }
+          const int src = __builtin_ctzll(__ballot(m == wk));
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) cc[i][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc[k]), src));
+          chb[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb), src));
+        }
+      }
     }
     // ---- the prefix that is provably the sequential selection
     int nb = nc > 0 ? 1 : 0;
+    float hbound = chb[0];  // largest hidden-point bound over the accepted candidates
 #pragma unroll
     for (int i = 1; i < KMAX; ++i) {
       if (nb == i && i < nc) {  // (wave-uniform: every candidate before i was accepted)
         const float mi = __uint_as_float((uint32_t)(ck[i] >> 32));
-        bool ok = mi > 0.f;
+        bool ok = mi > 0.f && mi > hbound;
 #pragma unroll
         for (int l = 0; l < KMAX; ++l) {
           if (l < i) ok = ok && !(dist2<DIM>(cc[i], cc[l]) < mi);
         }
-        if (ok) nb = i + 1;
+        if (ok) {
+          nb = i + 1;
+          hbound = __builtin_fmaxf(hbound, chb[i]);
+        }
       }
     }
     if (nb > n_lms - it) nb = n_lms - it;
@@ -293,8 +362,10 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
       tm &= tm - 1ull;
       const int64_t tb = (int64_t)src * n_waves + w;
       u64 b1 = 0ull, b2 = 0ull;
-      float x[RPL][DIM], m0[RPL];
+      float x[RPL][DIM], m0[RPL], bx[DIM];
       uint32_t o[RPL];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) bx[k] = 0.f;
 #pragma unroll
       for (int u = 0; u < RPL; ++u) {
         const int64_t j = tb * (RPL * 64) + u * 64 + lane;
@@ -317,30 +388,72 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
           }
           if (m < m0[u]) minsq[j] = m;
           const u64 k = make_key(m, o[u]);
-          if (k > b1) { b2 = b1; b1 = k; } else if (k > b2) { b2 = k; }
+          if (k > b1) {
+            b2 = b1;
+            b1 = k;
+#pragma unroll
+            for (int kk = 0; kk < DIM; ++kk) bx[kk] = x[u][kk];
+          } else if (k > b2) {
+            b2 = k;
+          }
         }
       }
       const u64 nk1 = wave_max_key(b1);
       const u64 nk2 = wave_max_key(b1 == nk1 ? b2 : b1);
+      const int bl = __builtin_ctzll(__ballot(b1 == nk1));
+      float nbx[DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) nbx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
       if (lane == src) {
         k1 = nk1;
         k2 = nk2;
         keys[2 * tb] = nk1;
         keys[2 * tb + 1] = nk2;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          bc[k] = nbx[k];
+          bcoord[tb * DP + k] = nbx[k];
+        }
       }
     }
   } else if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctr[L + 1] = it;
   }
-  // ---- this wave's best point and the best of everything else it owns -> top-2 slot of the next launch
-  const u64 w1 = wave_max_key(k1);
-  const u64 w2 = wave_max_key(k1 == w1 ? k2 : k1);
-  if (lane == 0 && w1 != 0ull) {
-    u64* nx = slots + (int64_t)(L + 1) * (SLOTS2 * 2) + 2 * (w % SLOTS2);
-    const u64 old = atomicMax(&nx[0], w1);
-    const u64 loser = old < w1 ? old : w1;
-    const u64 v = loser > w2 ? loser : w2;
-    if (v != 0ull) atomicMax(&nx[1], v);
+  // ---- this block's record for the next launch
+  __shared__ u64 s_w1[4], s_k2[4], s_oth[4];
+  __shared__ float s_c[4][3 * DIM];
+  {
+    const u64 w1 = wave_max_key(k1);
+    const int wl = w1 != 0ull ? __builtin_ctzll(__ballot(k1 == w1 && has)) : 0;
+    const u64 oth = wave_max_key(lane == wl ? 0ull : k1);  // (the other buckets' second-best points are below their best)
+    const u64 ok2 = readlane_u64(k2, wl);
+    if (lane == 0) { s_w1[wv] = w1; s_k2[wv] = ok2; s_oth[wv] = oth; }
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc[k]), wl));
+      const float l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[k]), wl));
+      const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[k]), wl));
+      if (lane == 0) { s_c[wv][k] = c; s_c[wv][DIM + k] = l; s_c[wv][2 * DIM + k] = h; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int wb = 0;
+    for (int q = 1; q < 4; ++q) wb = s_w1[q] > s_w1[wb] ? q : wb;
+    u64 bo = 0ull;
+    for (int q = 0; q < 4; ++q) {
+      if (q != wb && s_w1[q] > bo) bo = s_w1[q];
+      if (s_oth[q] > bo) bo = s_oth[q];
+    }
+    uint32_t* r = rec + ((int64_t)(L + 1) * gridDim.x + blockIdx.x) * RC::WORDS;
+    *reinterpret_cast<u64*>(r + RC::B1) = s_w1[wb];
+    *reinterpret_cast<u64*>(r + RC::K2) = s_k2[wb];
+    *reinterpret_cast<u64*>(r + RC::BO) = bo;
+    for (int k = 0; k < DIM; ++k) {
+      r[RC::C + k] = __float_as_uint(s_c[wb][k]);
+      r[RC::LO + k] = __float_as_uint(s_c[wb][DIM + k]);
+      r[RC::HI + k] = __float_as_uint(s_c[wb][2 * DIM + k]);
+    }
   }
 }
 
@@ -355,13 +468,22 @@ __global__ void fps2_last_kernel(const u64* best, int n_lms, int64_t* out_idx) {
 
 __global__ void fps2_set_ctr_kernel(int32_t* ctr, int value) { ctr[0] = value; }
 
-template <int DIM, int RPL>
-int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, const int32_t* order, int n_lms,
-                int64_t start, int k0, int64_t* out_idx, float* minsq, float* box, u64* keys, u64* best, u64* slots,
-                int32_t* ctr, int32_t* launches_out, hipStream_t st) {
+template <int RPL>
+int64_t batched_blocks(int64_t n) {
   const int64_t n_buckets = (n + RPL * 64 - 1) / (RPL * 64);
   const int64_t n_waves = (n_buckets + 63) / 64;
-  const unsigned grid = (unsigned)((n_waves + 3) / 4);
+  return (n_waves + 3) / 4;
+}
+
+inline int batched_rpl(int64_t n) { return g_fps_rpl ? g_fps_rpl : (n >= (4 << 20) ? 4 : 1); }
+
+template <int DIM, int RPL>
+int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, const int32_t* order, int n_lms,
+                int64_t start, int k0, int64_t* out_idx, float* minsq, float* box, u64* keys, float* bcoord, u64* best,
+                uint32_t* rec, int32_t* ctr, int32_t* launches_out, hipStream_t st) {
+  const int64_t n_buckets = (n + RPL * 64 - 1) / (RPL * 64);
+  const unsigned grid = (unsigned)batched_blocks<RPL>(n);
+  if (grid > 64 * NREC) return fail(FLOODER_E_ARG, "flooder_fps_batched_f32: cloud too large (use flooder_fps_indexed_f32)");
   const int64_t brute_blocks = (n + 1023) / 1024;
   hipLaunchKernelGGL(fps2_start_kernel, dim3(1), dim3(1), 0, st, best, start);
   const int k_brute = k0 < n_lms ? k0 : n_lms;
@@ -376,10 +498,10 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
   }
   // landmarks 0 .. k_brute - 2 are applied; the batched phase re-selects landmark k_brute - 1 (the same arg-max)
   hipLaunchKernelGGL((fps2_bucket_init_kernel<DIM, RPL>), dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, st,
-                     pts_sorted, minsq, n, order, n_buckets, box, keys);
+                     pts_sorted, minsq, n, order, n_buckets, box, keys, bcoord);
   hipLaunchKernelGGL(fps2_set_ctr_kernel, dim3(1), dim3(1), 0, st, ctr, k_brute - 1);
-  hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order, pts,
-                     ld, n_buckets, box, keys, 0, n_lms, ctr, slots, out_idx, 1);
+  hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
+                     n_buckets, box, keys, bcoord, 0, n_lms, ctr, rec, out_idx, 1);
   int L = 1, done = k_brute - 1;
   int round = 64;
   while (done < n_lms) {
@@ -387,7 +509,7 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
     if (round > remaining) round = remaining;  // (a launch selects at least one landmark)
     for (int i = 0; i < round; ++i, ++L)
       hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
-                         pts, ld, n_buckets, box, keys, L, n_lms, ctr, slots, out_idx, 0);
+                         n_buckets, box, keys, bcoord, L, n_lms, ctr, rec, out_idx, 0);
     int32_t now = 0;
     if (hipMemcpyAsync(&now, ctr + L, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
@@ -406,19 +528,19 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
 template <int DIM>
 struct FpsBatchedOp {
   static int run(const float* pts, int64_t n, int ld, const float* pts_sorted, const int32_t* order, int n_lms,
-                 int64_t start, int64_t* out_idx, float* minsq, float* box, u64* keys, u64* best, u64* slots,
-                 int32_t* ctr, int32_t* launches_out, hipStream_t st) {
+                 int64_t start, int64_t* out_idx, float* minsq, float* box, u64* keys, float* bcoord, u64* best,
+                 uint32_t* rec, int32_t* ctr, int32_t* launches_out, hipStream_t st) {
     // small clouds: 64-row buckets (more waves to spread a landmark's neighbourhood over) and a late switch (a
     // brute step over an L2-resident cloud costs about as much as a launch); large clouds: 256-row buckets
-    const int rpl = g_fps_rpl ? g_fps_rpl : (n >= (4 << 20) ? 4 : 1);
+    const int rpl = batched_rpl(n);
     // (measured: 1 M / 1 k 2.92 ms at 96, 3.15 at 32, 3.07 at 256; 16 M / 4 k 19.3 ms at 8, 20.2 at 32, 29.9 at 256)
     int k0 = g_fps_switch ? g_fps_switch : (n >= (4 << 20) ? 8 : 96);
     if (k0 < 2) k0 = 2;  // (the start point is applied by a brute-force step)
     if (rpl == 4)
-      return run_batched<DIM, 4>(pts, n, ld, pts_sorted, order, n_lms, start, k0, out_idx, minsq, box, keys, best, slots,
-                                 ctr, launches_out, st);
-    return run_batched<DIM, 1>(pts, n, ld, pts_sorted, order, n_lms, start, k0, out_idx, minsq, box, keys, best, slots,
-                               ctr, launches_out, st);
+      return run_batched<DIM, 4>(pts, n, ld, pts_sorted, order, n_lms, start, k0, out_idx, minsq, box, keys, bcoord, best,
+                                 rec, ctr, launches_out, st);
+    return run_batched<DIM, 1>(pts, n, ld, pts_sorted, order, n_lms, start, k0, out_idx, minsq, box, keys, bcoord, best,
+                               rec, ctr, launches_out, st);
   }
 };
 
@@ -426,19 +548,25 @@ struct FpsBatchedOp {
 
 extern "C" {
 
-int64_t flooder_fps_batched_slot_words(int n_lms) { return (int64_t)(n_lms + 4) * (SLOTS2 * 2); }
+int64_t flooder_fps_batched_max_points(void) { return (int64_t)64 * NREC * 4 * 64 * 64 * 4; }  // 256 blocks of 256-row buckets
+
+int64_t flooder_fps_batched_rec_words(int64_t n_pts, int dim, int n_lms) {
+  if (n_pts < 1 || dim < 1 || dim > FLOODER_MAX_DIM || n_lms < 1) return 0;
+  const int64_t blocks = batched_rpl(n_pts) == 4 ? batched_blocks<4>(n_pts) : batched_blocks<1>(n_pts);
+  return (int64_t)(n_lms + 4) * blocks * (6 + 3 * padded_dim(dim));
+}
 
 int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,
                             const int32_t* order, int n_lms, int64_t start, int64_t* out_idx, float* minsq,
-                            float* bucket_box, uint64_t* bucket_keys, uint64_t* work_best, uint64_t* work_slots,
-                            int32_t* work_ctr, int32_t* launches_out, void* stream) {
-  if (!pts || !pts_sorted || !order || !out_idx || !minsq || !bucket_box || !bucket_keys || !work_best ||
-      !work_slots || !work_ctr || n_pts < 1 || n_lms < 1 || n_lms > n_pts || start < 0 || start >= n_pts || ld < dim ||
+                            float* bucket_box, uint64_t* bucket_keys, float* bucket_coord, uint64_t* work_best,
+                            uint32_t* work_rec, int32_t* work_ctr, int32_t* launches_out, void* stream) {
+  if (!pts || !pts_sorted || !order || !out_idx || !minsq || !bucket_box || !bucket_keys || !bucket_coord || !work_best ||
+      !work_rec || !work_ctr || n_pts < 1 || n_lms < 1 || n_lms > n_pts || start < 0 || start >= n_pts || ld < dim ||
       dim < 1 || dim > FLOODER_MAX_DIM || n_pts > 0xfffffffeLL)
     return fail(FLOODER_E_ARG, "flooder_fps_batched_f32: bad argument");
   return dispatch_dim<FpsBatchedOp>(dim, pts, n_pts, ld, pts_sorted, order, n_lms, start, out_idx, minsq, bucket_box,
-                                    reinterpret_cast<u64*>(bucket_keys), reinterpret_cast<u64*>(work_best),
-                                    reinterpret_cast<u64*>(work_slots), work_ctr, launches_out, (hipStream_t)stream);
+                                    reinterpret_cast<u64*>(bucket_keys), bucket_coord, reinterpret_cast<u64*>(work_best),
+                                    work_rec, work_ctr, launches_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -384,19 +384,21 @@ int flooder_fps_indexed_f32(const float* pts, int64_t n_pts, int dim, int ld, co
 /* The same selection with SEVERAL landmarks per launch (default of generate_landmarks on ROCm tensors, dim <= 8).
  * FPS is sequential, but the runners-up of the arg-max stay the next landmarks as long as each is at least its own
  * running minimum away from the ones before it (flood_fps2.hip): a launch selects such a prefix (<= 8) and applies
- * all its updates at once - same indices as flooder_fps_indexed_f32 / flooder_fps_f32, a quarter of the launches.
+ * all its updates at once - same indices as flooder_fps_indexed_f32 / flooder_fps_f32 in a fraction of the launches.
  * pts_sorted / order: rows of the cloud in curve order (flooder_padded_dim(dim) floats each) and the sorted row ->
- * original index map (flooder_index_rows_f32 / flooder_index_sort).  Workspaces (device): minsq n_pts floats;
- * bucket_box 2 * padded_dim * flooder_fps_bucket_count(n_pts) floats; bucket_keys 2 * bucket count uint64;
- * work_best 64 * n_lms uint64, ZEROED; work_slots flooder_fps_batched_slot_words(n_lms) uint64, ZEROED; work_ctr
- * n_lms + 4 int32, ZEROED.  launches_out (host pointer, may be NULL): kernel launches used.
+ * original index map (flooder_index_rows_f32 / flooder_index_sort).  n_pts <= flooder_fps_batched_max_points().
+ * Workspaces (device): minsq n_pts floats; bucket_box 2 * padded_dim * flooder_fps_bucket_count(n_pts) floats;
+ * bucket_keys 2 * bucket count uint64; bucket_coord padded_dim * bucket count floats; work_best 64 * n_lms uint64,
+ * ZEROED; work_rec flooder_fps_batched_rec_words(n_pts, dim, n_lms) uint32; work_ctr n_lms + 4 int32, ZEROED.
+ * launches_out (host pointer, may be NULL): kernel launches used.
  * UNLIKE every other entry point this one SYNCHRONISES the stream: the number of launches depends on the data, so
  * they are enqueued in rounds and the landmark counter (4 bytes) is read back between rounds. */
-int64_t flooder_fps_batched_slot_words(int n_lms);
+int64_t flooder_fps_batched_max_points(void);
+int64_t flooder_fps_batched_rec_words(int64_t n_pts, int dim, int n_lms);
 int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,
                             const int32_t* order, int n_lms, int64_t start, int64_t* out_idx, float* minsq,
-                            float* bucket_box, uint64_t* bucket_keys, uint64_t* work_best, uint64_t* work_slots,
-                            int32_t* work_ctr, int32_t* launches_out, void* stream);
+                            float* bucket_box, uint64_t* bucket_keys, float* bucket_coord, uint64_t* work_best,
+                            uint32_t* work_rec, int32_t* work_ctr, int32_t* launches_out, void* stream);
 
 #ifdef __cplusplus
 }

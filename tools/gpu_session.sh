@@ -31,7 +31,8 @@ PY
             ;;
     prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
             python tools/summarize_profiles.py ${s#prof:} r3_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
-            mkdir -p $OUT/profiles && cp profiles/r3_${s#prof:}_* profiles/traffic.json $OUT/profiles/ ;;
+            mkdir -p $OUT/profiles && cp profiles/r3_${s#prof:}_* profiles/traffic.json $OUT/profiles/
+            rm -rf $R/gpurun_out/prof_${s#prof:} ;;   # (only the summaries travel back: gpurun_out is capped at 64 MiB)
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
     emul:*) bash tools/emulate_scaling.sh ${s#emul:} > $OUT/emulate_${s#emul:}.txt 2>&1; cat $OUT/emulate_${s#emul:}.txt ;;
     timers) FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so

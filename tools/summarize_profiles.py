@@ -43,12 +43,15 @@ traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/t
 sha = kernel_source_sha()
 # span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
 # (method, span, ((kernel, launches per step), ...))
-SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true>", 1), ("cell_sweep_kernel<3, false>", 1))),
+SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true, 4>", 1), ("cell_sweep_kernel<3, false, 4>", 1))),
          # the pass over the flagged tiles, its hard tiles (one workgroup each), the ordering of the flagged tiles:
          # one launch each per step (the "top pass" that doubled the first two is off by default since round 2)
          ("cell", "fallback", (("finish_faces_kernel<3, false>", 1), ("finish_faces_kernel<3, true>", 1),
                                ("order_flags_kernel", 1))),
-         ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)), ("bvh", "sweep_bvh", (("sweep_bvh_kernel<6, 1, 1>", 1),)),
+         ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)),
+         # tree sweep over sorted samples: keys, the radix sort's launches (rocprim kernels are not listed by name:
+         # their share is in kernel_stats.csv), the sweep
+         ("bvh", "sweep_bvh", (("sweep_sorted_kernel<6>", 1), ("sample_keys_kernel<6>", 1))),
          ("ball", "sweep_ball", (("sweep_kernel<3, true>", 1),)))
 for method, span, kerns, in SPANS:
     have = [(k, m) for k, m in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
