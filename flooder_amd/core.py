@@ -875,6 +875,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
     if S == 0:
         return (torch.empty((0, faces.n_faces), dtype=torch.float32, device=dev),
                 torch.empty((0, R), dtype=torch.float32, device=dev) if want_dist else None)
+    planes = torch.empty(24 * S, dtype=torch.float32, device=dev)   # face planes per simplex (filled by the sweep's entry)
     if FUSED_FACES and not want_dist and reduce_hook is None and plan.memb_all is not None:
         # ---- only the per-face maxima are wanted: fused path.  The cell sweep delivers every settled sample to
         # face_bits (integer atomic max), the finish drops what cannot raise a face maximum, the (S, R) buffer is
@@ -913,7 +914,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
                 ctl[27:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
-                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(sub(0, 9)), st),
+                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(sub(0, 9)), st),
                 "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
@@ -942,7 +943,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         _native.check(lib.flooder_sweep_cell_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2), _native.ptr(flags),
-            ctl[1:].data_ptr(), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
+            ctl[1:].data_ptr(), _native.ptr(planes), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),

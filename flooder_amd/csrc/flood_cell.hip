@@ -113,6 +113,106 @@ struct DeferList {
   int32_t* tile_count = nullptr;
 };
 
+// Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
+// pn . (x - org) <= po relative to the LOCAL origin org = vertex 0 (no cancellation for clouds far from the
+// coordinate origin).  A point within c of a sample lies within c of every such half-space; the test in the sweep
+// allows c plus the fp32 error of the plane itself: the direction of a cross product of two edges is off by
+// about 4 eps / sin(angle between them), which the per-plane slack pslack (8 eps / sin) times the simplex
+// extent covers.  Needle faces (sin < 1e-4), flat simplices (height below 1e-4 of the extent: the sign of
+// `side` is not trustworthy) and degenerate faces switch their plane off.
+// One table row per simplex (PLANE_ROW floats: org[3], sext, then pn[3], po, pslack per face), written by
+// simplex_planes_kernel before the sweep: the same for all ~20 chunks of a simplex, and ~150 wave-uniform
+// instructions with two square roots and a division that every chunk used to repeat on the vector ALU.
+constexpr int PLANE_ROW = 24;
+
+template <int DIM>
+__global__ __launch_bounds__(256) void simplex_planes_kernel(const float* __restrict__ verts, int k1, int64_t n_simplices,
+                                                             float* __restrict__ tab) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_simplices) return;
+  const float* vs = verts + s * (int64_t)k1 * DIM;
+  float pn[DIM + 1][DIM], po[DIM + 1], pslack[DIM + 1], org[DIM];
+  float sext2 = 0.f;  // squared extent of the simplex around org
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) org[k] = vs[k];
+  for (int j = 1; j < k1; ++j) {
+    float e2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) e2 = __builtin_fmaf(vs[j * DIM + k] - org[k], vs[j * DIM + k] - org[k], e2);
+    sext2 = __builtin_fmaxf(sext2, e2);
+  }
+  const float sext = __builtin_sqrtf(sext2);
+#pragma unroll
+  for (int f = 0; f <= DIM; ++f) {
+    po[f] = 3.0e38f;  // disabled plane: the test always passes
+    pslack[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) pn[f][k] = 0.f;
+  }
+  if (k1 == DIM + 1) {
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+      int id[DIM];
+      int qq = 0;
+#pragma unroll
+      for (int j = 0; j <= DIM; ++j)
+        if (j != f) id[qq++] = j;
+      float nrm[DIM];
+      float l12;  // |e1|^2 |e2|^2 (3D) or |e|^2 (2D): len2 / l12 = sin^2 of the angle between the edges
+      if constexpr (DIM == 3) {
+        float e1[3], e2[3];
+        float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          e1[k] = vs[id[1] * 3 + k] - vs[id[0] * 3 + k];
+          e2[k] = vs[id[2] * 3 + k] - vs[id[0] * 3 + k];
+          l1 = __builtin_fmaf(e1[k], e1[k], l1);
+          l2 = __builtin_fmaf(e2[k], e2[k], l2);
+        }
+        nrm[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        nrm[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        l12 = l1 * l2;
+      } else {
+        const float ex = vs[id[1] * 2 + 0] - vs[id[0] * 2 + 0];
+        const float ey = vs[id[1] * 2 + 1] - vs[id[0] * 2 + 1];
+        nrm[0] = ey;
+        nrm[1] = -ex;
+        l12 = ex * ex + ey * ey;
+      }
+      float len2 = 0.f, side = 0.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        len2 = __builtin_fmaf(nrm[k], nrm[k], len2);
+        side = __builtin_fmaf(nrm[k], vs[f * DIM + k] - vs[id[0] * DIM + k], side);
+      }
+      const bool ok = len2 > 1e-30f && len2 >= 1e-8f * l12 && side * side >= 1e-8f * len2 * sext2;
+      const float sc = ok ? (side > 0.f ? -1.f : 1.f) / __builtin_sqrtf(len2) : 0.f;
+      float off = 0.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        pn[f][k] = nrm[k] * sc;
+        off = __builtin_fmaf(pn[f][k], vs[id[0] * DIM + k] - org[k], off);
+      }
+      po[f] = ok ? off : 3.0e38f;
+      pslack[f] = ok ? 1e-6f * __builtin_sqrtf(l12 / len2) : 0.f;
+    }
+  }
+  float* row = tab + s * PLANE_ROW;
+#pragma unroll
+  for (int i = 0; i < PLANE_ROW; ++i) row[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) row[k] = org[k];
+  row[3] = sext;
+#pragma unroll
+  for (int f = 0; f <= DIM; ++f) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) row[4 + 5 * f + k] = pn[f][k];
+    row[4 + 5 * f + 3] = po[f];
+    row[4 + 5 * f + 4] = pslack[f];
+  }
+}
+
 // SUPER = true: a work item is a run of GS consecutive chunks of one simplex (1024 samples: with the bisection order
 // of the samples still a compact patch).  The points around the whole run are gathered, filtered and staged ONCE
 // (one density estimate, one cell size) and the chunks are then queried one after the other against that stage - the
@@ -123,7 +223,7 @@ template <int DIM, bool SUPER, int SPLV>
 __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
    
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
-    const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
+    const float* __restrict__ verts, const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int retry_pct, int retry_keep, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
     unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl) {
@@ -266,78 +366,24 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         best[i] = __builtin_inff();
       }
     };
-    // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
-    // pn . (x - org) <= po relative to the LOCAL origin org = vertex 0 (no cancellation for clouds far from the
-    // coordinate origin).  A point within c of a sample lies within c of every such half-space; the test below
-    // allows c plus the fp32 error of the plane itself: the direction of a cross product of two edges is off by
-    // about 4 eps / sin(angle between them), which the per-plane slack pslack (8 eps / sin) times the simplex
-    // extent covers.  Needle faces (sin < 1e-4), flat simplices (height below 1e-4 of the extent: the sign of
-    // `side` is not trustworthy) and degenerate faces switch their plane off.
+    // face planes of the simplex: one table row, six scalar 16-byte loads (simplex_planes_kernel above)
     float pn[DIM + 1][DIM], po[DIM + 1], pslack[DIM + 1], org[DIM];
-    float sext2 = 0.f;  // squared extent of the simplex around org (wave-uniform)
+    float sext;
+    {
+      const float* pt = plane_tab + s * PLANE_ROW;
+      typename RowVec<4>::type t[PLANE_ROW / 4];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) org[k] = vs[k];
-    for (int j = 1; j < k1; ++j) {
-      float e2 = 0.f;
+      for (int i = 0; i < PLANE_ROW / 4; ++i) t[i] = load_uniform_row<4>(pt + 4 * i);
+      auto at = [&](int i) { return t[i >> 2][i & 3]; };
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) e2 = __builtin_fmaf(vs[j * DIM + k] - org[k], vs[j * DIM + k] - org[k], e2);
-      sext2 = __builtin_fmaxf(sext2, e2);
-    }
-    const float sext = __builtin_sqrtf(sext2);
-#pragma unroll
-    for (int f = 0; f <= DIM; ++f) {
-      po[f] = 3.0e38f;  // disabled plane: the test below always passes
-      pslack[f] = 0.f;
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) pn[f][k] = 0.f;
-    }
-    if (k1 == DIM + 1) {
+      for (int k = 0; k < DIM; ++k) org[k] = at(k);
+      sext = at(3);
 #pragma unroll
       for (int f = 0; f <= DIM; ++f) {
-        int id[DIM];
-        int qq = 0;
 #pragma unroll
-        for (int j = 0; j <= DIM; ++j)
-          if (j != f) id[qq++] = j;
-        float nrm[DIM];
-        float l12;  // |e1|^2 |e2|^2 (3D) or |e|^2 (2D): len2 / l12 = sin^2 of the angle between the edges
-        if constexpr (DIM == 3) {
-          float e1[3], e2[3];
-          float l1 = 0.f, l2 = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            e1[k] = vs[id[1] * 3 + k] - vs[id[0] * 3 + k];
-            e2[k] = vs[id[2] * 3 + k] - vs[id[0] * 3 + k];
-            l1 = __builtin_fmaf(e1[k], e1[k], l1);
-            l2 = __builtin_fmaf(e2[k], e2[k], l2);
-          }
-          nrm[0] = e1[1] * e2[2] - e1[2] * e2[1];
-          nrm[1] = e1[2] * e2[0] - e1[0] * e2[2];
-          nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
-          l12 = l1 * l2;
-        } else {
-          const float ex = vs[id[1] * 2 + 0] - vs[id[0] * 2 + 0];
-          const float ey = vs[id[1] * 2 + 1] - vs[id[0] * 2 + 1];
-          nrm[0] = ey;
-          nrm[1] = -ex;
-          l12 = ex * ex + ey * ey;
-        }
-        float len2 = 0.f, side = 0.f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          len2 = __builtin_fmaf(nrm[k], nrm[k], len2);
-          side = __builtin_fmaf(nrm[k], vs[f * DIM + k] - vs[id[0] * DIM + k], side);
-        }
-        const bool ok = len2 > 1e-30f && len2 >= 1e-8f * l12 && side * side >= 1e-8f * len2 * sext2;
-        const float sc = ok ? (side > 0.f ? -1.f : 1.f) / __builtin_sqrtf(len2) : 0.f;
-        float off = 0.f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          pn[f][k] = nrm[k] * sc;
-          off = __builtin_fmaf(pn[f][k], vs[id[0] * DIM + k] - org[k], off);
-        }
-        po[f] = ok ? off : 3.0e38f;
-        pslack[f] = ok ? 1e-6f * __builtin_sqrtf(l12 / len2) : 0.f;
+        for (int k = 0; k < DIM; ++k) pn[f][k] = at(4 + 5 * f + k);
+        po[f] = at(4 + 5 * f + 3);
+        pslack[f] = at(4 + 5 * f + 4);
       }
     }
 
@@ -1162,7 +1208,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
 
 template <int DIM>
 struct CellOp {
-  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts,
+  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, float* plane_tab,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
                  FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, hipStream_t st) {
@@ -1170,6 +1216,8 @@ struct CellOp {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
+      hipLaunchKernelGGL((simplex_planes_kernel<DIM>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, verts, k1, ns,
+                         plane_tab);
       constexpr int CHUNK = 64 * SPL_CHUNK;
       const int64_t n_chunks = ns * ((R + CHUNK - 1) / CHUNK);
       int64_t want = n_chunks / 48;
@@ -1184,7 +1232,7 @@ struct CellOp {
       }
       if (!g_cell_tiles) { dl.tile_list = nullptr; dl.tile_c = nullptr; dl.tile_count = nullptr; }
 #define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
-  hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, weights, \
+  hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
                      k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \
                      g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl)
       if (dl.list) {
@@ -1255,11 +1303,11 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
 }
 
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
-                     const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
+                     float* plane_tab, const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
                      DeferList dl, int32_t* queue2, int32_t* queue3, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
-  if (!pts_sorted || !nodes || !verts || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
+  if (!pts_sorted || !nodes || !verts || !plane_tab || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
       n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
     return fail(FLOODER_E_ARG, who);
   if (dim != 2 && dim != 3) return fail(FLOODER_E_ARG, "cell sweep: only dim 2 and 3");
@@ -1270,7 +1318,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
   if ((n_pts + FLOODER_BVH_LEAF) * (int64_t)(padded_dim(dim) * sizeof(float)) >= (1LL << 32) ||
       total_nodes(lv) * (int64_t)(2 * padded_dim(dim) * sizeof(float)) >= (1LL << 32))
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
-  return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices, alpha, queue,
+  return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, plane_tab, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), acc,
                               dl, queue2, queue3, (hipStream_t)stream);
 }
@@ -1282,8 +1330,8 @@ extern "C" {
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                            float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
-                           uint64_t* stats, void* stream) {
-  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue, out_d2,
+                           float* plane_scratch, uint64_t* stats, void* stream) {
+  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           flag_list, flag_count, stats, FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
                           DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr, stream,
                           "flooder_sweep_cell_f32: bad argument");
@@ -1296,7 +1344,8 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
                                  int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
-                                 int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream) {
+                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch, uint64_t* stats,
+                                 void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)) ||
       (defer_list && (!defer_c || !defer_ctl)) || (simplex_weight && (!defer_list || !light_list || !heavy_list)) ||
@@ -1316,7 +1365,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
     dl.tile_c = defer_c + n_chunk_slots;
     dl.tile_count = defer_ctl + 6;
   }
-  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, alpha, queue,
+  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot, flag_key, flag_hist},

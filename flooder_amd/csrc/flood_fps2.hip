@@ -192,9 +192,11 @@ __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __re
 // Block record of a launch (plain stores by the block that owns it, read by every wave of the next launch):
 //   b1 best point of the block's buckets | k2 second-best point of THAT point's bucket | bo best of every other point of
 //   the block (an upper bound) | coordinates of the b1 point | box of its bucket.  32-bit words:
+// (sections of 16 bytes or whole padded rows: a record is read with 16-byte loads)
 template <int DP>
 struct Rec {
-  static constexpr int B1 = 0, K2 = 2, BO = 4, C = 6, LO = 6 + DP, HI = 6 + 2 * DP, WORDS = 6 + 3 * DP;
+  static constexpr int DPR = DP < 4 ? 4 : DP;  // row section (floats)
+  static constexpr int B1 = 0, K2 = 2, BO = 4, C = 8, LO = 8 + DPR, HI = 8 + 2 * DPR, WORDS = 8 + 3 * DPR;
 };
 constexpr int NREC = 4;  // records per lane: at most 256 blocks
 
@@ -254,31 +256,35 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
       for (int k = 0; k < DIM; ++k) { ac[t][k] = 0.f; alo[t][k] = 0.f; ahi[t][k] = 0.f; }
       if (idx < (int)gridDim.x) {
         const uint32_t* r = rc + (int64_t)idx * RC::WORDS;
-        a[t] = *reinterpret_cast<const u64*>(r + RC::B1);
-        ak2[t] = *reinterpret_cast<const u64*>(r + RC::K2);
-        const u64 o = *reinterpret_cast<const u64*>(r + RC::BO);
+        const uint4 h0 = *reinterpret_cast<const uint4*>(r);        // b1, k2
+        const uint2 h1 = *reinterpret_cast<const uint2*>(r + RC::BO);
+        a[t] = ((u64)h0.y << 32) | (u64)h0.x;
+        ak2[t] = ((u64)h0.w << 32) | (u64)h0.z;
+        const u64 o = ((u64)h1.y << 32) | (u64)h1.x;
         bo = o > bo ? o : bo;
+        float rc_[RC::DPR], rl_[RC::DPR], rh_[RC::DPR];
+        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::C), rc_);
+        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::LO), rl_);
+        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::HI), rh_);
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          ac[t][k] = __uint_as_float(r[RC::C + k]);
-          alo[t][k] = __uint_as_float(r[RC::LO + k]);
-          ahi[t][k] = __uint_as_float(r[RC::HI + k]);
-        }
+        for (int k = 0; k < DIM; ++k) { ac[t][k] = rc_[k]; alo[t][k] = rl_[k]; ahi[t][k] = rh_[k]; }
       }
     }
     const u64 B = wave_max_key(bo);
+    // ---- candidates in descending order, each accepted (or the batch closed) before the next is looked for: a
+    // round is a chain of dependent cross-lane reductions (~0.3 us for a wave alone on its SIMD), and most batches
+    // close after three or four
     u64 ck[KMAX];
-    float cc[KMAX][DIM];   // coordinates of the candidates
-    float chb[KMAX];       // bound of the hidden points of a candidate's bucket once the candidate is a landmark
-    int nc = 0;
+    float cc[KMAX][DIM];   // coordinates of the accepted candidates
+    int nb = 0;
+    float hbound = 0.f;    // largest bound of the points hidden in an accepted candidate's own bucket
     u64 prev = ~0ull;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
       ck[i] = 0ull;
-      chb[i] = 0.f;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) cc[i][k] = 0.f;
-      if (nc == i) {  // (wave-uniform)
+      if (nb == i && i < n_lms - it) {  // (wave-uniform: every candidate before i was accepted)
         u64 m = 0ull;
         int tsel = 0;
 #pragma unroll
@@ -286,9 +292,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
           if (a[t] > B && a[t] < prev && a[t] > m) { m = a[t]; tsel = t; }
         const u64 wk = wave_max_key(m);
         if (wk != 0ull) {
-          ck[i] = wk;
           prev = wk;
-          ++nc;
           // the lane that holds this record broadcasts its coordinates and the hidden-point bound of its bucket:
           // min(second-best minimum of the bucket, farthest corner of the bucket's box from the candidate) - every
           // point of the bucket is at most that far from the new landmark (same fma chain on |corner gap| >= |difference|)
@@ -310,27 +314,23 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
             }
           }
           const int src = __builtin_ctzll(__ballot(m == wk));
+          float ci[DIM];
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) cc[i][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc[k]), src));
-          chb[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb), src));
-        }
-      }
-    }
-    // ---- the prefix that is provably the sequential selection
-    int nb = nc > 0 ? 1 : 0;
-    float hbound = chb[0];  // largest hidden-point bound over the accepted candidates
+          for (int k = 0; k < DIM; ++k) ci[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc[k]), src));
+          const float hbi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb), src));
+          const float mi = __uint_as_float((uint32_t)(wk >> 32));
+          bool ok = i == 0 || (mi > 0.f && mi > hbound);
 #pragma unroll
-    for (int i = 1; i < KMAX; ++i) {
-      if (nb == i && i < nc) {  // (wave-uniform: every candidate before i was accepted)
-        const float mi = __uint_as_float((uint32_t)(ck[i] >> 32));
-        bool ok = mi > 0.f && mi > hbound;
+          for (int l = 0; l < KMAX; ++l) {
+            if (l < i) ok = ok && !(dist2<DIM>(ci, cc[l]) < mi);
+          }
+          if (ok) {
+            ck[i] = wk;
 #pragma unroll
-        for (int l = 0; l < KMAX; ++l) {
-          if (l < i) ok = ok && !(dist2<DIM>(cc[i], cc[l]) < mi);
-        }
-        if (ok) {
-          nb = i + 1;
-          hbound = __builtin_fmaxf(hbound, chb[i]);
+            for (int k = 0; k < DIM; ++k) cc[i][k] = ci[k];
+            hbound = __builtin_fmaxf(hbound, hbi);
+            nb = i + 1;
+          }
         }
       }
     }
@@ -553,7 +553,8 @@ int64_t flooder_fps_batched_max_points(void) { return (int64_t)64 * NREC * 4 * 6
 int64_t flooder_fps_batched_rec_words(int64_t n_pts, int dim, int n_lms) {
   if (n_pts < 1 || dim < 1 || dim > FLOODER_MAX_DIM || n_lms < 1) return 0;
   const int64_t blocks = batched_rpl(n_pts) == 4 ? batched_blocks<4>(n_pts) : batched_blocks<1>(n_pts);
-  return (int64_t)(n_lms + 4) * blocks * (6 + 3 * padded_dim(dim));
+  const int dpr = padded_dim(dim) < 4 ? 4 : padded_dim(dim);
+  return (int64_t)(n_lms + 4) * blocks * (8 + 3 * dpr);
 }
 
 int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,

@@ -245,11 +245,13 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
  * queue: one zeroed int32.  stats: NULL or nine zeroed uint64 {pairs evaluated, points staged, tiles
  * flagged, re-staging rounds, chunks given up: tree gather overflow at density / at staging, kept list
  * full, cell doublings exhausted; rounds evaluated exhaustively because the LDS stage was full}.
+ * plane_scratch: 24 * n_simplices floats of device scratch (the face planes of every simplex, computed once by a
+ * small kernel instead of by each of its chunks).
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                            float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
-                           uint64_t* stats, void* stream);
+                           float* plane_scratch, uint64_t* stats, void* stream);
 
 /*
  * Cell sweep fused with the per-face maxima (core.py:251-276 folded into the sweep): as flooder_sweep_cell_f32 over
@@ -279,6 +281,7 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * flag_key / flag_hist (both NULL, or as many uint32 as flag_list holds / 8192 zeroed int32; need top): the probe's
  * bound of every flagged tile, parallel to flag_list, and a histogram of the bounds' top 12 bits - with them the
  * finish works the tiles off longest search first.
+ * plane_scratch: as flooder_sweep_cell_f32.
  * Followed by flooder_finish_faces_f32 (probed = 1 when top was passed here) and flooder_face_values_f32.
  */
 int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
@@ -288,7 +291,8 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
                                  int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
-                                 int32_t* light_list, int32_t* heavy_list, uint64_t* stats, void* stream);
+                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch, uint64_t* stats,
+                                 void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
