@@ -56,12 +56,14 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p]),
+                                       c_void_p, c_void_p, c_void_p]),
+    "flooder_density_grid_words": (c_int64, [c_int]),
+    "flooder_density_grid_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_cell_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_finish_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -537,6 +537,12 @@ class PointIndex:
             _native.check(lib.flooder_index_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
                                                      _native.ptr(self.pts), n_pad, _native.ptr(self.nodes), st),
                           "flooder_index_rows_f32")
+            # density grid for the cell sweep (2D / 3D): point counts per cell, from the leaf boxes
+            self.dens = None
+            if dim in (2, 3) and CELL_DENSITY_GRID:
+                self.dens = torch.zeros(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
+                _native.check(lib.flooder_density_grid_f32(_native.ptr(self.nodes), n, dim, _native.ptr(self.box),
+                                                           _native.ptr(self.dens), st), "flooder_density_grid_f32")
 
 
 def index_from_host(points_cpu: torch.Tensor, device, chunk_rows: int = 1 << 21):
@@ -834,6 +840,7 @@ FUSED_FACES = True
 CELL_PROBE = True    # the finish's probe (one greedy tree descent per flagged tile) runs inside the cell sweep
 SHARED_FACE_SLOTS = True   # one running maximum per distinct face of the complex (top-dimensional grid sweeps)
 FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does not fit is finished by one wave)
+CELL_DENSITY_GRID = True   # PointIndex carries a density grid; the cell sweep reads its first cell size from it
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 
 
@@ -914,7 +921,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
                 ctl[27:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
-                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(sub(0, 9)), st),
+                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(index.dens),
+                _native.ptr(index.box), _native.ptr(sub(0, 9)), st),
                 "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
@@ -943,7 +951,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         _native.check(lib.flooder_sweep_cell_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
             _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2), _native.ptr(flags),
-            ctl[1:].data_ptr(), _native.ptr(planes), _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
+            ctl[1:].data_ptr(), _native.ptr(planes), _native.ptr(index.dens), _native.ptr(index.box),
+            _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),

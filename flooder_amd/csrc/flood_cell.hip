@@ -37,6 +37,22 @@ constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively 
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 constexpr int BRUTE_CAP = CAPW - CAPW / 4 - 4;  // compacted points the classification pass may leave in the stage
 
+// Density grid of the cloud (flooder_density_grid_f32: G^DIM point counts over the cloud's box, then a coarse level
+// of RAT^DIM fine cells each).  With it a chunk reads the local density from the cells under its box - nine loads -
+// instead of walking the tree for the leaves under the box and counting their points (15 % of the sweep's wave time).
+struct DensGrid {
+  const int32_t* grid = nullptr;  // fine level, then the coarse level
+  const float* box = nullptr;     // the cloud's box (16 floats: [0:dim] min, [8:8+dim] max), device memory
+};
+template <int DIM>
+struct DensCfg {
+  static constexpr int G = DIM == 2 ? 256 : 64;   // fine cells per axis
+  static constexpr int RAT = DIM == 2 ? 8 : 4;    // fine cells per coarse cell and axis
+  static constexpr int GC = G / RAT;
+  static constexpr int NF = DIM == 2 ? G * G : G * G * G;
+  static constexpr int NCOARSE = DIM == 2 ? GC * GC : GC * GC * GC;
+};
+
 template <int DIM>
 struct CellCfg {
   static constexpr int G = DIM == 2 ? 32 : 10;                  // cells per axis
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     const float* __restrict__ verts, const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int retry_pct, int retry_keep, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
     int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl) {
+    unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl, DensGrid dg) {
   constexpr int DP = padded_dim(DIM);
   constexpr int SPL = SPLV;          // samples per lane
   constexpr int CHUNK = 64 * SPL;    // samples per wave item (SPLV = 1: the tile launch)
@@ -514,13 +530,70 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     // ---- 1. density of the cloud inside the region's box -> first cell size
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { qlo[k] = blo[k]; qhi[k] = bhi[k]; }
-    int n_leaves = seeded ? 0 : gather();
+    const bool use_grid = dg.grid != nullptr && !seeded;
+    int n_leaves = (seeded || use_grid) ? 0 : gather();
     PHASE(2);
     bool give_up = n_leaves < 0;
     if (give_up) ++g_gather0;
     float c = seeded ? c_seed : ext;
     int n0 = 0;  // points of the cloud inside the box
-    if (!give_up && !seeded) {
+    if (use_grid) {
+      // local density from the grid: the cells under the centre and the corners of the box (all loads in flight at
+      // once), their mean as the box's density; a sparse neighbourhood (fewer than 8 points seen) asks the coarse
+      // level at the centre.  Any value is correct - a bad cell size costs time only.
+      typedef DensCfg<DIM> DC;
+      const typename RowVec<4>::type b0 = load_uniform_row<4>(dg.box), b1 = load_uniform_row<4>(dg.box + 8);
+      float glo[DIM], gsc[DIM], cell_vol = 1.f;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {
+        const float e = b1[k] - b0[k];
+        glo[k] = b0[k];
+        gsc[k] = e > 0.f ? (float)DC::G / e : 0.f;
+        cell_vol *= e > 0.f ? e / (float)DC::G : 1.f;
+      }
+      auto cell_at = [&](const float (&x)[DIM], int& fine, int& coarse) {
+        fine = 0;
+        coarse = 0;
+#pragma unroll
+        for (int k = DIM - 1; k >= 0; --k) {
+          int ck = (int)((x[k] - glo[k]) * gsc[k]);
+          ck = ck < 0 ? 0 : (ck >= DC::G ? DC::G - 1 : ck);
+          fine = fine * DC::G + ck;
+          coarse = coarse * DC::GC + ck / DC::RAT;
+        }
+      };
+      constexpr int NP = (1 << DIM) + 1;
+      int cnt[NP], cc_idx = 0;
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) {
+        float x[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          x[k] = pi == NP - 1 ? 0.5f * (blo[k] + bhi[k]) : (((pi >> k) & 1) ? bhi[k] : blo[k]);
+        int fi, ci;
+        cell_at(x, fi, ci);
+        if (pi == NP - 1) cc_idx = ci;
+        cnt[pi] = dg.grid[fi];
+      }
+      const int coarse_cnt = dg.grid[DC::NF + cc_idx];
+      int sum = 0;
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) sum += cnt[pi];
+      float dens = (float)sum / ((float)NP * cell_vol);
+      if (sum < 8) {
+        float rv = 1.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) rv *= (float)DC::RAT;
+        dens = (float)coarse_cnt / (cell_vol * rv);
+      }
+      if (dens > 0.f) {
+        const float h = DIM == 3 ? cbrtf(1.f / dens) : __builtin_sqrtf(1.f / dens);
+        c = alpha * h;
+        const float est = dens * vol;
+        n0 = est < 1.f ? 1 : (est > 1.0e9f ? 1000000000 : (int)est);
+      }
+    }
+    if (!give_up && !seeded && !use_grid) {
       // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
       const int n_cand0 = n_leaves * LEAF;
       for (int ib = 0; ib < n_cand0; ib += 64 * UNR) {
@@ -1211,8 +1284,9 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, float* plane_tab,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, hipStream_t st) {
+                 FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
+      if (!g_cell_density_grid) dg = DensGrid{};
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
@@ -1234,7 +1308,7 @@ struct CellOp {
 #define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
   hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
                      k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \
-                     g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl)
+                     g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl, dg)
       if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         FLOODER_CELL_LAUNCH(true, SPL_CHUNK, queue);
@@ -1302,10 +1376,53 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
   if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
 }
 
+// every leaf of the box tree (16 consecutive points of the curve order) adds its point count to the fine cell under
+// the centre of its box: a sixteenth of the atomics of a pass over the points, accurate to a leaf
+template <int DIM>
+__global__ __launch_bounds__(256) void density_leaves_kernel(const float* __restrict__ nodes, int64_t n_pts,
+                                                             int64_t n_leaves, const float* __restrict__ cbox,
+                                                             int32_t* __restrict__ grid) {
+  constexpr int DP = padded_dim(DIM);
+  typedef DensCfg<DIM> DC;
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_leaves) return;
+  float lo[DP], hi[DP];
+  load_row<DP>(nodes + l * 2 * DP, lo);
+  load_row<DP>(nodes + l * 2 * DP + DP, hi);
+  int fine = 0;
+#pragma unroll
+  for (int k = DIM - 1; k >= 0; --k) {
+    const float e = cbox[8 + k] - cbox[k];
+    const float sc = e > 0.f ? (float)DC::G / e : 0.f;
+    int ck = (int)((0.5f * (lo[k] + hi[k]) - cbox[k]) * sc);
+    ck = ck < 0 ? 0 : (ck >= DC::G ? DC::G - 1 : ck);
+    fine = fine * DC::G + ck;
+  }
+  const int64_t left = n_pts - l * LEAF;
+  atomicAdd(&grid[fine], (int)(left < LEAF ? left : LEAF));
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void density_coarse_kernel(int32_t* __restrict__ grid) {
+  typedef DensCfg<DIM> DC;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= DC::NCOARSE) return;
+  int cz = DIM == 3 ? c / (DC::GC * DC::GC) : 0;
+  int cy = (c / DC::GC) % DC::GC, cx = c % DC::GC;
+  int sum = 0;
+  for (int dz = 0; dz < (DIM == 3 ? DC::RAT : 1); ++dz)
+    for (int dy = 0; dy < DC::RAT; ++dy)
+      for (int dx = 0; dx < DC::RAT; ++dx) {
+        const int f = ((cz * DC::RAT + dz) * DC::G + (cy * DC::RAT + dy)) * DC::G + (cx * DC::RAT + dx);
+        sum += grid[f];
+      }
+  grid[DC::NF + c] = sum;
+}
+
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      float* plane_tab, const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
-                     DeferList dl, int32_t* queue2, int32_t* queue3, void* stream, const char* who) {
+                     DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !plane_tab || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
       n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
@@ -1320,7 +1437,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, plane_tab, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), acc,
-                              dl, queue2, queue3, (hipStream_t)stream);
+                              dl, queue2, queue3, dg, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -1330,10 +1447,13 @@ extern "C" {
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                            float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
-                           float* plane_scratch, uint64_t* stats, void* stream) {
+                           float* plane_scratch, const int32_t* density_grid, const float* cloud_box, uint64_t* stats,
+                           void* stream) {
+  DensGrid dg;
+  if (density_grid && cloud_box) { dg.grid = density_grid; dg.box = cloud_box; }
   return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue, out_d2,
                           flag_list, flag_count, stats, FaceAcc{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
-                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr, stream,
+                          DeferList{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, nullptr, nullptr, dg, stream,
                           "flooder_sweep_cell_f32: bad argument");
 }
 
@@ -1344,9 +1464,11 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
                                  int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
-                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch, uint64_t* stats,
-                                 void* stream) {
+                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch,
+                                 const int32_t* density_grid, const float* cloud_box, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  DensGrid dg;
+  if (density_grid && cloud_box) { dg.grid = density_grid; dg.box = cloud_box; }
   if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)) ||
       (defer_list && (!defer_c || !defer_ctl)) || (simplex_weight && (!defer_list || !light_list || !heavy_list)) ||
       (flag_key && (!flag_hist || !top)) || n_simplices > 0x7fffffffLL)
@@ -1369,8 +1491,33 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot, flag_key, flag_hist},
-                          dl, defer_list ? defer_ctl + 1 : nullptr, defer_list ? defer_ctl + 7 : nullptr,
+                          dl, defer_list ? defer_ctl + 1 : nullptr, defer_list ? defer_ctl + 7 : nullptr, dg,
                           stream, "flooder_sweep_cell_faces_f32: bad argument");
+}
+
+
+int64_t flooder_density_grid_words(int dim) {
+  if (dim == 2) return DensCfg<2>::NF + DensCfg<2>::NCOARSE;
+  if (dim == 3) return DensCfg<3>::NF + DensCfg<3>::NCOARSE;
+  return 0;
+}
+
+int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const float* cloud_box, int32_t* grid,
+                             void* stream) {
+  if (!nodes || !cloud_box || !grid || n_pts < 1 || (dim != 2 && dim != 3))
+    return fail(FLOODER_E_ARG, "flooder_density_grid_f32: bad argument (dim 2 and 3 only)");
+  const int64_t n_leaves = (n_pts + LEAF - 1) / LEAF;
+  hipStream_t st = (hipStream_t)stream;
+  if (dim == 2) {
+    hipLaunchKernelGGL((density_leaves_kernel<2>), dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, nodes, n_pts,
+                       n_leaves, cloud_box, grid);
+    hipLaunchKernelGGL((density_coarse_kernel<2>), dim3((DensCfg<2>::NCOARSE + 255) / 256), dim3(256), 0, st, grid);
+  } else {
+    hipLaunchKernelGGL((density_leaves_kernel<3>), dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, nodes, n_pts,
+                       n_leaves, cloud_box, grid);
+    hipLaunchKernelGGL((density_coarse_kernel<3>), dim3((DensCfg<3>::NCOARSE + 255) / 256), dim3(256), 0, st, grid);
+  }
+  return check_launch("density_grid");
 }
 
 }  // extern "C"

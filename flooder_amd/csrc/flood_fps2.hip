@@ -357,62 +357,83 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
       }
     }
     u64 tm = __ballot(touched && has);
-    while (tm) {  // (wave-uniform) the whole wave updates one touched bucket at a time
-      const int src = __builtin_ctzll(tm);
-      tm &= tm - 1ull;
-      const int64_t tb = (int64_t)src * n_waves + w;
-      u64 b1 = 0ull, b2 = 0ull;
-      float x[RPL][DIM], m0[RPL], bx[DIM];
-      uint32_t o[RPL];
+    constexpr int TB = 4;  // touched buckets in flight: their rows are fetched together, one memory round trip
+    while (tm) {           // (wave-uniform) the whole wave updates its touched buckets, TB at a time
+      int srcs[TB];
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) bx[k] = 0.f;
-#pragma unroll
-      for (int u = 0; u < RPL; ++u) {
-        const int64_t j = tb * (RPL * 64) + u * 64 + lane;
-        const int64_t jj = j < n ? j : n - 1;
-        row_coords<DIM, DP>(pts_sorted, jj, x[u]);
-        m0[u] = minsq[jj];
-        o[u] = (uint32_t)order[jj];
+      for (int g = 0; g < TB; ++g) {
+        srcs[g] = -1;
+        if (tm) {
+          srcs[g] = __builtin_ctzll(tm);
+          tm &= tm - 1ull;
+        }
       }
+      float x[TB][RPL][DIM], m0[TB][RPL];
+      uint32_t o[TB][RPL];
 #pragma unroll
-      for (int u = 0; u < RPL; ++u) {
-        const int64_t j = tb * (RPL * 64) + u * 64 + lane;
-        if (j < n) {
-          float m = m0[u];
+      for (int g = 0; g < TB; ++g) {
+        if (srcs[g] >= 0) {
+          const int64_t tb = (int64_t)srcs[g] * n_waves + w;
 #pragma unroll
-          for (int i = 0; i < KMAX; ++i) {
-            if (i < nb) {
-              const float d2 = dist2<DIM>(x[u], cc[i]);
-              m = d2 < m ? d2 : m;
-            }
-          }
-          if (m < m0[u]) minsq[j] = m;
-          const u64 k = make_key(m, o[u]);
-          if (k > b1) {
-            b2 = b1;
-            b1 = k;
-#pragma unroll
-            for (int kk = 0; kk < DIM; ++kk) bx[kk] = x[u][kk];
-          } else if (k > b2) {
-            b2 = k;
+          for (int u = 0; u < RPL; ++u) {
+            const int64_t j = tb * (RPL * 64) + u * 64 + lane;
+            const int64_t jj = j < n ? j : n - 1;
+            row_coords<DIM, DP>(pts_sorted, jj, x[g][u]);
+            m0[g][u] = minsq[jj];
+            o[g][u] = (uint32_t)order[jj];
           }
         }
       }
-      const u64 nk1 = wave_max_key(b1);
-      const u64 nk2 = wave_max_key(b1 == nk1 ? b2 : b1);
-      const int bl = __builtin_ctzll(__ballot(b1 == nk1));
-      float nbx[DIM];
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) nbx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
-      if (lane == src) {
-        k1 = nk1;
-        k2 = nk2;
-        keys[2 * tb] = nk1;
-        keys[2 * tb + 1] = nk2;
+      for (int g = 0; g < TB; ++g) {
+        if (srcs[g] >= 0) {
+          const int src = srcs[g];
+          const int64_t tb = (int64_t)src * n_waves + w;
+          u64 b1 = 0ull, b2 = 0ull;
+          float bx[DIM];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-          bc[k] = nbx[k];
-          bcoord[tb * DP + k] = nbx[k];
+          for (int k = 0; k < DIM; ++k) bx[k] = 0.f;
+#pragma unroll
+          for (int u = 0; u < RPL; ++u) {
+            const int64_t j = tb * (RPL * 64) + u * 64 + lane;
+            if (j < n) {
+              float m = m0[g][u];
+#pragma unroll
+              for (int i = 0; i < KMAX; ++i) {
+                if (i < nb) {
+                  const float d2 = dist2<DIM>(x[g][u], cc[i]);
+                  m = d2 < m ? d2 : m;
+                }
+              }
+              if (m < m0[g][u]) minsq[j] = m;
+              const u64 k = make_key(m, o[g][u]);
+              if (k > b1) {
+                b2 = b1;
+                b1 = k;
+#pragma unroll
+                for (int kk = 0; kk < DIM; ++kk) bx[kk] = x[g][u][kk];
+              } else if (k > b2) {
+                b2 = k;
+              }
+            }
+          }
+          const u64 nk1 = wave_max_key(b1);
+          const u64 nk2 = wave_max_key(b1 == nk1 ? b2 : b1);
+          const int bl = __builtin_ctzll(__ballot(b1 == nk1));
+          float nbx[DIM];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) nbx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
+          if (lane == src) {
+            k1 = nk1;
+            k2 = nk2;
+            keys[2 * tb] = nk1;
+            keys[2 * tb + 1] = nk2;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              bc[k] = nbx[k];
+              bcoord[tb * DP + k] = nbx[k];
+            }
+          }
         }
       }
     }

@@ -233,6 +233,13 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
                                 int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
                                 int32_t* count2, uint64_t* stats, void* stream);
 
+/* Density grid of the cloud for the cell sweep (dim 2 and 3): point counts in 64^3 (256^2) cells over the cloud's box
+ * followed by a coarse level of 4^3 (8^2) fine cells each, accumulated from the leaves of the box tree (nodes: the
+ * array of flooder_index_rows_f32, leaves first).  grid: flooder_density_grid_words(dim) int32, ZEROED. */
+int64_t flooder_density_grid_words(int dim);
+int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const float* cloud_box, int32_t* grid,
+                             void* stream);
+
 /*
  * Cell sweep (dim 2 and 3; the default device path there).  One wave per chunk of 256 consecutive
  * samples of a simplex: the cloud's density inside the chunk's bounding box gives a cell size
@@ -247,11 +254,15 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
  * full, cell doublings exhausted; rounds evaluated exhaustively because the LDS stage was full}.
  * plane_scratch: 24 * n_simplices floats of device scratch (the face planes of every simplex, computed once by a
  * small kernel instead of by each of its chunks).
+ * density_grid / cloud_box (both NULL, or the grid of flooder_density_grid_f32 and the 16-float box of
+ * flooder_bbox_f32): with them a chunk takes the local density from the grid cells under its box instead of
+ * walking the tree and counting the points under it (option "cell_density_grid" 0 switches it off).
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                            float alpha, int32_t* queue, uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count,
-                           float* plane_scratch, uint64_t* stats, void* stream);
+                           float* plane_scratch, const int32_t* density_grid, const float* cloud_box, uint64_t* stats,
+                           void* stream);
 
 /*
  * Cell sweep fused with the per-face maxima (core.py:251-276 folded into the sweep): as flooder_sweep_cell_f32 over
@@ -291,8 +302,8 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
                                  int32_t* top_list, int32_t* top_count, int32_t* defer_list,
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
-                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch, uint64_t* stats,
-                                 void* stream);
+                                 int32_t* light_list, int32_t* heavy_list, float* plane_scratch,
+                                 const int32_t* density_grid, const float* cloud_box, uint64_t* stats, void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
