@@ -37,20 +37,18 @@ constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively 
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
 constexpr int BRUTE_CAP = CAPW - CAPW / 4 - 4;  // compacted points the classification pass may leave in the stage
 
-// Density grid of the cloud (flooder_density_grid_f32: G^DIM point counts over the cloud's box, then a coarse level
-// of RAT^DIM fine cells each).  With it a chunk reads the local density from the cells under its box - nine loads -
-// instead of walking the tree for the leaves under the box and counting their points (15 % of the sweep's wave time).
+// Density grid of the cloud (flooder_density_grid_f32: G^DIM point counts over the cloud's box).  Where its cells are
+// well filled a chunk reads the local density from the cells under its box - nine loads - instead of walking the
+// tree for the leaves under the box and counting their points (15 % of the sweep's wave time).
 struct DensGrid {
-  const int32_t* grid = nullptr;  // fine level, then the coarse level
+  const int32_t* grid = nullptr;  // G^DIM point counts
   const float* box = nullptr;     // the cloud's box (16 floats: [0:dim] min, [8:8+dim] max), device memory
+  int min_count = 16;             // the grid is used where every probed cell holds at least this many points
 };
 template <int DIM>
 struct DensCfg {
-  static constexpr int G = DIM == 2 ? 256 : 64;   // fine cells per axis
-  static constexpr int RAT = DIM == 2 ? 8 : 4;    // fine cells per coarse cell and axis
-  static constexpr int GC = G / RAT;
+  static constexpr int G = DIM == 2 ? 256 : 64;   // cells per axis
   static constexpr int NF = DIM == 2 ? G * G : G * G * G;
-  static constexpr int NCOARSE = DIM == 2 ? GC * GC : GC * GC * GC;
 };
 
 template <int DIM>
@@ -530,17 +528,15 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     // ---- 1. density of the cloud inside the region's box -> first cell size
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { qlo[k] = blo[k]; qhi[k] = bhi[k]; }
-    const bool use_grid = dg.grid != nullptr && !seeded;
-    int n_leaves = (seeded || use_grid) ? 0 : gather();
-    PHASE(2);
-    bool give_up = n_leaves < 0;
-    if (give_up) ++g_gather0;
+    // local density from the grid where the grid is telling (cells under the centre and the corners of the box, all
+    // loads in flight at once, their mean as the box's density): dense and uniform regions.  Where the cells hold only
+    // a few points each - the tails of a Gaussian cloud, where the density changes by an order of magnitude across
+    // a coarse cell - the estimate is off by factors either way (cfg 2: 30 % of the tiles flagged instead of 0.04 %),
+    // and the chunk counts the points under its box through the tree as before.
+    bool use_grid = false;
     float c = seeded ? c_seed : ext;
     int n0 = 0;  // points of the cloud inside the box
-    if (use_grid) {
-      // local density from the grid: the cells under the centre and the corners of the box (all loads in flight at
-      // once), their mean as the box's density; a sparse neighbourhood (fewer than 8 points seen) asks the coarse
-      // level at the centre.  Any value is correct - a bad cell size costs time only.
+    if (dg.grid != nullptr && !seeded) {
       typedef DensCfg<DIM> DC;
       const typename RowVec<4>::type b0 = load_uniform_row<4>(dg.box), b1 = load_uniform_row<4>(dg.box + 8);
       float glo[DIM], gsc[DIM], cell_vol = 1.f;
@@ -551,48 +547,39 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         gsc[k] = e > 0.f ? (float)DC::G / e : 0.f;
         cell_vol *= e > 0.f ? e / (float)DC::G : 1.f;
       }
-      auto cell_at = [&](const float (&x)[DIM], int& fine, int& coarse) {
-        fine = 0;
-        coarse = 0;
-#pragma unroll
-        for (int k = DIM - 1; k >= 0; --k) {
-          int ck = (int)((x[k] - glo[k]) * gsc[k]);
-          ck = ck < 0 ? 0 : (ck >= DC::G ? DC::G - 1 : ck);
-          fine = fine * DC::G + ck;
-          coarse = coarse * DC::GC + ck / DC::RAT;
-        }
-      };
       constexpr int NP = (1 << DIM) + 1;
-      int cnt[NP], cc_idx = 0;
+      int cnt[NP];
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi) {
-        float x[DIM];
+        int fine = 0;
 #pragma unroll
-        for (int k = 0; k < DIM; ++k)
-          x[k] = pi == NP - 1 ? 0.5f * (blo[k] + bhi[k]) : (((pi >> k) & 1) ? bhi[k] : blo[k]);
-        int fi, ci;
-        cell_at(x, fi, ci);
-        if (pi == NP - 1) cc_idx = ci;
-        cnt[pi] = dg.grid[fi];
+        for (int k = DIM - 1; k >= 0; --k) {
+          const float xk = pi == NP - 1 ? 0.5f * (blo[k] + bhi[k]) : (((pi >> k) & 1) ? bhi[k] : blo[k]);
+          int ck = (int)((xk - glo[k]) * gsc[k]);
+          ck = ck < 0 ? 0 : (ck >= DC::G ? DC::G - 1 : ck);
+          fine = fine * DC::G + ck;
+        }
+        cnt[pi] = dg.grid[fine];
       }
-      const int coarse_cnt = dg.grid[DC::NF + cc_idx];
-      int sum = 0;
+      int sum = 0, mn = cnt[0];
 #pragma unroll
-      for (int pi = 0; pi < NP; ++pi) sum += cnt[pi];
-      float dens = (float)sum / ((float)NP * cell_vol);
-      if (sum < 8) {
-        float rv = 1.f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) rv *= (float)DC::RAT;
-        dens = (float)coarse_cnt / (cell_vol * rv);
+      for (int pi = 0; pi < NP; ++pi) {
+        sum += cnt[pi];
+        mn = cnt[pi] < mn ? cnt[pi] : mn;
       }
-      if (dens > 0.f) {
+      if (mn >= dg.min_count) {  // every probed cell is well filled
+        const float dens = (float)sum / ((float)NP * cell_vol);
         const float h = DIM == 3 ? cbrtf(1.f / dens) : __builtin_sqrtf(1.f / dens);
         c = alpha * h;
         const float est = dens * vol;
         n0 = est < 1.f ? 1 : (est > 1.0e9f ? 1000000000 : (int)est);
+        use_grid = true;
       }
     }
+    int n_leaves = (seeded || use_grid) ? 0 : gather();
+    PHASE(2);
+    bool give_up = n_leaves < 0;
+    if (give_up) ++g_gather0;
     if (!give_up && !seeded && !use_grid) {
       // (uniform trip count: every lane takes part in every ballot, so n0 stays wave-uniform)
       const int n_cand0 = n_leaves * LEAF;
@@ -1287,6 +1274,7 @@ struct CellOp {
                  FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       if (!g_cell_density_grid) dg = DensGrid{};
+      dg.min_count = g_cell_density_grid;
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
@@ -1402,23 +1390,6 @@ __global__ __launch_bounds__(256) void density_leaves_kernel(const float* __rest
   atomicAdd(&grid[fine], (int)(left < LEAF ? left : LEAF));
 }
 
-template <int DIM>
-__global__ __launch_bounds__(256) void density_coarse_kernel(int32_t* __restrict__ grid) {
-  typedef DensCfg<DIM> DC;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= DC::NCOARSE) return;
-  int cz = DIM == 3 ? c / (DC::GC * DC::GC) : 0;
-  int cy = (c / DC::GC) % DC::GC, cx = c % DC::GC;
-  int sum = 0;
-  for (int dz = 0; dz < (DIM == 3 ? DC::RAT : 1); ++dz)
-    for (int dy = 0; dy < DC::RAT; ++dy)
-      for (int dx = 0; dx < DC::RAT; ++dx) {
-        const int f = ((cz * DC::RAT + dz) * DC::G + (cy * DC::RAT + dy)) * DC::G + (cx * DC::RAT + dx);
-        sum += grid[f];
-      }
-  grid[DC::NF + c] = sum;
-}
-
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      float* plane_tab, const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
@@ -1497,8 +1468,8 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
 
 
 int64_t flooder_density_grid_words(int dim) {
-  if (dim == 2) return DensCfg<2>::NF + DensCfg<2>::NCOARSE;
-  if (dim == 3) return DensCfg<3>::NF + DensCfg<3>::NCOARSE;
+  if (dim == 2) return DensCfg<2>::NF;
+  if (dim == 3) return DensCfg<3>::NF;
   return 0;
 }
 
@@ -1511,11 +1482,9 @@ int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const f
   if (dim == 2) {
     hipLaunchKernelGGL((density_leaves_kernel<2>), dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, nodes, n_pts,
                        n_leaves, cloud_box, grid);
-    hipLaunchKernelGGL((density_coarse_kernel<2>), dim3((DensCfg<2>::NCOARSE + 255) / 256), dim3(256), 0, st, grid);
   } else {
     hipLaunchKernelGGL((density_leaves_kernel<3>), dim3((unsigned)((n_leaves + 255) / 256)), dim3(256), 0, st, nodes, n_pts,
                        n_leaves, cloud_box, grid);
-    hipLaunchKernelGGL((density_coarse_kernel<3>), dim3((DensCfg<3>::NCOARSE + 255) / 256), dim3(256), 0, st, grid);
   }
   return check_launch("density_grid");
 }

@@ -683,7 +683,7 @@ int flooder_set_option(const char* name, int value) {
     g_cell_super_n0 = value;
     return FLOODER_OK;
   }
-  if (name && strcmp(name, "cell_density_grid") == 0 && (value == 0 || value == 1)) {
+  if (name && strcmp(name, "cell_density_grid") == 0 && value >= 0) {
     g_cell_density_grid = value;
     return FLOODER_OK;
   }

@@ -233,9 +233,9 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
                                 int32_t* queue, uint32_t* out_d2, int budget, int32_t* list2,
                                 int32_t* count2, uint64_t* stats, void* stream);
 
-/* Density grid of the cloud for the cell sweep (dim 2 and 3): point counts in 64^3 (256^2) cells over the cloud's box
- * followed by a coarse level of 4^3 (8^2) fine cells each, accumulated from the leaves of the box tree (nodes: the
- * array of flooder_index_rows_f32, leaves first).  grid: flooder_density_grid_words(dim) int32, ZEROED. */
+/* Density grid of the cloud for the cell sweep (dim 2 and 3): point counts in 64^3 (256^2) cells over the cloud's
+ * box, accumulated from the leaves of the box tree (nodes: the array of flooder_index_rows_f32, leaves first).
+ * grid: flooder_density_grid_words(dim) int32, ZEROED. */
 int64_t flooder_density_grid_words(int dim);
 int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const float* cloud_box, int32_t* grid,
                              void* stream);
@@ -255,8 +255,9 @@ int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const f
  * plane_scratch: 24 * n_simplices floats of device scratch (the face planes of every simplex, computed once by a
  * small kernel instead of by each of its chunks).
  * density_grid / cloud_box (both NULL, or the grid of flooder_density_grid_f32 and the 16-float box of
- * flooder_bbox_f32): with them a chunk takes the local density from the grid cells under its box instead of
- * walking the tree and counting the points under it (option "cell_density_grid" 0 switches it off).
+ * flooder_bbox_f32): with them a chunk whose box lies over well filled cells (option "cell_density_grid": at least
+ * that many points in each, default 16; 0 = never) takes the local density from the grid instead of walking the tree
+ * and counting the points under its box.
  */
 int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                            const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
