@@ -44,7 +44,8 @@ SIGNATURES = {
     "flooder_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_bvh_node_count": (c_int64, [c_int64]),
     "flooder_bvh_build_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "flooder_index_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "flooder_index_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sample_key_bits": (c_int, [c_int]),

@@ -533,16 +533,15 @@ class PointIndex:
         self.pts = torch.empty((n_pad, self.dp), dtype=torch.float32, device=dev)
         n_nodes = int(lib.flooder_bvh_node_count(n))
         self.nodes = torch.empty((n_nodes, 2 * self.dp), dtype=torch.float32, device=dev)
+        # density grid for the cell sweep (2D / 3D): point counts per cell, accumulated from the leaf boxes in the same pass
+        self.dens = None
+        if dim in (2, 3) and CELL_DENSITY_GRID:
+            self.dens = torch.zeros(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
         with _span(timer, "bvh_build"):  # rows in curve order + leaf boxes in one pass, then the inner levels
             _native.check(lib.flooder_index_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
-                                                     _native.ptr(self.pts), n_pad, _native.ptr(self.nodes), st),
+                                                     _native.ptr(self.pts), n_pad, _native.ptr(self.nodes),
+                                                     _native.ptr(self.dens), _native.ptr(self.box), st),
                           "flooder_index_rows_f32")
-            # density grid for the cell sweep (2D / 3D): point counts per cell, from the leaf boxes
-            self.dens = None
-            if dim in (2, 3) and CELL_DENSITY_GRID:
-                self.dens = torch.zeros(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
-                _native.check(lib.flooder_density_grid_f32(_native.ptr(self.nodes), n, dim, _native.ptr(self.box),
-                                                           _native.ptr(self.dens), st), "flooder_density_grid_f32")
 
 
 def index_from_host(points_cpu: torch.Tensor, device, chunk_rows: int = 1 << 21):

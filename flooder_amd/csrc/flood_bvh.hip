@@ -214,7 +214,8 @@ template <int DIM>
 __global__ __launch_bounds__(256) void gather_leaf_kernel(const float* __restrict__ pts, int64_t n, int ld,
                                                           const uint32_t* __restrict__ order,
                                                           float* __restrict__ out, int64_t n_pad, int64_t n_rows_all,
-                                                          float* __restrict__ leaves) {
+                                                          float* __restrict__ leaves, int32_t* __restrict__ dens,
+                                                          const float* __restrict__ cbox, int dens_g) {
   constexpr int DP = padded_dim(DIM);
   static_assert(LEAF == 16, "one DPP row of 16 lanes per leaf");
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -256,6 +257,21 @@ __global__ __launch_bounds__(256) void gather_leaf_kernel(const float* __restric
       float* dst = leaves + (j / LEAF) * 2 * DP;
 #pragma unroll
       for (int k = 0; k < DP; ++k) { dst[k] = lo[k]; dst[DP + k] = hi[k]; }
+      // density grid of the cloud for the cell sweep (dens_g^DIM cells over the cloud's box): every leaf adds its
+      // point count to the cell under the centre of its box - a sixteenth of the atomics of a pass over the points
+      if (dens != nullptr && j < n) {
+        int cell = 0;
+#pragma unroll
+        for (int k = DIM - 1; k >= 0; --k) {
+          const float e = cbox[8 + k] - cbox[k];
+          const float sc = e > 0.f ? (float)dens_g / e : 0.f;
+          int ck = (int)((0.5f * (lo[k] + hi[k]) - cbox[k]) * sc);
+          ck = ck < 0 ? 0 : (ck >= dens_g ? dens_g - 1 : ck);
+          cell = cell * dens_g + ck;
+        }
+        const int64_t left = n - j;
+        atomicAdd(&dens[cell], (int)(left < LEAF ? left : LEAF));
+      }
     }
   }
 }
@@ -761,14 +777,16 @@ struct BuildOp {
 template <int DIM>
 struct IndexRowsOp {
   static int run(const float* pts, int64_t n, int ld, const uint32_t* order, float* rows, int64_t n_pad,
-                 const Levels& lv, float* nodes, hipStream_t st) {
+                 const Levels& lv, float* nodes, int32_t* dens, const float* cbox, hipStream_t st) {
     constexpr int DP = padded_dim(DIM);
     const int64_t pad0 = (lv.count[0] + FAN - 1) / FAN * FAN;  // leaves incl. the empty ones that fill the level
     const int64_t n_rows_all = pad0 * LEAF;
     int64_t blocks = (n_rows_all + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    const int dens_g = DIM == 2 ? 256 : (DIM == 3 ? 64 : 0);  // (flooder_density_grid_words: the cell sweep's dimensions)
+    if (dens_g == 0) dens = nullptr;
     hipLaunchKernelGGL((gather_leaf_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, order, rows, n_pad,
-                       n_rows_all, nodes + lv.off[0] * 2 * DP);
+                       n_rows_all, nodes + lv.off[0] * 2 * DP, dens, cbox, dens_g);
     for (int l = 1; l < lv.n_levels; ++l) {
       int64_t pad = (lv.count[l] + FAN - 1) / FAN * FAN;
       hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 3) / 4)), dim3(256), 0, st,
@@ -863,12 +881,12 @@ int flooder_curve_key_bits(int dim) {
 }
 
 int flooder_index_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* rows,
-                           int64_t n_pad, float* nodes, void* stream) {
-  if (!pts || !order || !rows || !nodes || n_pts < 1 || n_pad < n_pts || ld < dim)
+                           int64_t n_pad, float* nodes, int32_t* density_grid, const float* cloud_box, void* stream) {
+  if (!pts || !order || !rows || !nodes || n_pts < 1 || n_pad < n_pts || ld < dim || (density_grid && !cloud_box))
     return fail(FLOODER_E_ARG, "flooder_index_rows_f32: bad argument");
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<IndexRowsOp>(dim, pts, n_pts, ld, reinterpret_cast<const uint32_t*>(order), rows, n_pad, lv,
-                                   nodes, (hipStream_t)stream);
+                                   nodes, density_grid, cloud_box, (hipStream_t)stream);
 }
 
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream) {

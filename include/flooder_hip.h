@@ -192,9 +192,12 @@ int64_t flooder_bvh_node_count(int64_t n_pts);
 int flooder_bvh_build_f32(const float* pts_sorted, int64_t n_pts, int dim, float* nodes, void* stream);
 
 /* flooder_gather_rows_f32 + flooder_bvh_build_f32 in one call: the rows are written in curve order and the leaf boxes
- * are reduced from them while they are in registers (one pass over the cloud instead of two), then the inner levels. */
+ * are reduced from them while they are in registers (one pass over the cloud instead of two), then the inner levels.
+ * density_grid / cloud_box (both NULL, or flooder_density_grid_words(dim) ZEROED int32 and the 16-float box of
+ * flooder_bbox_f32; dim 2 and 3): the same pass accumulates the density grid the cell sweep reads its first cell size
+ * from (what flooder_density_grid_f32 computes from a finished tree). */
 int flooder_index_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* rows,
-                           int64_t n_pad, float* nodes, void* stream);
+                           int64_t n_pad, float* nodes, int32_t* density_grid, const float* cloud_box, void* stream);
 
 /* Sweep: out_d2[s, r] = bits(min over all points of |p(s,r) - x|^2) with p as in flooder_sweep_f32.
  * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or four
