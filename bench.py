@@ -448,15 +448,15 @@ def main():
         sh = stats.cpu().tolist()
         ks = 2 if R > 64 else 1
         sorted_tiles = core.bvh_sorts_samples(w["dim"], S, R)   # tiles of 64 consecutive samples of ALL simplices
-        per_tile = 64 if sorted_tiles else min(64 * ks, R)
+        per_tile = int(lib.flooder_sorted_tile_samples()) if sorted_tiles else min(64 * ks, R)
         per_kernel[sweep_span] = dict(pairs=sh[0] * 16 * per_tile, share=1.0)
-        n_tiles = (S * R + 63) // 64 if sorted_tiles else S * ((R + 64 * ks - 1) // (64 * ks))
+        n_tiles = (S * R + per_tile - 1) // per_tile if sorted_tiles else S * ((R + 64 * ks - 1) // (64 * ks))
         st_h = {"leaves_evaluated": sh[0], "leaves_tested": sh[1], "nodes_expanded": sh[2], "tiles_total": n_tiles,
                 "leaves_evaluated_per_tile": round(sh[0] / max(n_tiles, 1), 2),
                 "leaves_tested_per_tile": round(sh[1] / max(n_tiles, 1), 2),
                 "nodes_expanded_per_tile": round(sh[2] / max(n_tiles, 1), 2),
                 "max_tests_one_tile": sh[3], "samples_per_tile": per_tile, "lanes_per_tile": 64,
-                "tiles": "64 consecutive samples of a Z-order of all (simplex, sample) pairs" if sorted_tiles
+                "tiles": f"{per_tile} consecutive samples of a Z-order of all (simplex, sample) pairs" if sorted_tiles
                          else "samples of one simplex"}
     elif args.method == "cell":
         sh = stats.cpu().tolist()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "flooder_sweep_bvh_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sample_key_bits": (c_int, [c_int]),
+    "flooder_sorted_tile_samples": (c_int, []),
     "flooder_sample_keys_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_bvh_sorted_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

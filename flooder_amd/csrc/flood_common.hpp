@@ -28,6 +28,7 @@ extern int g_cell_super_n0;
 extern int g_cell_super_sparse;
 extern int g_cell_super_min_chunks;
 extern int g_cell_density_grid;  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
+extern int g_sorted_ks;
 extern int g_cell_tiles;   // 1: dense chunks hand their tiles to a third launch (one sample per lane) instead of the exhaustive loop (measured slower: off)
 extern int g_curve_bits;
 extern int g_cell_exh_tries;

@@ -687,6 +687,10 @@ int flooder_set_option(const char* name, int value) {
     g_cell_density_grid = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "sorted_ks") == 0 && (value == 1 || value == 2)) {
+    g_sorted_ks = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_tiles") == 0 && (value == 0 || value == 1)) {
     g_cell_tiles = value;
     return FLOODER_OK;

@@ -20,6 +20,8 @@
 
 using namespace flooder;
 
+namespace flooder { int g_sorted_ks = 1; }  // samples per lane of the sorted sweep (option "sorted_ks": 1 or 2)
+
 namespace {
 
 constexpr float SAFE = 0.99999f;
@@ -64,18 +66,20 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restric
   }
 }
 
-template <int DIM>
+template <int DIM, int KS>
 __global__ __launch_bounds__(256) void sweep_sorted_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_samples, const uint32_t* __restrict__ order, int32_t* __restrict__ queue,
     uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct) {
+  // KS samples per lane: a tile is 64 * KS consecutive samples of the sorted order (lane l holds l, l + 64, ...)
   constexpr int DP = padded_dim(DIM);
+  constexpr int TILE = 64 * KS;
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int64_t n_tiles = (n_samples + 63) >> 6;
+  const int64_t n_tiles = (n_samples + TILE - 1) / TILE;
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
 
@@ -85,31 +89,39 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
     const int64_t g = (int64_t)wave_uniform(g32);
     if (g >= n_tiles) break;
     const unsigned long long tests_before = n_leaf_test + n_node_test;
-    const int64_t pos = g * 64 + lane;
-    const bool live = pos < n_samples;
-    const uint32_t id = order[live ? pos : n_samples - 1];  // (dead lanes repeat the last sample, never stored)
-    const uint32_t s = id / (uint32_t)R;
-    const uint32_t r = id - s * (uint32_t)R;
-
-    // ---- this lane's sample: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
-    float p[DIM];
+    // ---- this lane's samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
+    float p[KS][DIM], best[KS];
+    uint32_t id[KS];
+    bool live[KS];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) p[k] = 0.f;
-    {
+    for (int i = 0; i < KS; ++i) {
+      const int64_t pos = g * TILE + i * 64 + lane;
+      live[i] = pos < n_samples;
+      id[i] = order[live[i] ? pos : n_samples - 1];  // (dead lanes repeat the last sample, never stored)
+      const uint32_t s = id[i] / (uint32_t)R;
+      const uint32_t r = id[i] - s * (uint32_t)R;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) p[i][k] = 0.f;
       const float* vs = verts + (int64_t)s * k1 * DIM;
       const float* ws = weights + (int64_t)r * k1;
       for (int j = 0; j < k1; ++j) {
         const float w = ws[j];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(w, vs[j * DIM + k], p[k]);
+        for (int k = 0; k < DIM; ++k) p[i][k] = __builtin_fmaf(w, vs[j * DIM + k], p[i][k]);
       }
+      best[i] = __builtin_inff();
     }
-    float best = __builtin_inff();
     float tlo[DIM], thi[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
-      tlo[k] = wave_min_f32(p[k]);
-      thi[k] = wave_max_f32(p[k]);
+      float mn = p[0][k], mx = p[0][k];
+#pragma unroll
+      for (int i = 1; i < KS; ++i) {
+        mn = __builtin_fminf(mn, p[i][k]);
+        mx = __builtin_fmaxf(mx, p[i][k]);
+      }
+      tlo[k] = wave_min_f32(mn);
+      thi[k] = wave_max_f32(mx);
     }
     float M = __builtin_inff();  // largest running minimum of the tile (wave-uniform)
 
@@ -167,24 +179,27 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
           lb0 = lb;
           grp0 = c;
           // ---- transposed refine: the 64 leaf boxes of the group (one per lane) against every sample of the tile
-          // (one lane's sample broadcast at a time); a leaf no sample can improve on is dropped here, in 1/64 of a
+          // (one lane's samples broadcast at a time); a leaf no sample can improve on is dropped here, in 1/64 of a
           // per-leaf test, before the nearest-first loop pops it.  Worth it when the per-leaf tests it replaces
-          // cost more than one pass over the 64 samples.
+          // cost more than one pass over the tile's samples.
           const bool cand = lb * SAFE < M;
-          constexpr int PER_LEAF = 4 * DIM + 40, PER_GROUP = 64 * (4 * DIM + 3);
+          constexpr int PER_LEAF = KS * 4 * DIM + 40, PER_GROUP = 64 * KS * (4 * DIM + 3);
           if ((int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 > (int64_t)PER_GROUP * refine_pct) {
             bool need = false;
 #pragma unroll 2
             for (int src = 0; src < 64; ++src) {
-              float lbp = 0.f;
 #pragma unroll
-              for (int k = 0; k < DIM; ++k) {
-                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[k]), src));
-                const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
-                lbp = __builtin_fmaf(gap, gap, lbp);
+              for (int i = 0; i < KS; ++i) {
+                float lbp = 0.f;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                  const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[i][k]), src));
+                  const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
+                  lbp = __builtin_fmaf(gap, gap, lbp);
+                }
+                const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best[i]), src));
+                need = need || (lbp * SAFE < bi);
               }
-              const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), src));
-              need = need || (lbp * SAFE < bi);
             }
             if (!(cand && need)) lb0 = __builtin_inff();
           }
@@ -201,20 +216,29 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       if (lane == j) lb0 = __builtin_inff();  // visited
       const int64_t c = grp0 * FAN + j;
       ++n_leaf_test;
-      // can any lane's sample still improve against leaf c?  (its box comes from lane j)
-      float lbp = 0.f;
+      // can any sample of any lane still improve against leaf c?  (its box comes from lane j)
+      float blo[DIM], bhi[DIM];
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
-        const float blo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
-        const float bhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
-        const float gap = __builtin_fmaxf(__builtin_fmaxf(blo - p[k], p[k] - bhi), 0.f);
-        lbp = __builtin_fmaf(gap, gap, lbp);
+        blo[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
+        bhi[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
       }
-      if (__ballot(lbp * SAFE < best) == 0ull) continue;
+      bool need = false;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        float lbp = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[i][k], p[i][k] - bhi[k]), 0.f);
+          lbp = __builtin_fmaf(gap, gap, lbp);
+        }
+        need = need || (lbp * SAFE < best[i]);
+      }
+      if (__ballot(need) == 0ull) continue;
       ++n_leaf_eval;
       const float* cp = pts + c * (int64_t)LEAF * DP;
       // rows stream through SGPRs (scalar loads), UB at a time: 8 rows of 8 floats would need 64 SGPRs on top of the
-      // traversal's own and spill into VGPRs (110 VGPRs = 4 waves per SIMD in 6D); 4 rows keep the kernel at 8 waves
+      // traversal's own; 4 rows keep the spills away
       constexpr int UB = DP == 8 ? 4 : 8;
 #pragma unroll
       for (int h = 0; h < LEAF; h += UB) {
@@ -223,25 +247,33 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
         for (int u = 0; u < UB; ++u) cc[u] = load_uniform_row<DP>(cp + (h + u) * DP);
 #pragma unroll
         for (int u = 0; u < UB; u += 2) {
-          float da, db;
 #pragma unroll
-          for (int k = 0; k < DIM; ++k) {
-            const float ta = p[k] - cc[u][k];
-            const float tb = p[k] - cc[u + 1][k];
-            if (k == 0) {
-              da = ta * ta;
-              db = tb * tb;
-            } else {
-              da = __builtin_fmaf(ta, ta, da);
-              db = __builtin_fmaf(tb, tb, db);
+          for (int i = 0; i < KS; ++i) {
+            float da, db;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float ta = p[i][k] - cc[u][k];
+              const float tb = p[i][k] - cc[u + 1][k];
+              if (k == 0) {
+                da = ta * ta;
+                db = tb * tb;
+              } else {
+                da = __builtin_fmaf(ta, ta, da);
+                db = __builtin_fmaf(tb, tb, db);
+              }
             }
+            best[i] = __builtin_fminf(best[i], __builtin_fminf(da, db));
           }
-          best = __builtin_fminf(best, __builtin_fminf(da, db));
         }
       }
-      M = wave_max_f32(best);
+      float bm = best[0];
+#pragma unroll
+      for (int i = 1; i < KS; ++i) bm = __builtin_fmaxf(bm, best[i]);
+      M = wave_max_f32(bm);
     }
-    if (live) out_d2[id] = __float_as_uint(best);
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+      if (live[i]) out_d2[id[i]] = __float_as_uint(best[i]);
     const unsigned long long item_tests = n_leaf_test + n_node_test - tests_before;
     max_item_tests = item_tests > max_item_tests ? item_tests : max_item_tests;
   }
@@ -267,28 +299,37 @@ struct SampleKeysOp {
 
 template <int DIM>
 struct SweepSortedOp {
-  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
-                 int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
-                 unsigned long long* stats, hipStream_t st) {
-    // persistent blocks of 4 independent waves, as many as the registers let a CU hold (asked once per dimension)
+  template <int KS>
+  static int launch(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
+                    int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
+                    unsigned long long* stats, hipStream_t st) {
+    // persistent blocks of 4 independent waves, as many as the registers let a CU hold (asked once per instantiation)
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM, KS>, 256, 0) != hipSuccess || nb < 1) nb = 4;
       blocks_per_cu = nb > 8 ? 8 : nb;
     }
-    const int64_t n_tiles = (n_samples + 63) / 64;
+    const int64_t n_tiles = (n_samples + 64 * KS - 1) / (64 * KS);
     int64_t grid = (int64_t)blocks_per_cu * 256;
     if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
-    hipLaunchKernelGGL((sweep_sorted_kernel<DIM>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts, weights,
-                       k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct);
+    hipLaunchKernelGGL((sweep_sorted_kernel<DIM, KS>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                       weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct);
     return check_launch("sweep_sorted");
+  }
+  static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
+                 int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
+                 unsigned long long* stats, hipStream_t st) {
+    if (g_sorted_ks == 2) return launch<2>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, st);
+    return launch<1>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, st);
   }
 };
 
 }  // namespace
 
 extern "C" {
+
+int flooder_sorted_tile_samples(void) { return 64 * (g_sorted_ks == 2 ? 2 : 1); }
 
 int flooder_sample_key_bits(int dim) {
   if (dim < 1 || dim > FLOODER_MAX_DIM) return 0;

@@ -217,6 +217,7 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
  *   flooder_sweep_bvh_sorted_f32   the sweep; queue = one zeroed int32; stats as flooder_sweep_bvh_f32.
  * Replaces compute_mask + nonzero + compute_filtration (core.py:210-226) like the other sweeps. */
 int flooder_sample_key_bits(int dim);
+int flooder_sorted_tile_samples(void);   /* samples per tile of the sorted sweep (64 x option "sorted_ks") */
 int flooder_sample_keys_f32(const float* verts, const float* weights, int k1, int R, int64_t n_simplices, int dim,
                             const float* box, uint32_t* keys, void* stream);
 int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,

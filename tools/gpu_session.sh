@@ -23,7 +23,7 @@ for s in $STEPS; do
             python - $OUT/ranks2_${wl}_${sh}.json "$wl $sh" <<'PY'
 import json, sys
 try:
-    d = json.load(open(sys.argv[1]))
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])   # (gloo prints its own lines on stdout)
     print("2 ranks / 1 GPU", sys.argv[2], d["config"]["parallelism"], "ms/step", d["ms_per_step"], {k: v["ms_per_step"] for k, v in d["kernels"].items()})
 except Exception as e:
     print(sys.argv[2], "FAILED", e, open(sys.argv[1].replace(".json", ".err")).read()[-800:])
