@@ -30,7 +30,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restrict__ verts,
                                                           const float* __restrict__ weights, int k1, int R,
                                                           int64_t n_samples, const float* __restrict__ dbox,
-                                                          uint32_t* __restrict__ keys) {
+                                                          uint32_t* __restrict__ keys, int hilbert) {
   constexpr int BITS = 32 / DIM > 10 ? 10 : 32 / DIM;
   float lo[DIM], scale[DIM];
 #pragma unroll
@@ -51,16 +51,49 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(w, verts[(s * k1 + j) * DIM + k], p[k]);
     }
-    uint32_t code = 0u;
+    uint32_t q[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
       float t = (p[k] - lo[k]) * scale[k];
       t = t < 0.f ? 0.f : t;  // (samples of landmarks off the cloud may leave the box: clamped, order only)
       const float top = (float)((1u << BITS) - 1u);
       t = t > top ? top : t;
-      const uint32_t q = (uint32_t)t;
+      q[k] = (uint32_t)t;
+    }
+    uint32_t code = 0u;
+    if (hilbert && DIM > 1) {
+      // Hilbert index (Skilling's axes-to-transpose transform, as morton_kernel does for the cloud): consecutive
+      // keys are neighbours in space - a Z-order jumps across the box at every power-of-two boundary, and a tile that
+      // straddles a jump has a box as large as the jump
+      const uint32_t MTOP = 1u << (BITS - 1);
+      for (uint32_t Q = MTOP; Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
 #pragma unroll
-      for (int b = 0; b < BITS; ++b) code |= ((q >> b) & 1u) << (b * DIM + k);
+        for (int k = 0; k < DIM; ++k) {
+          if (q[k] & Q) {
+            q[0] ^= P;
+          } else {
+            const uint32_t t = (q[0] ^ q[k]) & P;
+            q[0] ^= t;
+            q[k] ^= t;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 1; k < DIM; ++k) q[k] ^= q[k - 1];
+      uint32_t t = 0u;
+      for (uint32_t Q = MTOP; Q > 1u; Q >>= 1)
+        if (q[DIM - 1] & Q) t ^= Q - 1u;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) q[k] ^= t;
+      for (int b = BITS - 1; b >= 0; --b)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) code = (code << 1) | ((q[k] >> b) & 1u);
+    } else {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) code |= ((q[k] >> b) & 1u) << (b * DIM + k);
     }
     keys[i] = code;
   }
@@ -292,7 +325,7 @@ struct SampleKeysOp {
     int64_t blocks = (n_samples + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((sample_keys_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, verts, weights, k1, R,
-                       n_samples, box, keys);
+                       n_samples, box, keys, g_curve);
     return check_launch("sample_keys");
   }
 };
