@@ -214,3 +214,47 @@ def test_batched_fps_hard_cases_equal_brute_force(dev, case, monkeypatch):
     if P.shape[1] <= 3:  # the one-landmark-per-launch kernels stay selectable
         monkeypatch.setattr(core, "FPS_BATCHED", False)
         assert np.array_equal(a, core.fps_indices(tp, k, start, method="bucket").cpu().numpy())
+
+
+def test_method_switch_and_byte_offset_bound_at_2_28_points(dev):
+    """The cell sweep addresses the cloud with 32-bit BYTE offsets (16-byte rows: below 2^28 - 16 points) and
+    ``method="auto"`` switches to the tree sweep at N >= 2^28 - 64 (``core.py`` flood_complex).  A 3.2 GB cloud on
+    both sides of the switch: the last size "auto" gives to the cell sweep, the first it gives to the tree sweep (the
+    cell sweep still accepts it when asked: byte offsets up to 4 GiB - 1 KiB), and 2^28 points, which the cell sweep
+    must refuse.  The landmarks sit in the corner of the cube with the largest coordinates, so the rows their
+    neighbourhoods need are among the last of the curve order.  cell == tree sweep bit for bit; the longest edge
+    against a brute-force minimum over all points in float64."""
+    n_all = 1 << 28
+    n_cell, n_tree = n_all - 80, n_all - 64
+    g = torch.Generator(device=dev).manual_seed(7)
+    pts = torch.rand((n_all, 3), generator=g, device=dev, dtype=torch.float32)
+    lms = torch.tensor([[0.9990 + 0.0008 * ((i >> 0) & 1), 0.9990 + 0.0008 * ((i >> 1) & 1), 0.9990 + 0.0008 * ((i >> 2) & 1)]
+                        for i in range(8)], dtype=torch.float32, device=dev)
+    pts[:8] = lms
+    lib = _native.load()
+    for n in (n_cell, n_tree):
+        cloud = pts[:n]
+        index = core.PointIndex(cloud)
+        auto = fa.flood_complex(cloud, lms, points_per_edge=6, return_simplex_tree=True, index=index)
+        other = fa.flood_complex(cloud, lms, points_per_edge=6, method="bvh" if n == n_cell else "cell",
+                                 return_simplex_tree=True, index=index)
+        for d in (1, 2, 3):
+            assert np.array_equal(auto.filtrations_of_dimension(d), other.filtrations_of_dimension(d)), (n, d)
+        e = auto.simplices_of_dimension(1)
+        ev = auto.filtrations_of_dimension(1)
+        j = int(np.argmax(ev))
+        w = torch.linspace(0, 1, 6, device=dev, dtype=torch.float64)
+        a, b = lms[int(e[j, 0])].double(), lms[int(e[j, 1])].double()
+        samples = ((1 - w)[:, None] * a[None] + w[:, None] * b[None]).float().double()
+        best = torch.full((6,), float("inf"), device=dev, dtype=torch.float64)
+        for c0 in range(0, n, 1 << 23):
+            blk = cloud[c0:c0 + (1 << 23)].to(torch.float64)
+            d2 = ((blk[None, :, :] - samples[:, None, :]) ** 2).sum(-1)
+            best = torch.minimum(best, d2.min(dim=1).values)
+        ref = float(best.max().sqrt())
+        assert abs(ev[j] - ref) <= 2e-5 * ref + 5e-7, (n, ev[j], ref)   # (the sample coordinates are rebuilt in float32 on the device)
+        del index
+    with pytest.raises(RuntimeError, match="too large"):
+        fa.flood_complex(pts, lms, points_per_edge=6, method="cell")
+    del pts
+    torch.cuda.empty_cache()
