@@ -50,6 +50,7 @@ CAND_ALIGN = 8
 SWEEP_CHUNK = 2048
 TILE_SAMPLES = 512
 BVH_LEAF = 16
+QUEUE_WORDS = 512   # FLOODER_QUEUE_WORDS: zeroed int32 words of one sharded work queue
 # device sweep: "cell" = per-simplex LDS cell grid + exact tree finish (default in 2D/3D); "bvh" = box-tree
 # culled exact nearest neighbour (default in other dimensions); "ball" = the reference's formulation
 # (bounding-ball candidate lists + exhaustive sweep of each list)
@@ -740,7 +741,7 @@ def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: t
     inv[order] = torch.arange(R, device=dev)
     rows_perm = inv[faces.rows.long()].to(torch.int32).contiguous()
     d2 = torch.empty((S, R), dtype=torch.int64, device=dev)
-    queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    queue = torch.zeros(QUEUE_WORDS, dtype=torch.int32, device=dev)   # sharded work-queue heads
     with _span(timer, "sweep"):
         _native.check(lib.flooder_sweep_bvh_f64(_native.ptr(pts64_sorted), index.n, index.dim, _native.ptr(index.nodes),
                                                 _native.ptr(verts), _native.ptr(w_perm), k1, R, S, _native.ptr(queue),
@@ -785,7 +786,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     w_perm, rows_perm = plan.w_perm, plan.rows_perm
 
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
-    queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    queue = torch.zeros(QUEUE_WORDS, dtype=torch.int32, device=dev)   # sharded work-queue heads
     sorted_samples = bvh_sorts_samples(index.dim, S, R)
     with _span(timer, "sweep"):
         if sorted_samples:
@@ -893,7 +894,11 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # lists on; [24:48] finish (queue heads, [27] top count, [29], [31] hard tiles of the top / rest pass);
         # [48:] histogram of the flagged tiles' bounds and the cursors of the finish's counting sort
         # (one zero fill for everything that starts at zero: top | ctl | face_bits)
-        zeroed = torch.zeros(2 * S + 48 + 8192 + n_slots, dtype=torch.int32, device=dev)
+        # (the sharded work-queue heads of the sweep's launches sit in front: QUEUE_WORDS each)
+        zeroed = torch.zeros(6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots, dtype=torch.int32, device=dev)
+        qbuf = zeroed[:3 * QUEUE_WORDS]
+        fctl = zeroed[3 * QUEUE_WORDS:6 * QUEUE_WORDS + 24]   # finish: 24 control words, then its sharded queue heads
+        zeroed = zeroed[6 * QUEUE_WORDS + 24:]
         top = zeroed[:2 * S].view(torch.int64)
         ctl = zeroed[2 * S:2 * S + 48 + 8192]
         face_bits = zeroed[2 * S + 48 + 8192:]
@@ -914,11 +919,11 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         with _span(timer, "sweep"):
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2),
+                _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
                 ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
                 ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
-                ctl[27:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
+                fctl[3:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
                 ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
                 _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(index.dens),
                 _native.ptr(index.box), _native.ptr(sub(0, 9)), st),
@@ -928,14 +933,14 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, _native.ptr(flags[0]), ctl[1:].data_ptr(),
                 _native.ptr(flags[1]) if CELL_PROBE else None, ctl[48:].data_ptr() if CELL_PROBE else None,
-                _native.ptr(flags[2]) if CELL_PROBE else None, ctl[24:].data_ptr(),
+                _native.ptr(flags[2]) if CELL_PROBE else None, fctl.data_ptr(),
                 _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
                 _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(hard),
                 FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
             LAST_STATS.dense_tiles = int(ctl[18].item())
-            c_h = ctl[24:48].tolist()
+            c_h = fctl[:24].tolist()
             LAST_STATS.hard_entries = (int(c_h[5]), int(c_h[7]))
         out_face = torch.empty(n_slots if face_slots is not None else (S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
@@ -943,19 +948,21 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                           "flooder_face_values_f32")
         return out_face, None
 
-    ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # work-queue heads + flag counter
+    ctl = torch.zeros(8 + 4 * QUEUE_WORDS, dtype=torch.int32, device=dev)  # flag counter, list length | queue heads
+    qbuf = ctl[8:8 + 3 * QUEUE_WORDS]
+    q_items = ctl[8 + 3 * QUEUE_WORDS:]
     d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     flags = torch.empty(S * ((R + 63) // 64), dtype=torch.int32, device=dev)
     with _span(timer, "sweep"):
         _native.check(lib.flooder_sweep_cell_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-            _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), ctl.data_ptr(), _native.ptr(d2), _native.ptr(flags),
+            _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2), _native.ptr(flags),
             ctl[1:].data_ptr(), _native.ptr(planes), _native.ptr(index.dens), _native.ptr(index.box),
             _native.ptr(sub(0, 9)), st), "flooder_sweep_cell_f32")
     with _span(timer, "fallback"):
         _native.check(lib.flooder_sweep_bvh_items_f32(
             _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-            _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), ctl[2:].data_ptr(),
+            _native.ptr(w_perm), k1, R, S, _native.ptr(flags), ctl[1:].data_ptr(), q_items.data_ptr(),
             _native.ptr(d2), 0, None, None, _native.ptr(sub(9, 13)), st), "flooder_sweep_bvh_items_f32")
 
     if reduce_hook is not None:

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
   const bool static_deal = item_list && n_items <= (int64_t)gridDim.x * 4;
   bool dealt = false;
+  int q_shard = (int)(wave_id % QSHARDS), q_tried = 0;
   for (;;) {
     int64_t g;
     if (static_deal) {
@@ -364,10 +365,8 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
       dealt = true;
       g = wave_id;
     } else {
-      int g32 = 0;
-      if (lane == 0) g32 = atomicAdd(queue, 1);
-      g = (int64_t)wave_uniform(g32);
-      if (g >= n_items) break;
+      g = queue_pop(queue, q_shard, q_tried, n_items, lane);  // sharded heads (flood_common.hpp)
+      if (g < 0) break;
     }
     int sub = 0;
     if (item_list) {  // explicit (simplex, tile) work list

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
   const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+  int q_shard = (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;  // sharded work queue (flood_common.hpp)
   for (;;) {
     PHASE_T0();
 #ifdef FLOODER_PHASE_TIMERS
@@ -305,10 +306,8 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     unsigned long long t_phase0[12];
     for (int i = 0; i < 12; ++i) t_phase0[i] = t_phase[i];
 #endif
-    int g32 = 0;
-    if (lane == 0) g32 = atomicAdd(queue, 1);
-    const int64_t g = (int64_t)wave_uniform(g32);
-    if (g >= n_items) break;
+    const int64_t g = queue_pop(queue, q_shard, q_tried, n_items, lane);
+    if (g < 0) break;
     int64_t s;
     int q;            // current chunk of the simplex
     int n_sub = 1;    // chunks of this work item
@@ -1462,7 +1461,7 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot, flag_key, flag_hist},
-                          dl, defer_list ? defer_ctl + 1 : nullptr, defer_list ? defer_ctl + 7 : nullptr, dg,
+                          dl, queue + FLOODER_QUEUE_WORDS, queue + 2 * FLOODER_QUEUE_WORDS, dg,
                           stream, "flooder_sweep_cell_faces_f32: bad argument");
 }
 

@@ -89,6 +89,25 @@ __device__ __forceinline__ typename RowVec<DP>::type load_uniform_row(const floa
   return *((cptr_t)(uintptr_t)p);
 }
 
+// ---- sharded work queue of the persistent kernels.  One returning atomic on ONE head word serves ~88 pops per
+// microsecond chip-wide (MI355X_MICROARCH.md, "dequeue") - half a million chunks of a cfg 5 sweep would spend 5.7 ms
+// just queueing for it.  FLOODER_QUEUE_SHARDS heads, 128 B apart; item i lives in shard i % SHARDS (every shard keeps
+// the global order); a wave starts at its home shard and moves on, for good, when a shard is exhausted.
+constexpr int QSHARDS = FLOODER_QUEUE_SHARDS;
+constexpr int QSTRIDE = FLOODER_QUEUE_WORDS / FLOODER_QUEUE_SHARDS;
+__device__ __forceinline__ int64_t queue_pop(int32_t* __restrict__ heads, int& shard, int& tried, int64_t n_items, int lane) {
+  while (tried < QSHARDS) {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(&heads[shard * QSTRIDE], 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    const int64_t item = (int64_t)j * QSHARDS + shard;
+    if (item < n_items) return item;
+    shard = shard + 1 == QSHARDS ? 0 : shard + 1;
+    ++tried;
+  }
+  return -1;
+}
+
 // ---- 64-lane reductions on the DPP network (no LDS): result is wave-uniform.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float x) {

@@ -53,11 +53,10 @@ __global__ __launch_bounds__(256) void sweep_bvh_f64_kernel(
   const int64_t n_items = n_simplices * tiles;
   const int top = lv.n_levels - 1;
   const double INF = __builtin_inf();
+  int q_shard = (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) % QSHARDS), q_tried = 0;
   for (;;) {
-    int g32 = 0;
-    if (lane == 0) g32 = atomicAdd(queue, 1);
-    const int64_t g = (int64_t)wave_uniform(g32);
-    if (g >= n_items) break;
+    const int64_t g = queue_pop(queue, q_shard, q_tried, n_items, lane);  // sharded heads (flood_common.hpp)
+    if (g < 0) break;
     const int64_t s = g / tiles;
     const int tile = (int)(g - s * tiles);
     int r = tile * 64 + lane;

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
 #endif
   const bool static_deal = !TEAM && n_items <= (int64_t)gridDim.x * 4;
   bool dealt = false;
+  int q_shard = (int)(wave_id % QSHARDS), q_tried = 0;
   for (;;) {
 #ifdef FLOODER_WAVE_END_FIN
     if (t_item) {
@@ -170,10 +171,8 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
       dealt = true;
       g = wave_id;
     } else {
-      int g32 = 0;
-      if (lane == 0) g32 = atomicAdd(queue, 1);
-      g = (int64_t)wave_uniform(g32);
-      if (g >= n_items) break;
+      g = queue_pop(queue, q_shard, q_tried, n_items, lane);  // sharded heads (flood_common.hpp)
+      if (g < 0) break;
     }
     FIN_PHASE(5);  // (queue pop, bookkeeping)
 #ifdef FLOODER_WAVE_END_FIN
@@ -692,10 +691,14 @@ struct FinishOp {
                            queue, d2, acc, top, top_list, ctl + 3, hl, stats);
     };
     const HardLists none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hard_cap, 0};
-    if (!probed) launch(0, ctl + 0, none);
+    // (the per-wave passes pop from sharded heads behind the 24 control words; the team passes keep one word)
+    int32_t* q0 = ctl + 24;
+    int32_t* q1 = ctl + 24 + FLOODER_QUEUE_WORDS;
+    int32_t* q2 = ctl + 24 + 2 * FLOODER_QUEUE_WORDS;
+    if (!probed) launch(0, q0, none);
     if (!hard_on) {
-      if (g_finish_top) launch(1, ctl + 1, none);
-      launch(2, ctl + 2, none);
+      if (g_finish_top) launch(1, q1, none);
+      launch(2, q2, none);
       return check_launch("finish_faces");
     }
     // ctl: [0..2] queue heads of the probe / top / rest passes, [3] simplices with a top tile, [4], [5] queue head
@@ -704,12 +707,12 @@ struct FinishOp {
     a.budget = c.budget = g_finish_budget;
     if (g_finish_top) {
       list(0, false, ctl + 5, a);  // top pass: hard entries -> list 0
-      launch(1, ctl + 1, a);
+      launch(1, q1, a);
       list(0, true, ctl + 5, b);   // ... one workgroup each (one sample per entry: one round)
       launch(3, ctl + 4, b);
     }
     list(1, false, ctl + 7, c);  // the other samples: hard tiles -> list 1
-    launch(2, ctl + 2, c);
+    launch(2, q2, c);
     list(1, true, ctl + 7, d);   // ... one workgroup each, all their rounds
     launch(3, ctl + 6, d);
     return check_launch("finish_faces");

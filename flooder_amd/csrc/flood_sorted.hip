@@ -116,11 +116,10 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
 
+  int q_shard = (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;
   for (;;) {
-    int g32 = 0;
-    if (lane == 0) g32 = atomicAdd(queue, 1);
-    const int64_t g = (int64_t)wave_uniform(g32);
-    if (g >= n_tiles) break;
+    const int64_t g = queue_pop(queue, q_shard, q_tried, n_tiles, lane);  // sharded heads (flood_common.hpp)
+    if (g < 0) break;
     const unsigned long long tests_before = n_leaf_test + n_node_test;
     // ---- this lane's samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
     float p[KS][DIM], best[KS];

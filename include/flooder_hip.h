@@ -41,6 +41,8 @@ extern "C" {
 #define FLOODER_BVH_LEAF 16      /* points per leaf of the point hierarchy            */
 #define FLOODER_BVH_FANOUT 64    /* children per inner node (one per lane)            */
 #define FLOODER_BVH_MAX_LEVELS 6 /* 16 * 64^5 points                                  */
+#define FLOODER_QUEUE_SHARDS 16    /* heads of a sharded work queue ...                        */
+#define FLOODER_QUEUE_WORDS 512    /* ... and the zeroed int32 words one queue takes (heads 128 B apart) */
 #define FLOODER_BBOX_BLOCKS 1024  /* partial results of flooder_bbox_f32               */
 
 int flooder_abi_version(void);
@@ -200,7 +202,8 @@ int flooder_index_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, con
                            int64_t n_pad, float* nodes, int32_t* density_grid, const float* cloud_box, void* stream);
 
 /* Sweep: out_d2[s, r] = bits(min over all points of |p(s,r) - x|^2) with p as in flooder_sweep_f32.
- * Plain stores (every cell is written exactly once); queue = one zeroed int32; stats = NULL or four
+ * Plain stores (every cell is written exactly once); queue = FLOODER_QUEUE_WORDS zeroed int32 (sharded heads, see
+ * flooder_sweep_cell_f32); stats = NULL or four
  * zeroed uint64 counters {leaves evaluated, leaves tested, inner nodes expanded, most tests by one item}. */
 int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
                           const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
@@ -214,7 +217,7 @@ int flooder_sweep_bvh_f32(const float* pts_sorted, int64_t n_pts, int dim, const
  *   flooder_sample_keys_f32        keys[s * R + r] = Morton code of sample (s, r) inside box (16 floats, [0:dim] = min,
  *                                  [8:8+dim] = max: the cloud's box from flooder_bbox_f32); n_simplices * R < 2^32 - 1
  *   (sort)                         flooder_index_sort(keys, n_simplices * R, key bits, ...) -> sample_order
- *   flooder_sweep_bvh_sorted_f32   the sweep; queue = one zeroed int32; stats as flooder_sweep_bvh_f32.
+ *   flooder_sweep_bvh_sorted_f32   the sweep; queue = FLOODER_QUEUE_WORDS zeroed int32; stats as flooder_sweep_bvh_f32.
  * Replaces compute_mask + nonzero + compute_filtration (core.py:210-226) like the other sweeps. */
 int flooder_sample_key_bits(int dim);
 int flooder_sorted_tile_samples(void);   /* samples per tile of the sorted sweep (64 x option "sorted_ks") */
@@ -253,7 +256,9 @@ int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const f
  * of 64 samples that stay unverified or do not fit the LDS stage are appended to flag_list
  * (n_simplices * ceil(R/64) int32; *flag_count zeroed by the caller) for flooder_sweep_bvh_items_f32,
  * which finishes them exactly.  alpha > 0 only trades speed (1.35 is a good value), never correctness.
- * queue: one zeroed int32.  stats: NULL or nine zeroed uint64 {pairs evaluated, points staged, tiles
+ * queue: 3 x FLOODER_QUEUE_WORDS zeroed int32 (the sharded work-queue heads of up to three launches: one returning
+ * atomic on a single head word serves ~88 pops per microsecond chip-wide - half a million chunks would queue for
+ * 5.7 ms - so a queue has FLOODER_QUEUE_SHARDS heads 128 B apart).  stats: NULL or nine zeroed uint64 {pairs evaluated, points staged, tiles
  * flagged, re-staging rounds, chunks given up: tree gather overflow at density / at staging, kept list
  * full, cell doublings exhausted; rounds evaluated exhaustively because the LDS stage was full}.
  * plane_scratch: 24 * n_simplices floats of device scratch (the face planes of every simplex, computed once by a
@@ -317,7 +322,8 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * descent per tile: finite upper bounds, and per simplex the tile with the largest one; skipped when the cell sweep
  * did it), optionally ("finish_top" 1) the top tile of every simplex, then all tiles, largest bound first.  Face
  * values equal the exhaustive result bit for bit.
- *   ctl: 8 zeroed int32 (queue heads and list lengths; ctl[3] = number of entries of top_list, which the cell
+ *   ctl: 24 + 3 * FLOODER_QUEUE_WORDS zeroed int32 (list lengths and the team passes' queue heads, then the sharded
+ *   queue heads of the per-wave passes; ctl[3] = number of entries of top_list, which the cell
  *   sweep's probe may already have filled: then probed = 1 and the probe pass is skipped); top: n_simplices uint64
  *   (zeroed unless probed); top_list: n_simplices int32;
  *   flag_key / flag_hist / flag_sorted: all NULL, or what flooder_sweep_cell_faces_f32 filled plus scratch of the
@@ -373,7 +379,7 @@ int flooder_fps_f32(const float* pts, int64_t n_pts, int dim, int ld, int n_lms,
  * boxes are widened by one float32 ulp per side inside the kernel and every bound and distance is evaluated in double.
  *   flooder_gather_rows_f64: as flooder_gather_rows_f32 for double rows (padding rows +inf, padding columns 0);
  *   flooder_sweep_bvh_f64:   out_d2[s, r] = bit pattern of the double min over all points of |p(s, r) - x|^2
- *                            (non-negative doubles order like unsigned 64-bit integers); queue: one zeroed int32;
+ *                            (non-negative doubles order like unsigned 64-bit integers); queue: FLOODER_QUEUE_WORDS zeroed int32;
  *   flooder_face_max_f64:    face maxima + sqrt in double (layout as flooder_face_max_f32).
  */
 int flooder_gather_rows_f64(const double* pts, int64_t n_pts, int dim, int ld, const int32_t* order, double* out,
