@@ -621,6 +621,10 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       // atomic per face present in the chunk: interior chunks touch one face); the (S, R) buffer is only
       // written for the tiles the finish has to look at (bit 31 = already settled)
       uint32_t mb[SPL], um = 0u;
+      bool fl_on[SPL];
+      uint32_t fl_key[SPL];
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) { fl_on[i] = false; fl_key[i] = 0u; }
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         const bool settled = (q * CHUNK + i * 64 + lane < n_live) && !open[i];
@@ -706,15 +710,43 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           }
           if (q * CHUNK + i * 64 + lane < n_live)
             out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]) | (open[i] ? 0u : SETTLED_BIT);
-          if (lane == 0) {
-            const int pos = atomicAdd(flag_count, 1);
-            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
-            if (acc.flag_key) {
-              acc.flag_key[pos] = tile_key;
-              atomicAdd(&acc.flag_hist[tile_key >> 19], 1);
-            }
-          }
+          fl_on[i] = true;      // (appended below: one reservation for the chunk's tiles, not one atomic each)
+          fl_key[i] = tile_key;
           ++n_flagged;
+        }
+      }
+      // the flag list's one counter word takes every append of the launch: a returning atomic per flagged tile
+      // (138 k at cfg 3) queues on it at ~11 ns each - reserve the chunk's entries together, and count equal
+      // histogram bins once
+      int nf = 0;
+#pragma unroll
+      for (int i = 0; i < SPL; ++i) nf += fl_on[i] ? 1 : 0;
+      if (nf > 0) {  // (wave-uniform)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(flag_count, nf);
+        base = wave_uniform(base);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          if (fl_on[i]) {
+            if (lane == 0) {
+              flag_list[base + k] = (int)(s * tiles64 + q * SPL + i);
+              if (acc.flag_key) {
+                acc.flag_key[base + k] = fl_key[i];
+                bool first = true;
+                int same = 0;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                  if (fl_on[j] && (fl_key[j] >> 19) == (fl_key[i] >> 19)) {
+                    if (j < i) first = false;
+                    ++same;
+                  }
+                }
+                if (first) atomicAdd(&acc.flag_hist[fl_key[i] >> 19], same);
+              }
+            }
+            ++k;
+          }
         }
       }
     } else {
