@@ -96,6 +96,10 @@ __device__ __forceinline__ typename RowVec<DP>::type load_uniform_row(const floa
 constexpr int QSHARDS = FLOODER_QUEUE_SHARDS;
 constexpr int QSTRIDE = FLOODER_QUEUE_WORDS / FLOODER_QUEUE_SHARDS;
 __device__ __forceinline__ int64_t queue_pop(int32_t* __restrict__ heads, int& shard, int& tried, int64_t n_items, int lane) {
+  // (shard and tried are wave-uniform by construction; say so, or they cost vector registers in kernels that sit at
+  // their register limit: the cell sweep went from 0 to 21 spilled VGPRs = 91 MB of scratch writes per launch)
+  shard = __builtin_amdgcn_readfirstlane(shard);
+  tried = __builtin_amdgcn_readfirstlane(tried);
   while (tried < QSHARDS) {
     int j = 0;
     if (lane == 0) j = atomicAdd(&heads[shard * QSTRIDE], 1);

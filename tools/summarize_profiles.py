@@ -15,13 +15,17 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 name = sys.argv[2] if len(sys.argv) > 2 else f"r3_{tag}"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
-shutil.copy(stats, f"profiles/{name}_kernel_stats.csv")
+FROM_PMC = "--from-pmc" in sys.argv   # recompute traffic.json from the committed summaries (no raw profiler output)
 avg_ns = {}
-for row in csv.DictReader(open(stats)):
-    avg_ns[row["Name"]] = float(row["AverageNs"])
 out = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+if FROM_PMC:
+    out = json.load(open(f"profiles/{name}_pmc.json"))
+else:
+    stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+    shutil.copy(stats, f"profiles/{name}_kernel_stats.csv")
+    for row in csv.DictReader(open(stats)):
+        avg_ns[row["Name"]] = float(row["AverageNs"])
+for sub in (() if FROM_PMC else ("pmc_fetch", "pmc_write", "pmc_sq")):
     files = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")
     if not files:
         continue
@@ -38,7 +42,8 @@ for k, ns in avg_ns.items():
         key = k.split("(anonymous namespace)::")[1].split("(")[0]
         if key in out:
             out[key]["avg_duration_us_kernel_trace"] = round(ns / 1e3, 2)
-json.dump(out, open(f"profiles/{name}_pmc.json", "w"), indent=1)
+if not FROM_PMC:
+    json.dump(out, open(f"profiles/{name}_pmc.json", "w"), indent=1)
 traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
 sha = kernel_source_sha()
 # span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
@@ -51,7 +56,7 @@ SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true, 4>", 1), ("cell_sweep_k
          ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)),
          # tree sweep over sorted samples: keys, the radix sort's launches (rocprim kernels are not listed by name:
          # their share is in kernel_stats.csv), the sweep
-         ("bvh", "sweep_bvh", (("sweep_sorted_kernel<6>", 1), ("sample_keys_kernel<6>", 1))),
+         ("bvh", "sweep_bvh", (("sweep_sorted_kernel<6, 1>", 1), ("sample_keys_kernel<6>", 1))),
          ("ball", "sweep_ball", (("sweep_kernel<3, true>", 1),)))
 for method, span, kerns, in SPANS:
     have = [(k, m) for k, m in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
