@@ -657,6 +657,11 @@ struct FinishOp {
                  const uint32_t* flag_key, int32_t* flag_hist, int32_t* flag_sorted, int32_t* ctl,
                  uint32_t* d2, FaceAcc acc, unsigned long long* top, int32_t* top_list, int probed,
                  unsigned long long* hard, int hard_cap, unsigned long long* stats, hipStream_t st) {
+    // (the finish follows the cell sweep, which exists in 2D and 3D: the other dimensions are not instantiated -
+    // they were 91 KB of LDS and spilled registers for kernels nobody launches)
+    if constexpr (DIM != 2 && DIM != 3) {
+      return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: only dim 2 and 3");
+    } else {
     const int grid = g_bvh_grid;
     // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile (filled by the probe -
     // the cell sweep's when `probed`, else pass 0 here); the hard-entry launches' words: below
@@ -716,6 +721,7 @@ struct FinishOp {
     list(1, true, ctl + 7, d);   // ... one workgroup each, all their rounds
     launch(3, ctl + 6, d);
     return check_launch("finish_faces");
+    }
   }
 };
 
