@@ -137,6 +137,8 @@ FPS_BUCKET_MIN_POINTS = 200_000   # below this a brute-force step costs no more 
 FPS_BUCKET_MAX_DIM = 8            # ambient dimensions the bucketed selection supports
 FPS_BATCHED = True                # several landmarks per launch (flooder_fps_batched_f32); False: one per launch, dim <= 3
 LAST_FPS_LAUNCHES = 0             # kernel launches of the last batched selection (diagnostic)
+FPS_KEEP_DIAG = False             # keep the launch counters and block records of the last batched selection
+LAST_FPS_DIAG: Dict[str, object] = {}
 
 
 def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Optional[str] = None,
@@ -175,7 +177,7 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
             dp = index.dp
             minsq = torch.empty(n, dtype=torch.float32, device=pts.device)
             box = torch.empty(2 * dp * nb, dtype=torch.float32, device=pts.device)
-            keys = torch.empty(2 * nb, dtype=torch.int64, device=pts.device)
+            keys = torch.empty(3 * nb, dtype=torch.int64, device=pts.device)
             bcoord = torch.empty(dp * nb, dtype=torch.float32, device=pts.device)
             rec = torch.empty(int(lib.flooder_fps_batched_rec_words(n, dim, n_lms)), dtype=torch.int32, device=pts.device)
             zeroed = torch.zeros(64 * n_lms + (n_lms + 4 + 1) // 2, dtype=torch.int64, device=pts.device)
@@ -190,6 +192,9 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
                     _native.ptr(bcoord), _native.ptr(work_best), _native.ptr(rec), _native.ptr(work_ctr),
                     ctypes.addressof(launches), st), "flooder_fps_batched_f32")
             LAST_FPS_LAUNCHES = int(launches.value)
+            if FPS_KEEP_DIAG:
+                LAST_FPS_DIAG.update(ctr=work_ctr, rec=rec, blocks=rec.numel() // ((n_lms + 4) * (12 + max(dp, 4))),
+                                     words=12 + max(dp, 4))
             return out_idx
         if method == "bucket":
             return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx)

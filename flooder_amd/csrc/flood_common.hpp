@@ -40,6 +40,8 @@ extern int g_finish_top;     // 1: the finish settles one sample per simplex (it
 extern int g_finish_order;   // 1: the finish works the flagged tiles off by descending probe bound
 extern int g_fps_switch;
 extern int g_fps_rpl;
+extern int g_fps_lane_best;  // 1: batched FPS ranks one candidate per lane at most (the > 64 candidates path; test hook)
+extern int g_fps_rounds;  // 1: batched FPS enqueues rounds of launches and reads the counter back between them
 extern int g_curve;
 char* err_buf();
 int fail(int code, const char* msg);

@@ -254,7 +254,7 @@ void launch_bucketed(float4* rows, int64_t n, const int32_t* order, const float*
 
 }  // namespace
 
-namespace flooder { int g_fps_switch = 0; int g_fps_rpl = 0; }
+namespace flooder { int g_fps_switch = 0; int g_fps_rpl = 0; int g_fps_rounds = 0; int g_fps_lane_best = 0; }
 
 extern "C" {
 

@@ -15,21 +15,27 @@
 // One launch therefore selects a whole prefix y1 .. y_nb of the ranking (up to KMAX), all waves deciding the same
 // prefix redundantly from the same data, and applies all nb updates in one pass over the touched buckets.  The result
 // is the sequential selection, index for index (test_bucketed_fps_equals_brute_force); 1000 landmarks of a million
-// Gaussian points take ~240 launches instead of 1000.
+// Gaussian points take ~175 batched launches (after 95 brute-force steps) instead of 1000, 4000 of 16 M ~710.
 //
 // What the ranking needs - without sorting anything: every bucket keeps its best point key, its second best (k1, k2:
 // (minimum bits << 32 | ~original index), unique per point) and the coordinates of its best point; every workgroup
-// (4 waves x 64 buckets) ends a launch by writing ONE record for the next launch - plain stores, no atomics: its best
-// point b1 with coordinates, the second-best point and the box of THAT point's bucket, and bo = the best of all its
-// other points (an upper bound).  Every wave of the next launch reads all records (<= 256) with its first loads: the
-// block winners above B = max bo, in descending order, are the head of the ranking, EXCEPT for the points hidden in a
+// (4 waves x 64 buckets, consecutive buckets in different workgroups) ends a launch by writing ONE record for the
+// next launch - plain stores, no atomics: its best point b1 with coordinates, hb of THAT point's bucket (below), bo =
+// the best of all its other points (an upper bound) and the number of landmarks so far.  Every wave of the next launch
+// reads all records (<= 256) with its first loads, together with its own buckets - one memory round trip; the block
+// winners above B = max bo are the head of the ranking (compacted through LDS, one per lane, each lane counts the
+// candidates above its own: no chain of reductions), EXCEPT for the points hidden in a
 // winner's own bucket (in a dense cloud the runner-up of the arg-max is its neighbour).  Those are settled at
-// acceptance: once y_c is a landmark every point of its bucket is at most the farthest corner of the bucket's box away
-// from it, so candidate y_i is accepted only if its minimum also exceeds min(m(k2_c), farthest-corner d2) of every
-// accepted y_c.  Records and the landmark counter are indexed by launch number, so no launch re-reads what a
-// concurrent block still writes.  The host cannot know the number of launches: it enqueues them in rounds and reads
-// the counter (4 bytes) between rounds - the one entry point of this library that synchronises its stream; surplus
-// launches of a round see "done" and return at once.
+// acceptance: every bucket also keeps hb = max over its points of min(m(x), d2(x, best point)) - what its best minimum
+// becomes the moment its best point is a landmark (computed with the update's own d2 chain while the rows are in
+// registers; later landmarks only lower it) - and candidate y_i is accepted only if its minimum exceeds hb of every
+// accepted y_c.  Records are indexed by launch number, so no launch re-reads what a concurrent block still writes.
+// The host cannot know the number of launches, and a surplus launch costs a launch (the first version enqueued rounds
+// sized by the rate seen so far: 3331 launches for the 709 that 16 M / 4 k needs, because the rate grows 4x during a
+// selection).  Every launch now stores (launches done, landmarks so far) into a pinned host word; the host keeps 24
+// launches in flight beyond the last one it has seen complete and stops when the word says "all selected" - it never
+// drains the stream (option "fps_rounds": doubling rounds with a counter read-back, the fallback without pinned
+// memory).
 //
 // Rows: coordinates come from the curve-sorted padded rows of the PointIndex (the cloud is not copied again), the
 // running minima live in their own array.  Arithmetic per point as the brute-force kernels (direct differences, one
@@ -37,12 +43,17 @@
 
 #include "flood_common.hpp"
 
+#include <mutex>
+
 using namespace flooder;
 
 namespace {
 
 constexpr int BSLOTS = 64;    // arg-max slots per iteration of the brute-force phase
-constexpr int KMAX = 8;       // landmarks per launch at most
+#ifndef FLOODER_FPS_KMAX
+#define FLOODER_FPS_KMAX 8
+#endif
+constexpr int KMAX = FLOODER_FPS_KMAX;  // landmarks per launch at most
 
 typedef unsigned long long u64;
 
@@ -175,6 +186,19 @@ __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __re
     hi[k] = wave_max_f32(hi[k]);
     bx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
   }
+  // what the bucket's best minimum WOULD be once its best point is a landmark (the update's own d2 chain): the bound
+  // of the points hidden behind that point
+  float rad = 0.f;
+#pragma unroll
+  for (int u = 0; u < RPL; ++u) {
+    const int64_t j = b * (RPL * 64) + u * 64 + lane;
+    if (j < n) {
+      float x[DIM];
+      row_coords<DIM, DP>(pts_sorted, j, x);
+      rad = __builtin_fmaxf(rad, __builtin_fminf(minsq[j], dist2<DIM>(x, bx)));
+    }
+  }
+  rad = wave_max_f32(rad);
   if (lane == 0) {
     float* bb = box + b * 2 * DP;
     float* bc = bcoord + b * DP;
@@ -184,19 +208,21 @@ __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __re
       bb[DP + k] = k < DIM ? hi[k < DIM ? k : 0] : 0.f;
       bc[k] = k < DIM ? bx[k < DIM ? k : 0] : 0.f;
     }
-    keys[2 * b] = k1;
-    keys[2 * b + 1] = k2;
+    keys[3 * b] = k1;
+    keys[3 * b + 1] = k2;
+    keys[3 * b + 2] = (u64)__float_as_uint(rad);
   }
 }
 
 // Block record of a launch (plain stores by the block that owns it, read by every wave of the next launch):
-//   b1 best point of the block's buckets | k2 second-best point of THAT point's bucket | bo best of every other point of
-//   the block (an upper bound) | coordinates of the b1 point | box of its bucket.  32-bit words:
+//   b1 best point of the block's buckets | hb = best minimum of the other points of THAT point's bucket once b1 is a
+//   landmark: max over the bucket of min(m(x), d2(x, b1)) | bo best of every other point of the block (an upper
+//   bound) | landmarks applied after the launch | coordinates of the b1 point.  32-bit words:
 // (sections of 16 bytes or whole padded rows: a record is read with 16-byte loads)
 template <int DP>
 struct Rec {
   static constexpr int DPR = DP < 4 ? 4 : DP;  // row section (floats)
-  static constexpr int B1 = 0, K2 = 2, BO = 4, C = 8, LO = 8 + DPR, HI = 8 + 2 * DPR, WORDS = 8 + 3 * DPR;
+  static constexpr int B1 = 0, HB = 2, BO = 4, IT = 6, T0 = 8, C = 12, WORDS = 12 + DPR;
 };
 constexpr int NREC = 4;  // records per lane: at most 256 blocks
 
@@ -207,27 +233,38 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
 }
 
 // ---- one batched step (launch number L >= 1; L == 0 with init_only: only the block records)
+// Progress word in pinned host memory (one 8-byte store per launch, fire and forget): tag << 56 | launches done (24
+// bits, wraps) << 32 | landmarks selected.  The host reads it while it enqueues - it never drains the stream.
+__device__ __forceinline__ void report_progress(u64* progress, u64 tag, int launches_done, int landmarks) {
+  if (progress)
+    __hip_atomic_store(progress, (tag << 56) | ((u64)((uint32_t)launches_done & 0xffffffu) << 32) | (u64)(uint32_t)landmarks,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // lane l of wave w owns bucket l * n_waves + w (a landmark's neighbourhood spreads over the whole chip)
 template <int DIM, int RPL>
 __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     const float* __restrict__ pts_sorted, float* __restrict__ minsq, int64_t n, const int32_t* __restrict__ order,
     int64_t n_buckets, const float* __restrict__ box, u64* __restrict__ keys, float* __restrict__ bcoord, int L,
-    int n_lms, int32_t* __restrict__ ctr, uint32_t* __restrict__ rec, int64_t* __restrict__ out_idx, int init_only) {
+    int n_lms, int32_t* __restrict__ ctr, uint32_t* __restrict__ rec, int64_t* __restrict__ out_idx, int flags,
+    u64* __restrict__ progress, u64 progress_tag) {
+  const bool init_only = (flags & 1) != 0;  // (bit 1: test hook, see below)
   constexpr int DP = padded_dim(DIM);
   typedef Rec<DP> RC;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * 4;
-  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  // consecutive buckets (neighbours in space) belong to different workgroups: the runner-up next to the arg-max then
+  // is another block's winner - a candidate - and not the `bo` that closes every batch
+  const int64_t w = (int64_t)wv * gridDim.x + blockIdx.x;
   const int64_t b = (int64_t)lane * n_waves + w;
   const bool has = b < n_buckets;
-  const int it = ctr[L];  // landmarks applied so far (written by launch L - 1; the same for every block)
-  if (it >= n_lms) {      // done: surplus launch of a round
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[L + 1] = it;
-    return;
-  }
-  float blo[DIM], bhi[DIM], bc[DIM];
+  const uint32_t t_start = (uint32_t)wall_clock64();  // (diagnostic: record words 8, 9 of block 0; 100 MHz)
+  // ---- every load of the launch's head goes out together: this wave's buckets and ALL block records of the launch
+  // before (<= 256, NREC per lane), which also carry the number of landmarks applied so far
+  float blo[DIM], bhi[DIM], bc[DIM], brad = 0.f;
   u64 k1 = 0ull, k2 = 0ull;
+  int s_why = 0;
 #pragma unroll
   for (int k = 0; k < DIM; ++k) { blo[k] = 0.f; bhi[k] = 0.f; bc[k] = 0.f; }
   if (has) {
@@ -237,109 +274,156 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     load_row<DP>(bcoord + b * DP, r2);
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { blo[k] = r0[k]; bhi[k] = r1[k]; bc[k] = r2[k]; }
-    k1 = keys[2 * b];
-    k2 = keys[2 * b + 1];
+    k1 = keys[3 * b];
+    k2 = keys[3 * b + 1];
+    brad = __uint_as_float((uint32_t)keys[3 * b + 2]);
   }
-  if (!init_only) {
-    // ---- head of the ranking: block winners above B = the best of every point that is neither a block winner nor
-    // hidden behind one (the second-best point of a winner's own bucket is accounted for at acceptance)
-    const uint32_t* rc = rec + (int64_t)L * gridDim.x * RC::WORDS;
-    u64 a[NREC], ak2[NREC];
-    float ac[NREC][DIM], alo[NREC][DIM], ahi[NREC][DIM];
-    u64 bo = 0ull;
+  u64 a[NREC];
+  float ac[NREC][DIM], ahb[NREC];
+  u64 bo = 0ull;
+  int it_rec = 0;
 #pragma unroll
-    for (int t = 0; t < NREC; ++t) {
-      const int idx = lane + 64 * t;
-      a[t] = 0ull;
-      ak2[t] = 0ull;
+  for (int t = 0; t < NREC; ++t) {
+    const int idx = lane + 64 * t;
+    a[t] = 0ull;
+    ahb[t] = 0.f;
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) { ac[t][k] = 0.f; alo[t][k] = 0.f; ahi[t][k] = 0.f; }
-      if (idx < (int)gridDim.x) {
-        const uint32_t* r = rc + (int64_t)idx * RC::WORDS;
-        const uint4 h0 = *reinterpret_cast<const uint4*>(r);        // b1, k2
-        const uint2 h1 = *reinterpret_cast<const uint2*>(r + RC::BO);
-        a[t] = ((u64)h0.y << 32) | (u64)h0.x;
-        ak2[t] = ((u64)h0.w << 32) | (u64)h0.z;
-        const u64 o = ((u64)h1.y << 32) | (u64)h1.x;
-        bo = o > bo ? o : bo;
-        float rc_[RC::DPR], rl_[RC::DPR], rh_[RC::DPR];
-        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::C), rc_);
-        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::LO), rl_);
-        load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::HI), rh_);
+    for (int k = 0; k < DIM; ++k) ac[t][k] = 0.f;
+    if (!init_only && idx < (int)gridDim.x) {
+      const uint32_t* r = rec + ((int64_t)L * gridDim.x + idx) * RC::WORDS;
+      const uint4 h0 = *reinterpret_cast<const uint4*>(r);            // b1, hb
+      const uint4 h1 = *reinterpret_cast<const uint4*>(r + RC::BO);   // bo, landmarks so far
+      a[t] = ((u64)h0.y << 32) | (u64)h0.x;
+      ahb[t] = __uint_as_float(h0.z);
+      const u64 o = ((u64)h1.y << 32) | (u64)h1.x;
+      bo = o > bo ? o : bo;
+      if (t == 0) it_rec = (int)h1.z;
+      float rc_[RC::DPR];
+      load_row<RC::DPR>(reinterpret_cast<const float*>(r + RC::C), rc_);
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) { ac[t][k] = rc_[k]; alo[t][k] = rl_[k]; ahi[t][k] = rh_[k]; }
+      for (int k = 0; k < DIM; ++k) ac[t][k] = rc_[k];
+    }
+  }
+  // landmarks applied so far (the same for every block: block 0's record of the launch before)
+  const int it = init_only ? ctr[0] : __builtin_amdgcn_readfirstlane(it_rec);
+  if (it >= n_lms) {  // done: a surplus launch.  The next one still reads "landmarks so far" from block 0's record
+    if (threadIdx.x == 0) {
+      rec[((int64_t)(L + 1) * gridDim.x + blockIdx.x) * RC::WORDS + RC::IT] = (uint32_t)it;
+      if (blockIdx.x == 0) {
+        ctr[L + 1] = it;
+        report_progress(progress, progress_tag, L + 1, it);
       }
     }
-    const u64 B = wave_max_key(bo);
-    // ---- candidates in descending order, each accepted (or the batch closed) before the next is looked for: a
-    // round is a chain of dependent cross-lane reductions (~0.3 us for a wave alone on its SIMD), and most batches
-    // close after three or four
+    return;
+  }
+  int nb = 0;
+  if (!init_only) {
+    // ---- head of the ranking: block winners above B = the best of every point that is neither a block winner nor
+    // hidden behind one (the points hidden behind a winner are accounted for at acceptance).  All candidates are
+    // ranked at once: compacted through LDS (one per lane), each lane counts the candidates above its own.
+    __shared__ u64 s_ckey[4][64];
+    __shared__ float s_cdat[4][64][DIM + 1];
+    u64 B = wave_max_key(bo);
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < NREC; ++t) total += __builtin_popcountll(__ballot(a[t] > B));
+    if (total > 64 || (flags & 2)) {  // more candidates than lanes (or option "fps_lane_best", a test hook): every lane keeps its best, the others close the ranking like any
+                       // other point (the arg-max is some lane's best)
+      u64 best = 0ull, oth = 0ull;
+#pragma unroll
+      for (int t = 0; t < NREC; ++t) best = a[t] > best ? a[t] : best;
+#pragma unroll
+      for (int t = 0; t < NREC; ++t) {
+        if (a[t] != best) {
+          oth = a[t] > oth ? a[t] : oth;
+          a[t] = 0ull;
+        }
+      }
+      const u64 d = wave_max_key(oth);
+      B = d > B ? d : B;
+    }
+    int n_c = 0;
+#pragma unroll
+    for (int t = 0; t < NREC; ++t) {
+      const bool is = a[t] > B;
+      const u64 mask = __ballot(is);
+      if (mask) {  // (wave-uniform)
+        const int slot = n_c + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (is) {
+          s_ckey[wv][slot] = a[t];
+          s_cdat[wv][slot][DIM] = ahb[t];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) s_cdat[wv][slot][k] = ac[t][k];
+        }
+        n_c += __builtin_popcountll(mask);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    u64 key = 0ull;
+    float ci[DIM], hbi = 0.f;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) ci[k] = 0.f;
+    if (lane < n_c) {
+      key = s_ckey[wv][lane];
+      hbi = s_cdat[wv][lane][DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) ci[k] = s_cdat[wv][lane][k];
+    }
+    const bool valid = key != 0ull;
+    int rank = 0;
+    for (int j = 0; j < n_c; ++j) rank += readlane_u64(key, j) > key ? 1 : 0;
+    const float mi = __uint_as_float((uint32_t)(key >> 32));
+    // ---- acceptance, candidate by candidate in ranking order; every lane tracks its own candidate against the
+    // accepted ones (within its own minimum of one of them? below the points hidden behind one of them?), so a step
+    // costs a few cross-lane reads, not a reduction
     u64 ck[KMAX];
     float cc[KMAX][DIM];   // coordinates of the accepted candidates
-    int nb = 0;
-    float hbound = 0.f;    // largest bound of the points hidden in an accepted candidate's own bucket
-    u64 prev = ~0ull;
+    bool conflict = false;
+    float hmax = 0.f;      // largest bound of the points hidden in an accepted candidate's own bucket
+    bool open = true;
+    int why = 4;           // (diagnostic, record word 3 of block 0) what closed the batch: 1 nothing above B, 2 a
+                           // candidate within its own minimum of an accepted one, 3 hidden points, 4 KMAX / the end
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      ck[i] = 0ull;
+    for (int j = 0; j < KMAX; ++j) {
+      ck[j] = 0ull;
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) cc[i][k] = 0.f;
-      if (nb == i && i < n_lms - it) {  // (wave-uniform: every candidate before i was accepted)
-        u64 m = 0ull;
-        int tsel = 0;
+      for (int k = 0; k < DIM; ++k) cc[j][k] = 0.f;
+      if (open && j < n_lms - it) {  // (wave-uniform)
+        const u64 sm = __ballot(valid && rank == j);
+        if (sm == 0ull) {
+          why = 1;
+          open = false;
+        } else {
+          const int src = __builtin_ctzll(sm);
+          const bool hidden = !(mi > 0.f && mi > hmax);
+          const u64 fm = __ballot(conflict || hidden);
+          if (j > 0 && ((fm >> src) & 1ull)) {
+            why = ((__ballot(conflict) >> src) & 1ull) ? 2 : 3;
+            open = false;
+          } else {
+            ck[j] = readlane_u64(key, src);
 #pragma unroll
-        for (int t = 0; t < NREC; ++t)
-          if (a[t] > B && a[t] < prev && a[t] > m) { m = a[t]; tsel = t; }
-        const u64 wk = wave_max_key(m);
-        if (wk != 0ull) {
-          prev = wk;
-          // the lane that holds this record broadcasts its coordinates and the hidden-point bound of its bucket:
-          // min(second-best minimum of the bucket, farthest corner of the bucket's box from the candidate) - every
-          // point of the bucket is at most that far from the new landmark (same fma chain on |corner gap| >= |difference|)
-          float mc[DIM], hb = 0.f;
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) mc[k] = 0.f;
-#pragma unroll
-          for (int t = 0; t < NREC; ++t) {
-            if (t == tsel) {
-              float far = 0.f;
-#pragma unroll
-              for (int k = 0; k < DIM; ++k) {
-                mc[k] = ac[t][k];
-                const float g = __builtin_fmaxf(ac[t][k] - alo[t][k], ahi[t][k] - ac[t][k]);
-                far = __builtin_fmaf(g, g, far);
-              }
-              const float m2 = __uint_as_float((uint32_t)(ak2[t] >> 32));
-              hb = far < m2 ? far : m2;
+            for (int k = 0; k < DIM; ++k) cc[j][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci[k]), src));
+            const float hbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hbi), src));
+            nb = j + 1;
+            if (valid && rank > j) {
+              conflict = conflict || dist2<DIM>(ci, cc[j]) < mi;
+              hmax = __builtin_fmaxf(hmax, hbj);
             }
-          }
-          const int src = __builtin_ctzll(__ballot(m == wk));
-          float ci[DIM];
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) ci[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc[k]), src));
-          const float hbi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hb), src));
-          const float mi = __uint_as_float((uint32_t)(wk >> 32));
-          bool ok = i == 0 || (mi > 0.f && mi > hbound);
-#pragma unroll
-          for (int l = 0; l < KMAX; ++l) {
-            if (l < i) ok = ok && !(dist2<DIM>(ci, cc[l]) < mi);
-          }
-          if (ok) {
-            ck[i] = wk;
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) cc[i][k] = ci[k];
-            hbound = __builtin_fmaxf(hbound, hbi);
-            nb = i + 1;
           }
         }
       }
     }
+    s_why = why;
     if (nb > n_lms - it) nb = n_lms - it;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
       for (int i = 0; i < KMAX; ++i)
         if (i < nb) out_idx[it + i] = (int64_t)(0xffffffffu - (uint32_t)ck[i]);
       ctr[L + 1] = it + nb;
+      report_progress(progress, progress_tag, L + 1, it + nb);
     }
     // ---- which of this wave's buckets can still change?  (lower bound of d2 from a landmark to the bucket's box)
     bool touched = false;
@@ -406,6 +490,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
                 }
               }
               if (m < m0[g][u]) minsq[j] = m;
+              m0[g][u] = m;
               const u64 k = make_key(m, o[g][u]);
               if (k > b1) {
                 b2 = b1;
@@ -423,11 +508,20 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
           float nbx[DIM];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) nbx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx[k]), bl));
+          float rad = 0.f;   // the bucket's best minimum once its new best point is a landmark (rows still in registers)
+#pragma unroll
+          for (int u = 0; u < RPL; ++u) {
+            const int64_t j = tb * (RPL * 64) + u * 64 + lane;
+            if (j < n) rad = __builtin_fmaxf(rad, __builtin_fminf(m0[g][u], dist2<DIM>(x[g][u], nbx)));
+          }
+          rad = wave_max_f32(rad);
           if (lane == src) {
             k1 = nk1;
             k2 = nk2;
-            keys[2 * tb] = nk1;
-            keys[2 * tb + 1] = nk2;
+            brad = rad;
+            keys[3 * tb] = nk1;
+            keys[3 * tb + 1] = nk2;
+            keys[3 * tb + 2] = (u64)__float_as_uint(rad);
 #pragma unroll
             for (int k = 0; k < DIM; ++k) {
               bc[k] = nbx[k];
@@ -439,22 +533,23 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     }
   } else if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctr[L + 1] = it;
+    report_progress(progress, progress_tag, L + 1, it);
   }
   // ---- this block's record for the next launch
-  __shared__ u64 s_w1[4], s_k2[4], s_oth[4];
-  __shared__ float s_c[4][3 * DIM];
+  __shared__ u64 s_w1[4], s_oth[4];
+  __shared__ float s_hb[4];
+  __shared__ float s_c[4][DIM];
   {
     const u64 w1 = wave_max_key(k1);
     const int wl = w1 != 0ull ? __builtin_ctzll(__ballot(k1 == w1 && has)) : 0;
     const u64 oth = wave_max_key(lane == wl ? 0ull : k1);  // (the other buckets' second-best points are below their best)
-    const u64 ok2 = readlane_u64(k2, wl);
-    if (lane == 0) { s_w1[wv] = w1; s_k2[wv] = ok2; s_oth[wv] = oth; }
+    const float m2 = __uint_as_float((uint32_t)(readlane_u64(k2, wl) >> 32));
+    const float rd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(brad), wl));
+    if (lane == 0) { s_w1[wv] = w1; s_oth[wv] = oth; s_hb[wv] = rd < m2 ? rd : m2; }  // (rd <= m2 already)
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
       const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc[k]), wl));
-      const float l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blo[k]), wl));
-      const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bhi[k]), wl));
-      if (lane == 0) { s_c[wv][k] = c; s_c[wv][DIM + k] = l; s_c[wv][2 * DIM + k] = h; }
+      if (lane == 0) s_c[wv][k] = c;
     }
   }
   __syncthreads();
@@ -468,13 +563,13 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     }
     uint32_t* r = rec + ((int64_t)(L + 1) * gridDim.x + blockIdx.x) * RC::WORDS;
     *reinterpret_cast<u64*>(r + RC::B1) = s_w1[wb];
-    *reinterpret_cast<u64*>(r + RC::K2) = s_k2[wb];
+    r[RC::HB] = __float_as_uint(s_hb[wb]);
+    r[RC::HB + 1] = (uint32_t)s_why;
+    r[RC::IT] = (uint32_t)(it + nb);
+    r[RC::T0] = t_start;
+    r[RC::T0 + 1] = (uint32_t)wall_clock64();
     *reinterpret_cast<u64*>(r + RC::BO) = bo;
-    for (int k = 0; k < DIM; ++k) {
-      r[RC::C + k] = __float_as_uint(s_c[wb][k]);
-      r[RC::LO + k] = __float_as_uint(s_c[wb][DIM + k]);
-      r[RC::HI + k] = __float_as_uint(s_c[wb][2 * DIM + k]);
-    }
+    for (int k = 0; k < DIM; ++k) r[RC::C + k] = __float_as_uint(s_c[wb][k]);
   }
 }
 
@@ -488,6 +583,37 @@ __global__ void fps2_last_kernel(const u64* best, int n_lms, int64_t* out_idx) {
 }
 
 __global__ void fps2_set_ctr_kernel(int32_t* ctr, int value) { ctr[0] = value; }
+
+// one pinned progress word per device (allocated at first use, kept for the life of the process)
+struct ProgressSlot {
+  std::mutex busy;
+  u64* host = nullptr;
+  u64* dev = nullptr;
+  unsigned calls = 0;
+  bool tried = false;
+};
+inline ProgressSlot* progress_slot(int device) {
+  static ProgressSlot slots[64];
+  static std::mutex init;
+  if (device < 0 || device >= 64 || g_fps_rounds) return nullptr;
+  ProgressSlot& s = slots[device];
+  std::lock_guard<std::mutex> guard(init);
+  if (!s.tried) {
+    s.tried = true;
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        s.host = reinterpret_cast<u64*>(h);
+        s.dev = reinterpret_cast<u64*>(d);
+      } else {
+        hipHostFree(h);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  return s.host ? &s : nullptr;
+}
 
 template <int RPL>
 int64_t batched_blocks(int64_t n) {
@@ -521,26 +647,79 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
   hipLaunchKernelGGL((fps2_bucket_init_kernel<DIM, RPL>), dim3((unsigned)((n_buckets + 3) / 4)), dim3(256), 0, st,
                      pts_sorted, minsq, n, order, n_buckets, box, keys, bcoord);
   hipLaunchKernelGGL(fps2_set_ctr_kernel, dim3(1), dim3(1), 0, st, ctr, k_brute - 1);
+  // The host cannot know how many launches the selection takes, and a surplus launch costs a launch.  Every launch
+  // stores (launches done, landmarks selected) into a pinned host word; the host keeps a bounded number of launches
+  // in flight beyond the last one it has seen complete and stops enqueuing when the word says "all selected".  The
+  // stream is never drained; without pinned memory: rounds of launches with a counter read-back between them.
+  int device = 0;
+  hipGetDevice(&device);
+  ProgressSlot* slot = progress_slot(device);
+  if (slot) {
+    std::lock_guard<std::mutex> guard(slot->busy);
+    const u64 tag = (u64)(++slot->calls & 0xffu);
+    volatile u64* word = slot->host;
+    *word = 0ull;   // (a stale store of an earlier call carries that call's tag)
+    hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
+                       n_buckets, box, keys, bcoord, 0, n_lms, ctr, rec, out_idx, 1, slot->dev, tag);
+    const int flags = g_fps_lane_best ? 2 : 0;
+    constexpr int IN_FLIGHT = 24;
+    int enq = 1;                       // launches enqueued (launch numbers 0 .. enq - 1)
+    int seen_l = 0, seen_it = k_brute - 1;
+    long spins = 0;
+    for (;;) {
+      const u64 v = *word;
+      if ((v >> 56) == tag) {
+        const int lw = (int)((v >> 32) & 0xffffffu);
+        seen_l = enq - (int)(((uint32_t)enq - (uint32_t)lw) & 0xffffffu);
+        seen_it = (int)(uint32_t)v;
+      }
+      if (seen_it >= n_lms) break;
+      // never past what the remaining landmarks can need (a launch selects at least one): bounds the record array
+      int room = IN_FLIGHT - (enq - seen_l);
+      const int need = seen_l + (n_lms - seen_it) - enq;
+      if (room > need) room = need;
+      if (room > 0) {
+        for (int i = 0; i < room; ++i, ++enq)
+          hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n,
+                             order, n_buckets, box, keys, bcoord, enq, n_lms, ctr, rec, out_idx, flags, slot->dev, tag);
+        spins = 0;
+      } else if (++spins > (1L << 22)) {   // nothing reported for a long time: is the stream still alive?
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: the stream failed during the selection");
+        if (q == hipSuccess && (*word >> 56) == tag && (int)(uint32_t)*word < n_lms && (int)(uint32_t)*word == seen_it)
+          return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: no progress (internal error)");
+        spins = 0;
+      }
+    }
+    launches += enq - 1;
+    if (launches_out) *launches_out = launches;
+    return check_launch("fps_batched");
+  }
   hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
-                     n_buckets, box, keys, bcoord, 0, n_lms, ctr, rec, out_idx, 1);
+                     n_buckets, box, keys, bcoord, 0, n_lms, ctr, rec, out_idx, 1, (u64*)nullptr, 0ull);
   int L = 1, done = k_brute - 1;
-  int round = 64;
+  int round = 32, prev_round = 16;
   while (done < n_lms) {
     const int remaining = n_lms - done;
-    if (round > remaining) round = remaining;  // (a launch selects at least one landmark)
+    if (round > 2 * prev_round) round = 2 * prev_round;  // (the rate grows as the landmarks get denser)
+    if (round > remaining) round = remaining;            // (a launch selects at least one landmark)
     for (int i = 0; i < round; ++i, ++L)
       hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
-                         n_buckets, box, keys, bcoord, L, n_lms, ctr, rec, out_idx, 0);
+                         n_buckets, box, keys, bcoord, L, n_lms, ctr, rec, out_idx, g_fps_lane_best ? 2 : 0, (u64*)nullptr, 0ull);
     int32_t now = 0;
     if (hipMemcpyAsync(&now, ctr + L, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: reading the landmark counter failed");
     if (now <= done) return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: no progress (internal error)");
-    // next round: what is left at the rate seen so far, plus a margin (surplus launches return at once)
-    const double per_launch = (double)(now - (k_brute - 1)) / (double)(L - 1);
+    const double rate = (double)(now - done) / (double)round;  // landmarks per launch of this round
     done = now;
     launches += round;
-    round = (int)((double)(n_lms - done) / per_launch * 1.2) + 4;
+    prev_round = round;
+    const double est = (double)(n_lms - done) / rate;
+    round = est > 24.0 ? (int)(est * 0.8) : (int)(est * 1.25) + 1;
+    const int least = (n_lms - done + KMAX - 1) / KMAX;
+    if (round < least) round = least;
   }
   if (launches_out) *launches_out = launches;
   return check_launch("fps_batched");
@@ -575,7 +754,7 @@ int64_t flooder_fps_batched_rec_words(int64_t n_pts, int dim, int n_lms) {
   if (n_pts < 1 || dim < 1 || dim > FLOODER_MAX_DIM || n_lms < 1) return 0;
   const int64_t blocks = batched_rpl(n_pts) == 4 ? batched_blocks<4>(n_pts) : batched_blocks<1>(n_pts);
   const int dpr = padded_dim(dim) < 4 ? 4 : padded_dim(dim);
-  return (int64_t)(n_lms + 4) * blocks * (8 + 3 * dpr);
+  return (int64_t)(n_lms + 4) * blocks * (12 + dpr);
 }
 
 int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,

@@ -631,6 +631,14 @@ int flooder_set_option(const char* name, int value) {
     g_fps_switch = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "fps_lane_best") == 0 && (value == 0 || value == 1)) {
+    g_fps_lane_best = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "fps_rounds") == 0 && (value == 0 || value == 1)) {
+    g_fps_rounds = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "fps_rpl") == 0 && (value == 0 || value == 1 || value == 4)) {
     g_fps_rpl = value;
     return FLOODER_OK;

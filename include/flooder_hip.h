@@ -414,11 +414,16 @@ int flooder_fps_indexed_f32(const float* pts, int64_t n_pts, int dim, int ld, co
  * pts_sorted / order: rows of the cloud in curve order (flooder_padded_dim(dim) floats each) and the sorted row ->
  * original index map (flooder_index_rows_f32 / flooder_index_sort).  n_pts <= flooder_fps_batched_max_points().
  * Workspaces (device): minsq n_pts floats; bucket_box 2 * padded_dim * flooder_fps_bucket_count(n_pts) floats;
- * bucket_keys 2 * bucket count uint64; bucket_coord padded_dim * bucket count floats; work_best 64 * n_lms uint64,
+ * bucket_keys 3 * bucket count uint64; bucket_coord padded_dim * bucket count floats; work_best 64 * n_lms uint64,
  * ZEROED; work_rec flooder_fps_batched_rec_words(n_pts, dim, n_lms) uint32; work_ctr n_lms + 4 int32, ZEROED.
  * launches_out (host pointer, may be NULL): kernel launches used.
- * UNLIKE every other entry point this one SYNCHRONISES the stream: the number of launches depends on the data, so
- * they are enqueued in rounds and the landmark counter (4 bytes) is read back between rounds. */
+ * The number of launches depends on the data.  UNLIKE every other entry point this one therefore WAITS for the
+ * device: every launch stores (launches done, landmarks selected) into a pinned host word (one per device, allocated
+ * at first use), the host keeps 24 launches in flight beyond the last one it has seen complete and returns when the
+ * word says "all selected" (the stream itself is not drained: a few no-op launches may still be queued).  Option
+ * "fps_rounds" = 1 (and a host where pinned memory cannot be had): doubling rounds of launches with a read-back of
+ * the landmark counter (4 bytes, hipStreamSynchronize) between rounds.  "fps_lane_best" = 1: test hook, ranks at most
+ * one candidate per lane (the path more than 64 candidates take). */
 int64_t flooder_fps_batched_max_points(void);
 int64_t flooder_fps_batched_rec_words(int64_t n_pts, int dim, int n_lms);
 int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* pts_sorted,

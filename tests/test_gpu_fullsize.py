@@ -211,6 +211,15 @@ def test_batched_fps_hard_cases_equal_brute_force(dev, case, monkeypatch):
         finally:
             lib.flooder_set_option(b"fps_switch", 0)
         assert np.array_equal(a[:len(c)], c), sw
+    # the other paths of the same entry point: one candidate per lane (what > 64 candidates fall back to) and rounds
+    # of launches with a counter read-back (what a host without pinned memory falls back to)
+    for opt in (b"fps_lane_best", b"fps_rounds"):
+        try:
+            assert lib.flooder_set_option(opt, 1) == 0
+            c = core.fps_indices(tp, k, start, method="bucket").cpu().numpy()
+        finally:
+            lib.flooder_set_option(opt, 0)
+        assert np.array_equal(a, c), opt
     if P.shape[1] <= 3:  # the one-landmark-per-launch kernels stay selectable
         monkeypatch.setattr(core, "FPS_BATCHED", False)
         assert np.array_equal(a, core.fps_indices(tp, k, start, method="bucket").cpu().numpy())

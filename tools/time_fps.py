@@ -16,8 +16,9 @@ for name, pts, k in cases:
     index = core.PointIndex(tp); torch.cuda.synchronize()
     ref = None
     for method, batched, opts in (("brute", False, {}), ("bucket", False, {}), ("bucket", True, {}),
-                                  ("bucket", True, {"fps_switch": 32}), ("bucket", True, {"fps_switch": 8}),
-                                  ("bucket", True, {"fps_switch": 256})):
+                                  ("bucket", True, {"fps_switch": 4}), ("bucket", True, {"fps_switch": 16}),
+                                  ("bucket", True, {"fps_switch": 32}), ("bucket", True, {"fps_switch": 64}),
+                                  ("bucket", True, {"fps_switch": 128}), ("bucket", True, {"fps_rounds": 1})):
         if method == "bucket" and not batched and pts.shape[1] > 3:
             continue
         if method == "brute" and pts.shape[0] > 4_000_000 and "full" not in sys.argv:
