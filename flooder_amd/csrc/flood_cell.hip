@@ -125,6 +125,8 @@ struct DeferList {
   int32_t* tile_list = nullptr;
   float* tile_c = nullptr;
   int32_t* tile_count = nullptr;
+  int64_t tail_items = INT64_MAX;  // only the last so many items of the chunk launch hand dense chunks on to the tiles
+  int listed_first = 1;  // chunk launch: the deferred chunks ahead of the heavy simplices (0: behind them)
 };
 
 // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
@@ -278,15 +280,19 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
   const int chunks = (n_slots + CHUNK - 1) / CHUNK;
   const int tiles64 = (n_slots + 63) >> 6;
   const int supers = (chunks + GS - 1) / GS;
-  // (split[2] == 0: the split kernel found the cloud too dense for runs of four - the SUPER launch has no items and
-  // this one takes every chunk of every simplex in plain order, no lists)
+  // (split[2] == 0: lists not filled - not produced any more, kept for callers that zero the counts themselves; a
+  // cloud too dense for runs of four, or a short queue, has every simplex on the heavy list)
   const bool use_lists = TILES || (!SUPER && dl.list && (!dl.split || dl.split[2] != 0));
   const int64_t n_heavy_items = (!TILES && use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
+  // chunk launch: the chunks the runs deferred come FIRST - they are the long items of this launch (a neighbourhood
+  // that overflowed the shared stage), and at the end of the queue they were its tail
+  const bool lfirst = TILES || dl.listed_first != 0;
+  const int64_t n_listed = TILES ? (int64_t)dl.tile_count[0] : (use_lists ? (int64_t)dl.count[0] : 0);
   const int32_t* item_list = TILES ? dl.tile_list : dl.list;
   const float* item_c = TILES ? dl.tile_c : dl.c;
   const int64_t n_items = TILES ? (int64_t)dl.tile_count[0]
                           : SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
-                                  : (use_lists ? n_heavy_items + (int64_t)dl.count[0] : n_simplices * chunks);
+                                  : (use_lists ? n_heavy_items + n_listed : n_simplices * chunks);
   if (n_items == 0) return;  // (nothing for this launch: no need for 3072 waves to pop an empty queue)
   unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
 #ifdef FLOODER_PHASE_TIMERS
@@ -318,14 +324,16 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       q = (int)(g - s * supers) * GS;
       n_sub = chunks - q < GS ? chunks - q : GS;
       if (dl.light) s = dl.light[s];
-    } else if (use_lists && g < n_heavy_items) {
-      s = g / chunks;
-      q = (int)(g - s * chunks);
+    } else if (use_lists && (lfirst ? g >= n_listed : g < n_heavy_items)) {
+      const int64_t gh = lfirst ? g - n_listed : g;
+      s = gh / chunks;
+      q = (int)(gh - s * chunks);
       s = dl.heavy[s];
     } else if (use_lists) {
-      const int e = item_list[g - n_heavy_items];
+      const int64_t gl = lfirst ? g : g - n_heavy_items;
+      const int e = item_list[gl];
       seeded = (e & 1) != 0;
-      c_seed = item_c[g - n_heavy_items];
+      c_seed = item_c[gl];
       s = (int64_t)(e >> 1) / chunks;
       q = (int)((e >> 1) - s * chunks);
     } else {
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         if (n_keep > CAPW) break;  // the neighbourhood of the whole run does not fit the stage: chunk by chunk
       }
       if constexpr (!SUPER && !TILES) {
-        if (n_keep > CAPW && dl.tile_list) {
+        if (n_keep > CAPW && dl.tile_list && g >= n_items - dl.tail_items) {
           // dense chunk: its open tiles of 64 samples go to the tile launch (a quarter of the region each: most fit the
           // stage there) instead of an exhaustive evaluation of every kept point against all 256 samples.  A chunk
           // that already holds minima (seeded, or a second attempt) parks them first, as a run of four does.
@@ -1270,8 +1278,11 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
   // whose same-address atomics would themselves stretch the end of the kernel)
   if (stats) {
     if (lane == 0) {
-      stats[64 + 2 * (blockIdx.x * 4 + wv)] = t_wave0;
-      stats[65 + 2 * (blockIdx.x * 4 + wv)] = __builtin_amdgcn_s_memrealtime();
+      const int slot = (SUPER ? 0 : 4096) + (int)(blockIdx.x * 4 + wv);  // (runs launch | chunk launch: <= 4096 waves each)
+      if (slot < 8192) {
+        stats[64 + 2 * slot] = t_wave0;
+        stats[65 + 2 * slot] = __builtin_amdgcn_s_memrealtime();
+      }
     }
     return;
   }
@@ -1313,24 +1324,30 @@ struct CellOp {
                          plane_tab);
       constexpr int CHUNK = 64 * SPL_CHUNK;
       const int64_t n_chunks = ns * ((R + CHUNK - 1) / CHUNK);
-      int64_t want = n_chunks / 48;
-      want = want < 384 ? 384 : want;
+      int64_t want = n_chunks / (g_cell_chunks_per_block > 0 ? g_cell_chunks_per_block : 48);
+      want = want < g_cell_min_grid ? g_cell_min_grid : want;
       const int grid = (int)(want < g_cell_grid ? want : g_cell_grid);
       const int brute_max = g_cell_brute_max < BRUTE_CAP ? g_cell_brute_max : BRUTE_CAP;
       // (a short queue - a rank's share of a multi-GPU run - is balanced better chunk by chunk than in runs of four)
-      if (dl.list && n_chunks < (int64_t)g_cell_super_min_chunks) {
+      const bool runs_launch = dl.list && (!dl.split || n_chunks >= (int64_t)g_cell_super_min_chunks);
+      if (dl.list && !dl.split && n_chunks < (int64_t)g_cell_super_min_chunks) {  // (no weights: plain order, no lists)
         DeferList d2{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         d2.tile_list = dl.tile_list; d2.tile_c = dl.tile_c; d2.tile_count = dl.tile_count;
         dl = d2;
       }
       if (!g_cell_tiles) { dl.tile_list = nullptr; dl.tile_c = nullptr; dl.tile_count = nullptr; }
+      // (2: only where an exhaustive evaluation by ONE wave - 150 us and more - would be the tail of the launch)
+      if (g_cell_tiles == 2) dl.tail_items = (int64_t)g_cell_tail_waves * grid * 4 / 100;
+      dl.listed_first = g_cell_listed_first;
 #define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
   hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
                      k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \
                      g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl, dg)
       if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
-        FLOODER_CELL_LAUNCH(true, SPL_CHUNK, queue);
+        // (split: every simplex is on the heavy list of a short queue - the split kernel was told - and the chunk
+        // launch takes them heaviest first)
+        if (runs_launch) FLOODER_CELL_LAUNCH(true, SPL_CHUNK, queue);
         FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue2);
       } else {
         FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue);
@@ -1351,7 +1368,7 @@ namespace {
 
 // Order-preserving split of 0 .. n-1 by weight[i] <= limit: one block, ballot scans (n is a few thousand).
 // Runs of four chunks pay in sparse volumetric clouds (most runs fit the stage); where fewer than half of the simplices
-// are sparse (weight <= sparse_limit) the whole sweep stays chunk by chunk: counts = {0, 0, 0}.
+// are sparse (weight <= sparse_limit) the whole sweep stays chunk by chunk: every simplex on the heavy list.
 __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __restrict__ weight, int n, float limit,
                                                                float sparse_limit, int32_t* __restrict__ light,
                                                                int32_t* __restrict__ heavy, int32_t* __restrict__ counts) {
@@ -1366,8 +1383,9 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
   if (lane == 0) atomicAdd(&s_sparse, mine);
   __syncthreads();
-  if (2 * s_sparse < n) {
-    if (threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }
+  if (2 * s_sparse < n) {  // every simplex heavy, in the given order
+    for (int i = threadIdx.x; i < n; i += 1024) heavy[i] = i;
+    if (threadIdx.x == 0) { counts[0] = 0; counts[1] = n; counts[2] = 1; }
     return;
   }
   int n_light = 0, n_heavy = 0;  // (block-uniform running totals)
@@ -1391,6 +1409,141 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
     n_light += total;
     n_heavy += valid - total;
     __syncthreads();
+  }
+  if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
+}
+
+// A SHORT queue (a rank's share of a multi-GPU run: no runs of four, every simplex on the heavy list) in DESCENDING
+// weight class (powers of two around the limit), the given order kept inside a class: one block.  The persistent kernels pop their items in list order, and the long items - the
+// chunks of the densest simplices, whose neighbourhood overflows the stage and is evaluated exhaustively by ONE wave
+// for 150 - 200 us - used to sit wherever the axis order put them: the last of them to start was the tail of the
+// launch (a quarter of it on cfg 2, half of it on an eighth of cfg 2).
+// Runs of four chunks pay in sparse volumetric clouds (most runs fit the stage); where fewer than half of the simplices
+// are sparse (weight <= sparse_limit), or the caller says so (runs_allowed = 0: a short queue), every simplex is heavy.
+constexpr int SPLIT_THREADS = 256;  // (1024 threads leave 128 VGPRs each: the class arrays spilled, and scratch costs a launch 25 us)
+constexpr int SPLIT_CLASSES = 9;  // weight > limit x 32, 16, 8, 4, 2, 1, 1/2, 1/4, rest
+// (a stable counting sort: every thread owns a run of consecutive simplices, counts its classes, one block-wide
+// exclusive scan per class - wave scans + partial sums through LDS - and every thread writes its run: two barriers)
+__global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float* __restrict__ weight, int n, float limit,
+                                                               float sparse_limit, int runs_allowed,
+                                                               int32_t* __restrict__ light, int32_t* __restrict__ heavy,
+                                                               int32_t* __restrict__ counts) {
+  __shared__ int s_cnt[SPLIT_THREADS / 64][SPLIT_CLASSES + 1];
+  // the weights come in coalesced and are read back run by run from LDS (a run of consecutive simplices per thread
+  // straight from memory is a chain of dependent cache misses: 34 us for 6000 simplices instead of 8)
+  constexpr int W_LDS = 15360;
+  __shared__ float s_w[W_LDS];
+  const bool staged = n <= W_LDS;
+  if (staged) {
+    for (int base = 0; base < n; base += SPLIT_THREADS * 8) {  // (eight loads in flight: the loop is latency, not bytes)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * SPLIT_THREADS + (int)threadIdx.x;
+        v[u] = i < n ? weight[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * SPLIT_THREADS + (int)threadIdx.x;
+        if (i < n) s_w[i] = v[u];
+      }
+    }
+    __syncthreads();
+  }
+  auto wt = [&](int i) -> float { return staged ? s_w[i] : weight[i]; };
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool by_class = (runs_allowed & 2) != 0;
+  auto cls = [&](float w) -> int {  // 0 = heaviest
+    if (!by_class) return w > limit ? 5 : 6;
+    int c = 0;
+    float t = limit * 32.f;
+#pragma unroll
+    for (int k = 0; k < SPLIT_CLASSES - 1; ++k) {
+      c += w > t ? 0 : 1;
+      t *= 0.5f;
+    }
+    return c;
+  };
+  const int per = ((n + SPLIT_THREADS - 1) / SPLIT_THREADS) | 1;  // (odd: the runs start in different LDS banks)
+  const int i0 = threadIdx.x * per < n ? threadIdx.x * per : n;
+  const int i1 = i0 + per < n ? i0 + per : n;
+  int cnt[SPLIT_CLASSES + 1];  // [SPLIT_CLASSES]: sparse simplices
+#pragma unroll
+  for (int k = 0; k <= SPLIT_CLASSES; ++k) cnt[k] = 0;
+  for (int ib = i0; ib < i1; ib += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ib + u < i1 ? wt(ib + u) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (ib + u < i1) {
+        const int c = cls(v[u]);
+#pragma unroll
+        for (int k = 0; k < SPLIT_CLASSES; ++k) cnt[k] += c == k ? 1 : 0;
+        cnt[SPLIT_CLASSES] += v[u] <= sparse_limit ? 1 : 0;
+      }
+    }
+  }
+  int excl[SPLIT_CLASSES];  // simplices of the class in the threads before this one (this wave)
+#pragma unroll
+  for (int k = 0; k <= SPLIT_CLASSES; ++k) {
+    int v = cnt[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      v += lane >= o ? u : 0;
+    }
+    if (k < SPLIT_CLASSES) excl[k] = v - cnt[k];
+    if (lane == 63) s_cnt[wv][k] = v;
+  }
+  __syncthreads();
+  int before[SPLIT_CLASSES], total[SPLIT_CLASSES];
+  int n_sparse = 0;
+#pragma unroll
+  for (int k = 0; k < SPLIT_CLASSES; ++k) { before[k] = 0; total[k] = 0; }
+  for (int w = 0; w < SPLIT_THREADS / 64; ++w) {
+#pragma unroll
+    for (int k = 0; k < SPLIT_CLASSES; ++k) {
+      const int v = s_cnt[w][k];
+      before[k] += w < wv ? v : 0;
+      total[k] += v;
+    }
+    n_sparse += s_cnt[w][SPLIT_CLASSES];
+  }
+  const bool runs = (runs_allowed & 1) != 0 && 2 * n_sparse >= n;
+  constexpr int FIRST_LIGHT = 6;  // classes 6, 7, 8: weight <= limit
+  const bool flat = !by_class && !runs;  // one list in the given order
+  int pos[SPLIT_CLASSES];  // where this thread's first simplex of the class goes
+  int n_light = 0, n_heavy = 0;
+#pragma unroll
+  for (int k = 0; k < SPLIT_CLASSES; ++k) {
+    const bool is_light = runs && k >= FIRST_LIGHT;
+    pos[k] = (is_light ? n_light : n_heavy) + before[k] + excl[k];
+    if (is_light) n_light += total[k];
+    else n_heavy += total[k];
+  }
+  if (flat) {
+    for (int i = i0; i < i1; ++i) heavy[i] = i;
+  } else {
+    for (int ib = i0; ib < i1; ib += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ib + u < i1 ? wt(ib + u) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (ib + u < i1) {
+          const int c = cls(v[u]);
+#pragma unroll
+          for (int k = 0; k < SPLIT_CLASSES; ++k) {
+            if (c == k) {
+              int32_t* dst = (runs && k >= FIRST_LIGHT) ? light : heavy;
+              dst[pos[k]] = ib + u;
+              pos[k] += 1;
+            }
+          }
+        }
+      }
+    }
   }
   if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
 }
@@ -1477,9 +1630,16 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
     return fail(FLOODER_E_ARG, "flooder_sweep_cell_faces_f32: bad argument");
   if (!simplex_weight) light_list = heavy_list = nullptr;
   if (simplex_weight) {  // split the simplices (order kept) into the light and the heavy list
-    hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
-                       (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
-                       defer_ctl + 2);
+    const bool long_queue = n_simplices * (int64_t)((R + 255) / 256) >= (int64_t)g_cell_super_min_chunks;
+    if (long_queue) {
+      hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
+                         (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
+                         defer_ctl + 2);
+    } else {
+      hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
+                         (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse,
+                         g_cell_weight_classes ? 2 : 0, light_list, heavy_list, defer_ctl + 2);
+    }
   }
   DeferList dl{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,
                light_list ? defer_ctl + 2 : nullptr, g_cell_super_n0};

@@ -27,7 +27,12 @@ extern int g_cell_super_weight;
 extern int g_cell_super_n0;
 extern int g_cell_super_sparse;
 extern int g_cell_super_min_chunks;
-extern int g_cell_density_grid;  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
+extern int g_cell_density_grid;
+extern int g_cell_chunks_per_block;  // cell sweep: chunks per persistent workgroup that size a short queue's launch
+extern int g_cell_weight_classes;   // cell sweep: the simplex lists in descending weight class (0: in the given order)
+extern int g_cell_listed_first;     // cell sweep, chunk launch: deferred chunks ahead of the heavy simplices
+extern int g_cell_tail_waves;       // cell_tiles = 2: the tail = the last (this percentage of the launch's waves) items
+extern int g_cell_min_grid;          // ... and the smallest launch  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
 extern int g_sorted_ks;
 extern int g_cell_tiles;   // 1: dense chunks hand their tiles to a third launch (one sample per lane) instead of the exhaustive loop (measured slower: off)
 extern int g_curve_bits;

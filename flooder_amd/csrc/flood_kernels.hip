@@ -679,6 +679,26 @@ int flooder_set_option(const char* name, int value) {
     g_cell_super_weight = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_chunks_per_block") == 0 && value >= 1) {
+    g_cell_chunks_per_block = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_weight_classes") == 0 && (value == 0 || value == 1)) {
+    g_cell_weight_classes = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_listed_first") == 0 && (value == 0 || value == 1)) {
+    g_cell_listed_first = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_tail_waves") == 0 && value >= 0) {
+    g_cell_tail_waves = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_min_grid") == 0 && value >= 1) {
+    g_cell_min_grid = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_super_min_chunks") == 0 && value >= 0) {
     g_cell_super_min_chunks = value;
     return FLOODER_OK;
@@ -699,7 +719,7 @@ int flooder_set_option(const char* name, int value) {
     g_sorted_ks = value;
     return FLOODER_OK;
   }
-  if (name && strcmp(name, "cell_tiles") == 0 && (value == 0 || value == 1)) {
+  if (name && strcmp(name, "cell_tiles") == 0 && value >= 0 && value <= 2) {
     g_cell_tiles = value;
     return FLOODER_OK;
   }

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for wl in ${@:-cfg2}; do
 OUT=$R/gpurun_out/tr_$wl; rm -rf $OUT; mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline --no-cold ${EXTRA_BENCH:-} > $OUT/bench.json 2> $OUT/err.txt
 python3 - $OUT $wl <<'PY'
 import sys, glob, csv
 f = glob.glob(sys.argv[1] + '/trace/**/*kernel_trace.csv', recursive=True)[0]

@@ -4,7 +4,6 @@ import sys, torch, numpy as np
 sys.path.insert(0, '.')
 import flooder_amd as fa
 from flooder_amd import _native, core
-core.CELL_SUPER = False  # (the per-chunk records below assume one work item per chunk)
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 torch.manual_seed(42)
@@ -27,16 +26,18 @@ for _ in range(3):
     stats.zero_()
     core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
 torch.cuda.synchronize()
-t = stats[64:64 + 2 * 8192].cpu().numpy().reshape(-1, 2)
-t = t[t[:, 1] > 0]
-if len(t) == 0:
-    t = np.zeros((1, 2), dtype=np.int64) + 1
-t0, t1 = t[:, 0].min(), t[:, 1].max()
-end = np.sort(t[:, 1] - t0)
-print(f"{which} W={W}: {len(t)} waves, span {t1 - t0} ticks (10 ns); wave end percentiles: " +
-      " ".join(f"p{p}={np.percentile(end, p):.0f}" for p in (1, 10, 25, 50, 75, 90, 99, 100)))
-print(f"mean end {end.mean():.0f} = {end.mean() / (t1 - t0) * 100:.1f}% of the span: a perfectly balanced queue would take ~{end.mean():.0f} ticks "
-      f"({(1 - end.mean() / (t1 - t0)) * 100:.1f}% of the kernel is tail)")
+tall = stats[64:64 + 2 * 8192].cpu().numpy().reshape(-1, 2)
+g0 = tall[tall[:, 1] > 0][:, 0].min() if (tall[:, 1] > 0).any() else 0
+for name, t in (("runs of four", tall[:4096]), ("chunk by chunk", tall[4096:])):
+    t = t[t[:, 1] > 0]
+    if len(t) == 0:
+        continue
+    t0, t1 = t[:, 0].min(), t[:, 1].max()
+    end = np.sort(t[:, 1] - t0)
+    print(f"{which} W={W} {name}: {len(t)} waves, first start at {t0 - g0} ticks, span {t1 - t0} ticks (10 ns); wave end percentiles: " +
+          " ".join(f"p{p}={np.percentile(end, p):.0f}" for p in (1, 10, 25, 50, 75, 90, 99, 100)))
+    print(f"  mean end {end.mean():.0f} = {end.mean() / (t1 - t0) * 100:.1f}% of the span: a perfectly balanced queue would take ~{end.mean():.0f} ticks "
+          f"({(1 - end.mean() / (t1 - t0)) * 100:.1f}% of the launch is tail)")
 
 # the finish's last pass (its stats slice starts at word 9 of the buffer: 9 + 64 + 16384)
 f = stats[9 + 64 + 16384: 9 + 64 + 16384 + 3 * 4096].cpu().numpy().reshape(-1, 3)
