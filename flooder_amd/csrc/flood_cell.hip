@@ -1424,14 +1424,26 @@ constexpr int SPLIT_THREADS = 256;  // (1024 threads leave 128 VGPRs each: the c
 constexpr int SPLIT_CLASSES = 9;  // weight > limit x 32, 16, 8, 4, 2, 1, 1/2, 1/4, rest
 // (a stable counting sort: every thread owns a run of consecutive simplices, counts its classes, one block-wide
 // exclusive scan per class - wave scans + partial sums through LDS - and every thread writes its run: two barriers)
+// reorder != 0: the heavy list of split_simplices_kernel (counts[1] entries) is put into class order IN PLACE (its
+// entries are staged in LDS first; longer than the stage: left as it is) and the counts are not touched.
 __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float* __restrict__ weight, int n, float limit,
-                                                               float sparse_limit, int runs_allowed,
+                                                               float sparse_limit, int runs_allowed, int reorder,
                                                                int32_t* __restrict__ light, int32_t* __restrict__ heavy,
                                                                int32_t* __restrict__ counts) {
   __shared__ int s_cnt[SPLIT_THREADS / 64][SPLIT_CLASSES + 1];
+  constexpr int ID_LDS = 7680;
+  __shared__ int s_id[ID_LDS];
+  if (reorder) {
+    n = counts[1];
+    // (no light list: a cloud too dense for runs, every simplex in the given order - measured: reordering those
+    // costs cfg 3 20 us and gains nothing)
+    if (n > ID_LDS || n < 2 || counts[0] == 0) return;
+    for (int i = threadIdx.x; i < n; i += SPLIT_THREADS) s_id[i] = heavy[i];
+    __syncthreads();
+  }
   // the weights come in coalesced and are read back run by run from LDS (a run of consecutive simplices per thread
   // straight from memory is a chain of dependent cache misses: 34 us for 6000 simplices instead of 8)
-  constexpr int W_LDS = 15360;
+  constexpr int W_LDS = 7680;
   __shared__ float s_w[W_LDS];
   const bool staged = n <= W_LDS;
   if (staged) {
@@ -1440,7 +1452,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = base + u * SPLIT_THREADS + (int)threadIdx.x;
-        v[u] = i < n ? weight[i] : 0.f;
+        v[u] = i < n ? weight[reorder ? s_id[i] : i] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1450,7 +1462,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
     }
     __syncthreads();
   }
-  auto wt = [&](int i) -> float { return staged ? s_w[i] : weight[i]; };
+  auto wt = [&](int i) -> float { return staged ? s_w[i] : weight[i]; };  // (reorder: always staged)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool by_class = (runs_allowed & 2) != 0;
   auto cls = [&](float w) -> int {  // 0 = heaviest
@@ -1523,7 +1535,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
     else n_heavy += total[k];
   }
   if (flat) {
-    for (int i = i0; i < i1; ++i) heavy[i] = i;
+    for (int i = i0; i < i1; ++i) heavy[i] = reorder ? s_id[i] : i;
   } else {
     for (int ib = i0; ib < i1; ib += 8) {
       float v[8];
@@ -1537,7 +1549,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
           for (int k = 0; k < SPLIT_CLASSES; ++k) {
             if (c == k) {
               int32_t* dst = (runs && k >= FIRST_LIGHT) ? light : heavy;
-              dst[pos[k]] = ib + u;
+              dst[pos[k]] = reorder ? s_id[ib + u] : ib + u;
               pos[k] += 1;
             }
           }
@@ -1545,7 +1557,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
       }
     }
   }
-  if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
+  if (threadIdx.x == 0 && !reorder) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
 }
 
 // every leaf of the box tree (16 consecutive points of the curve order) adds its point count to the fine cell under
@@ -1635,10 +1647,16 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
       hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
                          (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
                          defer_ctl + 2);
+      // ... and the heavy list heaviest first: its densest simplices hold the chunks that one wave evaluates
+      // exhaustively for 150 us and more, and the last of them to start was the tail of the chunk launch
+      if (g_cell_weight_classes)
+        hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
+                           (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, 2, 1, light_list,
+                           heavy_list, defer_ctl + 2);
     } else {
       hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
                          (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse,
-                         g_cell_weight_classes ? 2 : 0, light_list, heavy_list, defer_ctl + 2);
+                         g_cell_weight_classes ? 2 : 0, 0, light_list, heavy_list, defer_ctl + 2);
     }
   }
   DeferList dl{defer_list, defer_c, defer_list ? defer_ctl : nullptr, light_list, heavy_list,

@@ -7,7 +7,7 @@ wl=$1
 for lib in $2; do
   if [ "$lib" != product ]; then export FLOODER_HIP_LIB=$R/gpurun_in/$lib.so; else unset FLOODER_HIP_LIB; fi
   OUT=$R/gpurun_out/lt_${wl}_$lib; rm -rf $OUT; mkdir -p $OUT
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-cold > $OUT/bench.json 2> $OUT/err.txt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-cold ${EXTRA_BENCH:-} > $OUT/bench.json 2> $OUT/err.txt
   echo "== $wl $lib"
   python3 - $OUT <<'PY'
 import sys, glob, csv
