@@ -299,6 +299,12 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * in a dense region no run of four chunks fits the stage - and are worked off chunk by chunk by the second.  When
  * fewer than half of the simplices are sparse (weight <= option "cell_super_sparse", 600) the first launch gets no
  * work at all and the second sweeps everything in plain order.
+ * Queue order (option "cell_weight_classes", default 1): the heavy list of a long queue - and every simplex of a short
+ * one (fewer than "cell_super_min_chunks" chunks: a rank's share, no runs) - is taken in descending weight class
+ * (powers of two around "cell_super_weight", the given order kept inside a class), so that the densest simplices -
+ * their chunks overflow the stage and keep ONE wave busy for 150 us and more - start first; the chunks the runs
+ * deferred come ahead of the heavy simplices ("cell_listed_first", default 1).  A short queue is launched with one
+ * workgroup per "cell_chunks_per_block" (12) chunks, at least "cell_min_grid" (384).
  * flag_key / flag_hist (both NULL, or as many uint32 as flag_list holds / 8192 zeroed int32; need top): the probe's
  * bound of every flagged tile, parallel to flag_list, and a histogram of the bounds' top 12 bits - with them the
  * finish works the tiles off longest search first.
