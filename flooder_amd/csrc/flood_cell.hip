@@ -44,6 +44,8 @@ struct DensGrid {
   const int32_t* grid = nullptr;  // G^DIM point counts
   const float* box = nullptr;     // the cloud's box (16 floats: [0:dim] min, [8:8+dim] max), device memory
   int min_count = 16;             // the grid is used where every probed cell holds at least this many points
+  int one_pass = 125;             // (rides along: single-pass exhaustive evaluation of dense chunks, see the kernel;
+                                  // percent of the give-up cap the extrapolated kept set may reach, 0 = off)
 };
 template <int DIM>
 struct DensCfg {
@@ -874,6 +876,59 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       // 2a. classify every candidate ONCE (keep? which cell?), count per cell, remember the kept ones
       int n_keep = 0;  // wave-uniform: the loop has a uniform trip count
       const int n_cand = n_leaves * LEAF;
+      // Single-pass exhaustive evaluation (per-chunk launch): the moment the kept set outgrows the stage the pass
+      // stops recording and starts EVALUATING - the kept points of the current and all following candidate rows are
+      // compacted into the first three quarters of the stage (the last quarter still holds the kept list recorded so
+      // far) and every lane runs its samples against each staged batch; the recorded ones are fetched again at the end
+      // (<= 480 rows).  The candidates of a dense chunk - 7 to 12 thousand rows for 2 to 3 thousand kept points -
+      // are streamed and classified once instead of twice.
+      bool one_pass = false;
+      int n_st = 0, n_rec = 0, ib_resume = 0;
+      bool decided = false;
+      constexpr int CAPE = CAPW - CAPW / 4 - 4;  // stage entries below the kept-list alias (and four of padding)
+      static_assert(CAPE >= 64 * UNR + 64, "a batch of candidate rows fits the part of the stage below the kept list");
+      auto flush_stage = [&]() {
+        if (lane < 4) s_pts[n_st + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+        wave_lds_sync();
+        for (int j = 0; j < n_st; j += 4) {
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
+#pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            float bb = best[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float t0 = p[i][0] - x[u].x;
+              float d2 = t0 * t0;
+              t0 = p[i][1] - x[u].y;
+              d2 = __builtin_fmaf(t0, t0, d2);
+              if constexpr (DIM == 3) {
+                t0 = p[i][2] - x[u].z;
+                d2 = __builtin_fmaf(t0, t0, d2);
+              }
+              bb = __builtin_fminf(bb, d2);
+            }
+            best[i] = bb;
+          }
+        }
+        if (stats) n_pairs += (unsigned long long)n_st * SPL;
+        n_st = 0;
+        wave_lds_sync();
+      };
+      auto stage_row = [&](const float (&x)[DP], bool k) {
+        const unsigned long long m = __ballot(k);
+        if (k) {
+          float4 v;
+          v.x = x[0];
+          v.y = x[1];
+          v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
+          v.w = 0.f;
+          s_pts[n_st + lane_rank(m)] = v;
+        }
+        n_st += __popcll(m);
+        return __popcll(m);
+      };
       for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
         float x[UNR][DP];
         bool keep[UNR];
@@ -884,6 +939,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           const uint32_t row = keep[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
           load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
         }
+        const int n_before = n_keep;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int idx = ib + u * 64 + lane;
@@ -904,6 +960,49 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             }
           }
           n_keep += __popcll(m);
+        }
+        if constexpr (!TILES) {
+          if (n_keep > CAPW && !decided) {  // the kept set has just outgrown the stage
+            decided = true;
+            if constexpr (SUPER) {
+              break;  // (a run that does not fit the stage is deferred: no need to count on)
+            } else if (dg.one_pass && !dl.tile_list && attempt < exh_tries) {
+              // will the kept set be given up anyway (the cap below)?  Extrapolate from the share of the candidates
+              // seen so far; a chunk that is likely to be dropped only counts on, as before
+              const int seen = ib + 64 * UNR < n_cand ? ib + 64 * UNR : n_cand;
+              const float est = (float)n_keep * (float)n_cand / (float)seen;
+              const float cap = (float)n0 * 8.f >= est ? (float)exh_dense : (float)exh_sparse;
+              if (est * 100.f <= (float)dg.one_pass * cap) {
+                // switch: the first CAPW kept points are on record (last quarter of the stage), some of them from
+                // this batch; the batch is streamed again below - a point evaluated twice does no harm to a minimum
+                one_pass = true;
+                n_rec = CAPW;
+                ib_resume = ib;
+                n_keep = n_before;
+                wave_lds_sync();
+                break;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (!SUPER && !TILES) {
+        if (one_pass) {  // the rest of the candidates: classified, staged and evaluated as they come
+          for (int ib = ib_resume; ib < n_cand; ib += 64 * UNR) {
+            float x[UNR][DP];
+            bool keep[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+              const int idx = ib + u * 64 + lane;
+              keep[u] = idx < n_cand;
+              const uint32_t row = keep[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+              load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
+            }
+            if (n_st + 64 * UNR > CAPE) flush_stage();
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) n_keep += stage_row(x[u], keep[u] && keep_point(x[u]));
+            if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) break;  // (hopeless after all: decided below)
+          }
         }
       }
       PHASE(5);
@@ -1017,6 +1116,25 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         // runs its open samples against the staged batch with broadcast LDS reads.
         wave_lds_sync();
         ++g_brute;
+        if (one_pass) {
+          // ... the rows that were recorded before the switch (their slots are still in the last quarter of the stage)
+          for (int h0 = 0; h0 < n_rec; h0 += 64 * UNR) {
+            int ent[UNR];
+            float x[UNR][DP];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+              const int k = h0 + u * 64 + lane;
+              ent[u] = k < n_rec ? s_keep[k] : -1;
+              const int idx = ent[u] < 0 ? 0 : ent[u] >> 10;
+              const uint32_t row = (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF);
+              load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
+            }
+            if (n_st + 64 * UNR > CAPE) flush_stage();
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) stage_row(x[u], ent[u] >= 0);
+          }
+          if (n_st > 0) flush_stage();
+        } else {
         int n_st = 0;
         auto flush = [&]() {
 #ifdef FLOODER_PHASE_TIMERS
@@ -1088,6 +1206,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           }
         }
         if (n_st > 0) flush();
+        }
         bool any_open = false;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
@@ -1317,6 +1436,7 @@ struct CellOp {
     if constexpr (DIM == 2 || DIM == 3) {
       if (!g_cell_density_grid) dg = DensGrid{};
       dg.min_count = g_cell_density_grid;
+      dg.one_pass = g_cell_one_pass;
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2

@@ -733,8 +733,9 @@ struct FpsBatchedOp {
     // small clouds: 64-row buckets (more waves to spread a landmark's neighbourhood over) and a late switch (a
     // brute step over an L2-resident cloud costs about as much as a launch); large clouds: 256-row buckets
     const int rpl = batched_rpl(n);
-    // (measured: 1 M / 1 k 2.92 ms at 96, 3.15 at 32, 3.07 at 256; 16 M / 4 k 19.3 ms at 8, 20.2 at 32, 29.9 at 256)
-    int k0 = g_fps_switch ? g_fps_switch : (n >= (4 << 20) ? 8 : 96);
+    // (measured: 1 M / 1 k 2.44 ms at 64, 2.46 at 32, 2.52 at 96 and 128, 2.63 at 4; 16 M / 4 k 13.1 ms at 4, 13.2 at 8,
+    // 14.3 at 32, 19.7 at 128)
+    int k0 = g_fps_switch ? g_fps_switch : (n >= (4 << 20) ? 8 : 64);
     if (k0 < 2) k0 = 2;  // (the start point is applied by a brute-force step)
     if (rpl == 4)
       return run_batched<DIM, 4>(pts, n, ld, pts_sorted, order, n_lms, start, k0, out_idx, minsq, box, keys, bcoord, best,

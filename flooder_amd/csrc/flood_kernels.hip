@@ -695,6 +695,10 @@ int flooder_set_option(const char* name, int value) {
     g_cell_tail_waves = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_one_pass") == 0 && value >= 0 && value <= 100000) {
+    g_cell_one_pass = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_min_grid") == 0 && value >= 1) {
     g_cell_min_grid = value;
     return FLOODER_OK;

@@ -305,6 +305,10 @@ int flooder_sweep_cell_f32(const float* pts_sorted, int64_t n_pts, int dim, cons
  * their chunks overflow the stage and keep ONE wave busy for 150 us and more - start first; the chunks the runs
  * deferred come ahead of the heavy simplices ("cell_listed_first", default 1).  A short queue is launched with one
  * workgroup per "cell_chunks_per_block" (12) chunks, at least "cell_min_grid" (384).
+ * Option "cell_one_pass" (default 125, 0 = off): a chunk of the per-chunk launch whose kept points outgrow the stage
+ * stops recording and evaluates them as they come, so that its candidates are streamed and classified once instead of
+ * twice - unless the kept set, extrapolated from the share of the candidates seen so far, exceeds this percentage of
+ * the cap ("cell_exh_dense" / "cell_exh_sparse") beyond which the chunk is left to the finish anyway.
  * flag_key / flag_hist (both NULL, or as many uint32 as flag_list holds / 8192 zeroed int32; need top): the probe's
  * bound of every flagged tile, parallel to flag_list, and a histogram of the bounds' top 12 bits - with them the
  * finish works the tiles off longest search first.
