@@ -202,6 +202,34 @@ def test_dense_chunk_tile_launch_changes_nothing(dev):
         assert on == off
 
 
+def test_cell_sweep_queue_and_pass_options_change_nothing(dev):
+    """Round-3 scheduling switches of the cell sweep: the single pass over the candidates of a dense chunk
+    ("cell_one_pass": off / default / always, i.e. even where the chunk is given up afterwards), the weight-class
+    order of the simplex lists, the deferred chunks ahead of the heavy ones, launch sizing of a short queue.  They
+    change the order and the amount of work, never a value: a surface cloud (overflowing chunks), a dense Gaussian
+    core (exhaustive chunks) and a cloud large enough for runs of four."""
+    lib = _native.load()
+    cases = ((fo.noisy_torus(400_000, seed=3), 150, 30),
+             (np.random.default_rng(4).normal(size=(500_000, 3)).astype(np.float32) * 0.05, 40, 30),
+             (np.random.default_rng(6).normal(size=(600_000, 3)).astype(np.float32), 700, 30))
+    for pts, n_l, ppe in cases:
+        tp = torch.as_tensor(pts, device=dev)
+        tl = fa.generate_landmarks(tp, n_l, start_idx=0)
+        ref = fa.flood_complex(tp, tl, points_per_edge=ppe)
+        for opts in ({b"cell_one_pass": 0}, {b"cell_one_pass": 100000}, {b"cell_weight_classes": 0},
+                     {b"cell_listed_first": 0}, {b"cell_chunks_per_block": 48, b"cell_min_grid": 64},
+                     {b"cell_super_min_chunks": 0}):
+            try:
+                for k, v in opts.items():
+                    assert lib.flooder_set_option(k, v) == 0
+                got = fa.flood_complex(tp, tl, points_per_edge=ppe)
+            finally:
+                for k, v in ((b"cell_one_pass", 125), (b"cell_weight_classes", 1), (b"cell_listed_first", 1),
+                             (b"cell_chunks_per_block", 12), (b"cell_min_grid", 384), (b"cell_super_min_chunks", 49152)):
+                    lib.flooder_set_option(k, v)
+            assert got == ref, opts
+
+
 def test_landmarks_outside_cloud_match_cpu_path(dev):
     """Landmarks that are NOT points of the cloud: the culled sweep still returns the exact value of
     the reference CPU path (the reference's own GPU path is only a bound there)."""
