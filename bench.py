@@ -571,7 +571,10 @@ def main():
                     "traffic_frac_of_algorithmic": None if not traffic else round(traffic / max(dom_bytes, 1), 4),
                     "note": "algorithmic bytes = reference candidate pairs P x 4*dim + vertices + weights + result "
                             "((S,F) face values on the fused path, (S,R) minima where materialised), apportioned to "
-                            "a kernel by the share of (simplex, sample) units it resolves"},
+                            "a kernel by the share of (simplex, sample) units it resolves"
+                            + ("; frac > 1: the reference's candidate rows are priced, which the culled sweep never "
+                               "has to move (that is what the culling is for) - the binding figure is the valu one"
+                               if dom_rec["hbm_frac"] > 1.0 else "")},
             "step": {"algorithmic_bytes": int(alg_bytes), "ms": round(ms_per_step, 4),
                      "achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5)},
         },
