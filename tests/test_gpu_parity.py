@@ -230,6 +230,24 @@ def test_cell_sweep_queue_and_pass_options_change_nothing(dev):
             assert got == ref, opts
 
 
+def test_many_simplices_short_queue_cell_equals_tree(dev):
+    """A short queue (few chunks: one per simplex here) of MANY simplices: the weight-class order of the queue is
+    built from global memory instead of the LDS stage (more than 7680 simplices), and every simplex must still be
+    swept exactly once: cell sweep == tree sweep bit for bit, and a sample of the triangles against the kd-tree."""
+    rng = np.random.default_rng(12)
+    pts = rng.normal(size=(200_000, 2)).astype(np.float32)
+    tp = torch.as_tensor(pts, device=dev)
+    tl = fa.generate_landmarks(tp, 6000, start_idx=0)
+    a = fa.flood_complex(tp, tl, points_per_edge=4, method="cell", return_simplex_tree=True)
+    b = fa.flood_complex(tp, tl, points_per_edge=4, method="bvh", return_simplex_tree=True)
+    n_tri = len(a.simplices_of_dimension(2))
+    assert n_tri > 7680
+    for d in range(3):
+        assert np.array_equal(a.filtrations_of_dimension(d), b.filtrations_of_dimension(d)), d
+    pick = np.sort(rng.choice(n_tri, size=600, replace=False))
+    assert_tree_matches_kdtree(a, pts, tl.cpu().numpy(), 4, 2, "many simplices, short queue", pick_top=pick, lower=False)
+
+
 def test_landmarks_outside_cloud_match_cpu_path(dev):
     """Landmarks that are NOT points of the cloud: the culled sweep still returns the exact value of
     the reference CPU path (the reference's own GPU path is only a bound there)."""
