@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
 
-HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip"]
+HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
 HOST_SOURCES = ["persistence.cpp"]
 
 
@@ -45,16 +45,35 @@ def build_hip(force: bool = False, verbose: bool = False, out: str = None) -> st
 
 
 def _build_hip_to(HIP_LIB: str, force: bool, verbose: bool) -> str:
+    """One object per source (compiled in parallel, kept under csrc/_obj keyed by the flags), then one link."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp"),
-                   os.path.join(CSRC, "flood_bvh.hpp")]
-    if not force and _newer(HIP_LIB, deps):
+    hdrs = [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp"),
+            os.path.join(CSRC, "flood_bvh.hpp")]
+    if not force and _newer(HIP_LIB, srcs + hdrs):
         return HIP_LIB
-    cmd = [
-        _hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-        "-DFLOODER_BUILD", "-Wl,-rpath,/opt/rocm/lib", *os.environ.get("FLOODER_HIPCC_FLAGS", "").split(),
-        "-o", HIP_LIB + ".tmp",
-    ] + srcs
+    extra = os.environ.get("FLOODER_HIPCC_FLAGS", "").split()
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DFLOODER_BUILD", *extra]
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    obj_dir = os.path.join(CSRC, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(obj_dir, f"{os.path.basename(src)}.{tag}.o")
+        if force or not _newer(obj, [src] + hdrs):
+            cmd = [hipcc, *flags, "-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", HIP_LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -701,6 +701,78 @@ def _sample_order_bisect(w: np.ndarray) -> np.ndarray:
     return np.concatenate(out)
 
 
+WIT_MAX_COARSE = 256     # FLOODER_WIT_MAX_COARSE
+WIT_MAX_ROWS = 8192      # FLOODER_WIT_MAX_ROWS
+WIT_MIN_ROWS = 512       # below this a simplex is too small for a coarse level to pay
+_WIT_PLAN_CACHE: Dict[tuple, Optional[tuple]] = {}
+
+
+def witness_plan(weights: torch.Tensor, perm: np.ndarray) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """Coarse level of the witness sweep (csrc/flood_wit.hip) for one weight table: ``(coarse_rows, parents)`` in
+    SWEEP order (``perm``: sweep position -> original row).  ``coarse_rows``: the positions of at most
+    ``WIT_MAX_COARSE`` coarse samples, padded with -1; ``parents``: per position four coarse slots (8 bits each) - the
+    coarse samples nearest to it in the regular-simplex embedding of the weights; a coarse sample comes first among
+    its own parents.  Lattice weights (``generate_grid``): on every face of the simplex the lattice points whose
+    barycentric numerators are congruent to 1 modulo M in all but the last coordinate of the face, M the smallest
+    stride that fits; other weight tables (``generate_uniform_weights``): farthest-point samples of the rows.
+    Any choice is valid - the bound of a sample is the distance to a real point of the cloud whoever found it -; it
+    only decides how many samples survive the bound.  None: table too small or too large for the kernel."""
+    w = weights.detach().cpu().numpy().astype(np.float64)
+    R, k1 = w.shape
+    if R < WIT_MIN_ROWS or R > WIT_MAX_ROWS or k1 < 2:
+        return None
+    key = (R, k1, hash(w.tobytes()), hash(np.asarray(perm).tobytes()))
+    if key in _WIT_PLAN_CACHE:
+        return _WIT_PLAN_CACHE[key]
+    from scipy.spatial import cKDTree
+
+    corners = np.eye(k1) - 1.0 / k1
+    basis = np.linalg.qr(corners.T)[0][:, :k1 - 1]
+    X = w @ (corners @ basis)
+    pos = w[w > 1e-9]
+    m = int(round(1.0 / pos.min())) if pos.size else 0
+    lat = np.rint(w * m).astype(np.int64) if m > 0 else None
+    coarse = None
+    if lat is not None and m <= 4096 and np.abs(w * m - lat).max() < 1e-3 and (lat.sum(axis=1) == m).all():
+        nz = lat > 0
+        last = (k1 - 1) - np.argmax(nz[:, ::-1], axis=1)          # last non-zero coordinate of every row
+        free = nz & (np.arange(k1)[None, :] != last[:, None])    # ... the others decide
+        for M in range(2, 65):
+            ok = np.where(free, lat % M == 1 % M, True).all(axis=1)
+            if ok.sum() <= WIT_MAX_COARSE:
+                coarse = np.nonzero(ok)[0]
+                break
+    if coarse is None or coarse.size < 4:   # no lattice: farthest-point samples
+        n_c = int(min(WIT_MAX_COARSE, max(16, R // 16)))
+        dmin = np.full(R, np.inf)
+        cur, picked = 0, []
+        for _ in range(n_c):
+            picked.append(cur)
+            dmin = np.minimum(dmin, ((X - X[cur]) ** 2).sum(axis=1))
+            cur = int(np.argmax(dmin))
+        coarse = np.array(sorted(set(picked)), dtype=np.int64)
+    inv = np.empty(R, dtype=np.int64)
+    inv[np.asarray(perm)] = np.arange(R)
+    coarse = coarse[np.argsort(inv[coarse], kind="stable")]        # slots in sweep order
+    kq = min(4, coarse.size)
+    _, nn = cKDTree(X[coarse]).query(X, k=kq)
+    nn = nn.reshape(R, kq)
+    if kq < 4:
+        nn = np.concatenate([nn] + [nn[:, :1]] * (4 - kq), axis=1)
+    slot_of = np.full(R, -1, dtype=np.int64)
+    slot_of[coarse] = np.arange(coarse.size)
+    own = slot_of >= 0                                             # (ties aside, a coarse row is its own nearest)
+    nn[own, 0] = slot_of[own]
+    par = (nn[:, 0] | (nn[:, 1] << 8) | (nn[:, 2] << 16) | (nn[:, 3] << 24)).astype(np.uint32)
+    rows = np.full(WIT_MAX_COARSE, -1, dtype=np.int32)
+    rows[:coarse.size] = inv[coarse]
+    out = (rows, np.ascontiguousarray(par[np.asarray(perm)]), int(coarse.size))
+    if len(_WIT_PLAN_CACHE) >= 32:
+        _WIT_PLAN_CACHE.clear()
+    _WIT_PLAN_CACHE[key] = out
+    return out
+
+
 class SamplePlan:
     """Device-resident sample weights in sweep order (``sample_order``) plus the face table remapped to that order
     and, per row, the bit mask of the faces it lies on (the fused face maxima); built once per dimension pass,
@@ -726,6 +798,11 @@ class SamplePlan:
             for f in range(n_faces):
                 memb_all[inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]] |= np.uint32(1 << f)
             self.memb_all = torch.as_tensor(memb_all.view(np.int32), device=dev)
+        # coarse level of the witness sweep (None: not applicable to this table)
+        self.wit = None
+        wp = witness_plan(weights, perm) if self.memb_all is not None else None
+        if wp is not None:
+            self.wit = (torch.as_tensor(wp[0], device=dev), torch.as_tensor(wp[1].view(np.int32), device=dev), wp[2])
 
 
 def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: torch.Tensor, weights: torch.Tensor,
@@ -847,6 +924,7 @@ SHARED_FACE_SLOTS = True   # one running maximum per distinct face of the comple
 FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does not fit is finished by one wave)
 CELL_DENSITY_GRID = True   # PointIndex carries a density grid; the cell sweep reads its first cell size from it
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
+CELL_WITNESS = True  # sparse simplices go to the witness sweep first (whole simplex per wave, coarse samples + bounds)
 
 
 def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
@@ -900,7 +978,12 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # [48:] histogram of the flagged tiles' bounds and the cursors of the finish's counting sort
         # (one zero fill for everything that starts at zero: top | ctl | face_bits)
         # (the sharded work-queue heads of the sweep's launches sit in front: QUEUE_WORDS each)
-        zeroed = torch.zeros(6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots, dtype=torch.int32, device=dev)
+        use_wit = CELL_WITNESS and CELL_SUPER and CELL_PROBE and plan.wit is not None and index.dim in (2, 3)
+        zeroed = torch.zeros((1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots,
+                             dtype=torch.int32, device=dev)
+        if use_wit:
+            qwit = zeroed[:QUEUE_WORDS]
+            zeroed = zeroed[QUEUE_WORDS:]
         qbuf = zeroed[:3 * QUEUE_WORDS]
         fctl = zeroed[3 * QUEUE_WORDS:6 * QUEUE_WORDS + 24]   # finish: 24 control words, then its sharded queue heads
         zeroed = zeroed[6 * QUEUE_WORDS + 24:]
@@ -922,6 +1005,15 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
                                                          k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
         with _span(timer, "sweep"):
+            if use_wit:
+                wst = stats[16:28] if stats is not None and stats.numel() >= 28 else None
+                _native.check(lib.flooder_sweep_witness_f32(
+                    _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                    _native.ptr(w_perm), k1, R, S, _native.ptr(plan.wit[0]), plan.wit[2], _native.ptr(plan.wit[1]),
+                    qwit.data_ptr(), _native.ptr(d2), _native.ptr(plan.memb_all), F, _native.ptr(face_bits),
+                    _native.ptr(slot_t), _native.ptr(flags[0]), ctl[1:].data_ptr(), _native.ptr(flags[1]),
+                    ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list), fctl[3:].data_ptr(),
+                    _native.ptr(wgt), _native.ptr(planes), _native.ptr(wst), st), "flooder_sweep_witness_f32")
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),

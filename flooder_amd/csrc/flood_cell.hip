@@ -1484,6 +1484,20 @@ struct CellOp {
 
 }  // namespace
 
+namespace flooder {
+int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st) {
+  if (dim == 2)
+    hipLaunchKernelGGL((simplex_planes_kernel<2>), dim3((unsigned)((n_simplices + 255) / 256)), dim3(256), 0, st, verts, k1,
+                       n_simplices, tab);
+  else if (dim == 3)
+    hipLaunchKernelGGL((simplex_planes_kernel<3>), dim3((unsigned)((n_simplices + 255) / 256)), dim3(256), 0, st, verts, k1,
+                       n_simplices, tab);
+  else
+    return fail(FLOODER_E_ARG, "simplex planes: only dim 2 and 3");
+  return check_launch("simplex_planes");
+}
+}  // namespace flooder
+
 namespace {
 
 // Order-preserving split of 0 .. n-1 by weight[i] <= limit: one block, ballot scans (n is a few thousand).
@@ -1492,42 +1506,46 @@ namespace {
 __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __restrict__ weight, int n, float limit,
                                                                float sparse_limit, int32_t* __restrict__ light,
                                                                int32_t* __restrict__ heavy, int32_t* __restrict__ counts) {
-  __shared__ int s_cnt[16];
-  __shared__ int s_sparse;
+  // (a negative weight marks a simplex the witness sweep has already handled: on neither list)
+  __shared__ int s_cl[16], s_ch[16];
+  __shared__ int s_sparse, s_act;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_sparse = 0;
+  if (threadIdx.x == 0) { s_sparse = 0; s_act = 0; }
   __syncthreads();
-  int mine = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) mine += weight[i] <= sparse_limit ? 1 : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-  if (lane == 0) atomicAdd(&s_sparse, mine);
-  __syncthreads();
-  if (2 * s_sparse < n) {  // every simplex heavy, in the given order
-    for (int i = threadIdx.x; i < n; i += 1024) heavy[i] = i;
-    if (threadIdx.x == 0) { counts[0] = 0; counts[1] = n; counts[2] = 1; }
-    return;
+  int mine = 0, act = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float w = weight[i];
+    mine += (w >= 0.f && w <= sparse_limit) ? 1 : 0;
+    act += w >= 0.f ? 1 : 0;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mine += __shfl_xor(mine, o);
+    act += __shfl_xor(act, o);
+  }
+  if (lane == 0) { atomicAdd(&s_sparse, mine); atomicAdd(&s_act, act); }
+  __syncthreads();
+  const bool all_heavy = 2 * s_sparse < s_act;  // every simplex heavy, in the given order
   int n_light = 0, n_heavy = 0;  // (block-uniform running totals)
   for (int base = 0; base < n; base += 1024) {
     const int i = base + threadIdx.x;
-    const bool in = i < n;
-    const bool is_light = in && weight[i] <= limit;
-    const unsigned long long m = __ballot(is_light);
-    if (lane == 0) s_cnt[wv] = __popcll(m);
+    const float w = i < n ? weight[i] : -1.f;
+    const bool is_light = w >= 0.f && !all_heavy && w <= limit;
+    const bool is_heavy = w >= 0.f && !is_light;
+    const unsigned long long ml = __ballot(is_light), mh = __ballot(is_heavy);
+    if (lane == 0) { s_cl[wv] = __popcll(ml); s_ch[wv] = __popcll(mh); }
     __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
-      const int c = s_cnt[w];
-      before += w < wv ? c : 0;
-      total += c;
+    int bl = 0, tl = 0, bh = 0, th = 0;
+    for (int w_ = 0; w_ < 16; ++w_) {
+      bl += w_ < wv ? s_cl[w_] : 0;
+      tl += s_cl[w_];
+      bh += w_ < wv ? s_ch[w_] : 0;
+      th += s_ch[w_];
     }
-    const int rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-    if (is_light) light[n_light + rank] = i;
-    else if (in) heavy[n_heavy + (threadIdx.x - rank)] = i;
-    const int valid = n - base < 1024 ? n - base : 1024;
-    n_light += total;
-    n_heavy += valid - total;
+    if (is_light) light[n_light + bl + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0))] = i;
+    if (is_heavy) heavy[n_heavy + bh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0))] = i;
+    n_light += tl;
+    n_heavy += th;
     __syncthreads();
   }
   if (threadIdx.x == 0) { counts[0] = n_light; counts[1] = n_heavy; counts[2] = 1; }
@@ -1585,7 +1603,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
   auto wt = [&](int i) -> float { return staged ? s_w[i] : weight[i]; };  // (reorder: always staged)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool by_class = (runs_allowed & 2) != 0;
-  auto cls = [&](float w) -> int {  // 0 = heaviest
+  auto cls = [&](float w) -> int {  // 0 = heaviest; -1: handled by the witness sweep already (on no list)
+    if (w < 0.f) return -1;
     if (!by_class) return w > limit ? 5 : 6;
     int c = 0;
     float t = limit * 32.f;
@@ -1612,7 +1631,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
         const int c = cls(v[u]);
 #pragma unroll
         for (int k = 0; k < SPLIT_CLASSES; ++k) cnt[k] += c == k ? 1 : 0;
-        cnt[SPLIT_CLASSES] += v[u] <= sparse_limit ? 1 : 0;
+        cnt[SPLIT_CLASSES] += (v[u] >= 0.f && v[u] <= sparse_limit) ? 1 : 0;
       }
     }
   }
@@ -1642,9 +1661,12 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
     }
     n_sparse += s_cnt[w][SPLIT_CLASSES];
   }
-  const bool runs = (runs_allowed & 1) != 0 && 2 * n_sparse >= n;
+  int n_act = 0;  // simplices still to be swept
+#pragma unroll
+  for (int k = 0; k < SPLIT_CLASSES; ++k) n_act += total[k];
+  const bool runs = (runs_allowed & 1) != 0 && 2 * n_sparse >= n_act;
   constexpr int FIRST_LIGHT = 6;  // classes 6, 7, 8: weight <= limit
-  const bool flat = !by_class && !runs;  // one list in the given order
+  const bool flat = !by_class && !runs && n_act == n;  // one list in the given order
   int pos[SPLIT_CLASSES];  // where this thread's first simplex of the class goes
   int n_light = 0, n_heavy = 0;
 #pragma unroll

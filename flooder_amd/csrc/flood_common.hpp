@@ -49,6 +49,12 @@ extern int g_fps_rpl;
 extern int g_fps_lane_best;  // 1: batched FPS ranks one candidate per lane at most (the > 64 candidates path; test hook)
 extern int g_fps_rounds;  // 1: batched FPS enqueues rounds of launches and reads the counter back between them
 extern int g_curve;
+extern int g_wit_weight;    // witness sweep: heaviest simplex (points in its box) it tries
+extern int g_wit_cmax_pct;  // ... its gather radius in percent of the local point spacing
+extern int g_wit_grid;      // ... its persistent one-wave workgroups
+extern int g_wit_min_bins;  // ... excess bins (of 64) the stage must hold at least
+// face planes of every simplex (flood_cell.hip: simplex_planes_kernel), 24 floats per simplex
+int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st);
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

@@ -695,6 +695,22 @@ int flooder_set_option(const char* name, int value) {
     g_cell_tail_waves = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "wit_weight") == 0 && value >= 0) {
+    g_wit_weight = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_cmax_pct") == 0 && value >= 10 && value <= 10000) {
+    g_wit_cmax_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_grid") == 0 && value >= 1) {
+    g_wit_grid = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_min_bins") == 0 && value >= 1 && value <= 64) {
+    g_wit_min_bins = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_one_pass") == 0 && value >= 0 && value <= 100000) {
     g_cell_one_pass = value;
     return FLOODER_OK;

@@ -44,6 +44,8 @@ extern "C" {
 #define FLOODER_QUEUE_SHARDS 16    /* heads of a sharded work queue ...                        */
 #define FLOODER_QUEUE_WORDS 512    /* ... and the zeroed int32 words one queue takes (heads 128 B apart) */
 #define FLOODER_BBOX_BLOCKS 1024  /* partial results of flooder_bbox_f32               */
+#define FLOODER_WIT_MAX_COARSE 256  /* coarse samples per simplex of flooder_sweep_witness_f32 (4 per lane) */
+#define FLOODER_WIT_MAX_ROWS 8192   /* samples per simplex it takes at most                                  */
 
 int flooder_abi_version(void);
 const char* flooder_last_error(void);
@@ -324,6 +326,36 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, float* plane_scratch,
                                  const int32_t* density_grid, const float* cloud_box, uint64_t* stats, void* stream);
+
+/*
+ * Witness sweep (dim 2 and 3): the sparse simplices of the fused path, a whole simplex per wave, BEFORE
+ * flooder_sweep_cell_faces_f32 (same buffers; replaces compute_filtration_kernel, triton_kernels.py:12-45, and the
+ * per-face amax of core.py:251-276 for those simplices).  The points around the simplex are gathered and staged once;
+ * a coarse sub-lattice of its samples (coarse_rows: n_coarse <= FLOODER_WIT_MAX_COARSE row numbers padded with -1 to
+ * FLOODER_WIT_MAX_COARSE entries) is evaluated first and every coarse sample keeps its witness, the point attaining
+ * its minimum; every other sample takes the distance to the witnesses of four nearby coarse samples (parents[r]: four
+ * coarse slots, 8 bits each; a coarse row's first parent is itself) as an upper bound, and is dropped when that bound
+ * cannot raise the running maximum of any face it lies on.  What is left is evaluated against the stage; samples whose
+ * nearest point may lie beyond the staged region are handed to flooder_finish_faces_f32 through flag_list / flag_key /
+ * flag_hist / top (as the cell sweep's open tiles; their rows of d2_scratch hold the bound, the other rows of such a
+ * tile are marked settled).  Face values are bit-identical to the exhaustive result.
+ * simplex_weight (n_simplices floats of flooder_simplex_weight_f32, READ AND WRITTEN): simplices heavier than option
+ * "wit_weight" (1500), or whose neighbourhood does not fit one LDS stage, are left alone; a simplex handled here gets
+ * weight -1, which flooder_sweep_cell_faces_f32 skips.  R <= FLOODER_WIT_MAX_ROWS.  queue: FLOODER_QUEUE_WORDS zeroed
+ * int32.  stats: NULL or 12 zeroed uint64 {simplices handled, too heavy, gather overflow, too dense for the stage,
+ * points staged, coarse samples certified, samples live after the bound, evaluation rounds, samples handed to the
+ * finish, tiles flagged, pairs evaluated, excess bins kept}.  Options: "wit_cmax_pct" (250: gather radius in percent of
+ * the local point spacing), "wit_min_bins" (6), "wit_grid".
+ */
+int flooder_wit_max_rows(void);
+int flooder_wit_max_coarse(void);
+int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
+                              const float* weights, int k1, int R, int64_t n_simplices, const int32_t* coarse_rows,
+                              int n_coarse, const uint32_t* parents, int32_t* queue, uint32_t* d2_scratch,
+                              const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
+                              int32_t* flag_list, int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist,
+                              uint64_t* top, int32_t* top_list, int32_t* top_count, float* simplex_weight,
+                              float* plane_scratch, uint64_t* stats, void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not
