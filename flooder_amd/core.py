@@ -1006,7 +1006,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                                                          k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
         with _span(timer, "sweep"):
             if use_wit:
-                wst = stats[16:28] if stats is not None and stats.numel() >= 28 else None
+                wst = stats[16:40] if stats is not None and stats.numel() >= 40 else None
                 _native.check(lib.flooder_sweep_witness_f32(
                     _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                     _native.ptr(w_perm), k1, R, S, _native.ptr(plan.wit[0]), plan.wit[2], _native.ptr(plan.wit[1]),

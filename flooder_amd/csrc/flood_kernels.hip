@@ -703,6 +703,14 @@ int flooder_set_option(const char* name, int value) {
     g_wit_cmax_pct = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "wit_cmax_ext_pct") == 0 && value >= 1 && value <= 10000) {
+    g_wit_cmax_ext_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_flags") == 0 && value >= 0) {
+    g_wit_flags = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "wit_grid") == 0 && value >= 1) {
     g_wit_grid = value;
     return FLOODER_OK;

@@ -35,27 +35,28 @@ using namespace flooder;
 namespace flooder {
 int g_wit_weight = 1500;    // simplices with at most this many cloud points in their box (flooder_simplex_weight_f32) are tried
 int g_wit_cmax_pct = 250;   // c_max in percent of the local point spacing
-int g_wit_grid = 256 * 11;  // persistent one-wave workgroups
+int g_wit_grid = 256 * 3;   // persistent workgroups (one simplex at a time each)
 int g_wit_min_bins = 6;     // the stage must hold the points of at least this many of the 64 excess bins
+int g_wit_flags = 0;        // test switches: 1 = no exact pass for the open samples, 2 = rounds not shared between waves
+int g_wit_cmax_ext_pct = 60;  // ... and at most this share of the simplex's extent
 }  // namespace flooder
 
 namespace {
 
-constexpr int WCAP = 480;      // points staged per item
+constexpr int WTHREADS = 256;  // one workgroup of four waves per simplex
+constexpr int WWAVES = WTHREADS / 64;
+constexpr int WCAP = 960;      // points staged per item
 constexpr int WLEAF = 1024;    // leaves gathered per item (16 K candidate points)
 constexpr int WFRONT = 192;    // inner nodes per level of the gather
-constexpr int WCOARSE = FLOODER_WIT_MAX_COARSE;  // coarse samples per item (4 per lane)
-constexpr int WPEND = 128;     // queued live samples
+constexpr int WCOARSE = FLOODER_WIT_MAX_COARSE;  // coarse samples per item (one per thread)
+constexpr int WUR = 64;        // open samples resolved by the exact pass per item (beyond: to the finish)
+constexpr int WQ = 768;        // queued live samples (beyond: handed to the finish with their bound)
 constexpr int WROWS = FLOODER_WIT_MAX_ROWS;      // samples per simplex at most
 constexpr int UNR = 4;         // candidate rows in flight per lane
+constexpr int UNRF = 2;        // groups of 256 rows in flight in the pass over all samples
 constexpr int NBIN = 64;
 constexpr int PLANE_ROW = 24;  // (layout of simplex_planes_kernel, flood_cell.hip)
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
+static_assert(WCOARSE == WTHREADS, "one coarse sample per thread");
 
 template <int DP>
 __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint32_t byte_off, float (&out)[DP]) {
@@ -79,204 +80,301 @@ struct WitOut {
   float* weight;         // in: rough point count per simplex box; out: -1 for the simplices handled here
 };
 
+// The simplex as a polytope (box of the vertices, extents along the face normals).  Wave-uniform, computed once per
+// item and parked in LDS: every phase loads what it needs into registers of its own scope - held across the whole
+// item these sixty values (the compiler keeps uniform floats in vector registers) cost the kernel its occupancy.
 template <int DIM>
-__global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
+struct Region {
+  float pn[DIM + 1][DIM], po[DIM + 1], ps[DIM + 1], org[DIM], sext, blo[DIM], bhi[DIM], slo[DIM + 1], shi[DIM + 1], epsb;
+  static constexpr int WORDS = (DIM + 1) * DIM + 4 * (DIM + 1) + 3 * DIM + 2;
+  __device__ __forceinline__ void store(float* c) const {
+    int i = 0;
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) c[i++] = pn[f][k];
+      c[i++] = po[f]; c[i++] = ps[f]; c[i++] = slo[f]; c[i++] = shi[f];
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) { c[i++] = org[k]; c[i++] = blo[k]; c[i++] = bhi[k]; }
+    c[i++] = sext;
+    c[i++] = epsb;
+  }
+  __device__ __forceinline__ void load(const float* c) {
+    int i = 0;
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) pn[f][k] = c[i++];
+      po[f] = c[i++]; ps[f] = c[i++]; slo[f] = c[i++]; shi[f] = c[i++];
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) { org[k] = c[i++]; blo[k] = c[i++]; bhi[k] = c[i++]; }
+    sext = c[i++];
+    epsb = c[i++];
+  }
+  // squared radius within which EVERY point around sample p is on a stage that holds all points of excess < c_sel:
+  // c_sel plus the sample's own distance to the nearest side of the polytope
+  __device__ __forceinline__ float cert_limit(const float (&p)[DIM], float c_sel) const {
+    float dl = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) dl = __builtin_fminf(dl, __builtin_fminf(p[k] - blo[k], bhi[k] - p[k]));
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+      if (po[f] < 1.0e37f) {  // (uniform: the plane is in use)
+        float dd = -po[f];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], p[k] - org[k], dd);
+        dl = __builtin_fminf(dl, __builtin_fminf(shi[f] - dd, dd - slo[f]));
+      }
+    }
+    const float rr = 0.999f * (c_sel + __builtin_fmaxf(dl, 0.f));
+    return rr * rr;
+  }
+};
+
+// excess of a point: the smallest c for which it counts as "within c of the simplex" (<= its distance to the polytope)
+template <int DIM>
+struct Excess {
+  float pn[DIM + 1][DIM], po[DIM + 1], org[DIM], blo_e[DIM], bhi_e[DIM], slo_t[DIM + 1], shi_t[DIM + 1], inv_den[DIM + 1];
+  __device__ __forceinline__ Excess(const Region<DIM>& g, float c_max) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) { blo_e[k] = g.blo[k] - g.epsb; bhi_e[k] = g.bhi[k] + g.epsb; org[k] = g.org[k]; }
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+      const float tol = g.ps[f] * (g.sext + c_max);
+      slo_t[f] = g.slo[f] - tol;
+      shi_t[f] = g.shi[f] + tol;
+      inv_den[f] = 1.f / (1.001f + g.ps[f]);
+      po[f] = g.po[f];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) pn[f][k] = g.pn[f][k];
+    }
+  }
+  template <int DP>
+  __device__ __forceinline__ float operator()(const float (&x)[DP]) const {
+    float e = 0.f;
+    float xr[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      e = __builtin_fmaxf(e, __builtin_fmaxf(x[k] - bhi_e[k], blo_e[k] - x[k]));
+      xr[k] = x[k] - org[k];
+    }
+#pragma unroll
+    for (int f = 0; f <= DIM; ++f) {
+      float dd = -po[f];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], xr[k], dd);
+      e = __builtin_fmaxf(e, __builtin_fmaxf(dd - shi_t[f], slo_t[f] - dd) * inv_den[f]);
+    }
+    return e;
+  }
+};
+
+template <int DIM>
+__global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv, const float* __restrict__ verts,
     const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R, int64_t n_simplices,
-    float w_limit, float cmax_mult, int min_bins, WitPlan plan, int32_t* __restrict__ queue, WitOut out, FaceAcc acc,
+    float w_limit, float cmax_mult, float cmax_ext, int min_bins, int flags, WitPlan plan, int32_t* __restrict__ queue, WitOut out, FaceAcc acc,
     unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
   __shared__ float4 s_pts[WCAP + 4];
   __shared__ int s_leaf[WLEAF];
+  __shared__ uint32_t s_qub[WQ];
+  __shared__ uint16_t s_qrow[WQ];
   __shared__ int s_hist[NBIN];
   __shared__ uint32_t s_mf[32];
   __shared__ uint32_t s_unres[WROWS / 32];
   __shared__ uint32_t s_tkey[WROWS / 64];
+  __shared__ int s_ftile[WROWS / 64];
+  __shared__ int s_gn[MAXL + 2];  // nodes found per tree level ([0]: leaves), [MAXL]: overflow flag
+  __shared__ int s_ctr[4];        // [0] points staged, [1] samples queued, [2] tiles flagged, [3] open samples
+  __shared__ uint16_t s_ur_row[WUR];   // samples left open by the stage: row, bound, coordinates
+  __shared__ uint32_t s_ur_best[WUR];
+  __shared__ float s_ur_p[WUR * 3];
+  __shared__ float s_rg[Region<DIM>::WORDS];
+  __shared__ long long s_item;
   static_assert(2 * WFRONT * sizeof(int) <= WCAP * sizeof(float4), "the gather's frontier lives inside the empty stage");
-  static_assert(WCOARSE * 3 * sizeof(float) + WPEND * 6 <= WLEAF * sizeof(int), "witness table + queue alias the leaf list");
+  static_assert(WCOARSE * 3 * sizeof(float) <= WLEAF * sizeof(int), "the witness table takes the place of the leaf list");
   int* s_front = reinterpret_cast<int*>(s_pts);
-  // (after staging the leaf list is dead: witnesses and the queue of live samples take its place)
-  float* s_wit = reinterpret_cast<float*>(s_leaf);
-  uint32_t* s_pub = reinterpret_cast<uint32_t*>(s_leaf) + WCOARSE * 3;
-  uint16_t* s_prow = reinterpret_cast<uint16_t*>(s_pub + WPEND);
-  const int lane = threadIdx.x;
+  float* s_wit = reinterpret_cast<float*>(s_leaf);  // (after staging the leaf list is dead)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
   const int top = lv.n_levels - 1;
   const int tiles64 = (R + 63) >> 6;
-  unsigned long long n_handled = 0, n_dense = 0, n_over = 0, n_staged = 0, n_ccert = 0, n_live = 0, n_rounds = 0,
-                     n_unres = 0, n_flagged = 0, n_pairs = 0, n_heavy = 0, n_bins = 0;
+  // work counters (diagnostic runs only: stats != NULL) live in LDS - fourteen 64-bit counters in registers cost the
+  // kernel 28 VGPRs it does not have
+  __shared__ unsigned long long s_stat[24];
+  enum { ST_HANDLED = 0, ST_HEAVY = 1, ST_OVER = 2, ST_DENSE = 3, ST_STAGED = 4, ST_CCERT = 5, ST_LIVE = 6, ST_ROUNDS = 7,
+         ST_UNRES = 8, ST_FLAGGED = 9, ST_PAIRS = 10, ST_BINS = 11, ST_EXACT = 22, ST_EXACT_OVER = 23 };
+  if (threadIdx.x < 24) s_stat[threadIdx.x] = 0ull;
+  auto count = [&](int what, unsigned long long n) {  // (call from one lane per event)
+    if (stats) atomicAdd(&s_stat[what], n);
+  };
 
+#ifdef FLOODER_WIT_TIMERS
+  unsigned long long t_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define WPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_ph[i] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define WPHASE(i) do {} while (0)
+#endif
   int q_shard = (int)(blockIdx.x % QSHARDS), q_tried = 0;
   for (;;) {
-    const int64_t s = queue_pop(queue, q_shard, q_tried, n_simplices, lane);
+    WPHASE(8);
+    __syncthreads();  // (the previous item's LDS is free)
+    if (wv == 0) {
+      const int64_t it = queue_pop(queue, q_shard, q_tried, n_simplices, lane);
+      if (lane == 0) s_item = (long long)it;
+    }
+    if (tid < MAXL + 2) s_gn[tid] = 0;
+    if (tid < 4) s_ctr[tid] = 0;
+    if (tid < NBIN) s_hist[tid] = 0;
+    for (int i = tid; i < WROWS / 32; i += WTHREADS) s_unres[i] = 0u;
+    for (int i = tid; i < WROWS / 64; i += WTHREADS) s_tkey[i] = 0u;
+    __syncthreads();
+    const int64_t s = (int64_t)s_item;
     if (s < 0) break;
     const float w_s = out.weight[s];
-    if (!(w_s <= w_limit) || w_s < 0.f) { ++n_heavy; continue; }
+    if (!(w_s <= w_limit) || w_s < 0.f) { if (tid == 0) count(ST_HEAVY, 1); continue; }
     const float* vs = verts + s * (int64_t)k1 * DIM;
+    WPHASE(0);
 
-    // ---- face planes of the simplex (table row written by simplex_planes_kernel)
-    float pn[DIM + 1][DIM], po[DIM + 1], ps[DIM + 1], org[DIM];
-    float sext;
+    // ---- 1. region: face planes of the simplex (table row written by simplex_planes_kernel), box of the vertices,
+    // extents along the face normals -> LDS
+    float c_max;
     {
+      Region<DIM> rg;
       const float* pt = plane_tab + s * PLANE_ROW;
       typename RowVec<4>::type t[PLANE_ROW / 4];
 #pragma unroll
       for (int i = 0; i < PLANE_ROW / 4; ++i) t[i] = load_uniform_row<4>(pt + 4 * i);
       auto at = [&](int i) { return t[i >> 2][i & 3]; };
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) org[k] = at(k);
-      sext = at(3);
+      for (int k = 0; k < DIM; ++k) rg.org[k] = at(k);
+      rg.sext = at(3);
 #pragma unroll
       for (int f = 0; f <= DIM; ++f) {
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) pn[f][k] = at(4 + 5 * f + k);
-        po[f] = at(4 + 5 * f + 3);
-        ps[f] = at(4 + 5 * f + 4) + 1e-6f;
+        for (int k = 0; k < DIM; ++k) rg.pn[f][k] = at(4 + 5 * f + k);
+        rg.po[f] = at(4 + 5 * f + 3);
+        rg.ps[f] = at(4 + 5 * f + 4) + 1e-6f;
       }
-    }
-    // ---- 1. region: box of the vertices, extents along the face normals
-    float blo[DIM], bhi[DIM], slo[DIM + 1], shi[DIM + 1];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) { blo[k] = __builtin_inff(); bhi[k] = -__builtin_inff(); }
+      for (int k = 0; k < DIM; ++k) { rg.blo[k] = __builtin_inff(); rg.bhi[k] = -__builtin_inff(); }
 #pragma unroll
-    for (int f = 0; f <= DIM; ++f) { slo[f] = __builtin_inff(); shi[f] = -__builtin_inff(); }
-    float amax = 0.f;
-    for (int j = 0; j < k1; ++j) {
-      float v[DIM];
+      for (int f = 0; f <= DIM; ++f) { rg.slo[f] = __builtin_inff(); rg.shi[f] = -__builtin_inff(); }
+      float amax = 0.f;
+      for (int j = 0; j < k1; ++j) {
+        float v[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          v[k] = vs[j * DIM + k];
+          rg.blo[k] = __builtin_fminf(rg.blo[k], v[k]);
+          rg.bhi[k] = __builtin_fmaxf(rg.bhi[k], v[k]);
+          amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
+        }
+#pragma unroll
+        for (int f = 0; f <= DIM; ++f) {
+          float dd = -rg.po[f];
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(rg.pn[f][k], v[k] - rg.org[k], dd);
+          rg.slo[f] = __builtin_fminf(rg.slo[f], dd);
+          rg.shi[f] = __builtin_fmaxf(rg.shi[f], dd);
+        }
+      }
+      // (a sample is a rounded combination of the vertices: it may leave their box by a few ulps)
+      rg.epsb = 8.f * 1.1920929e-7f * amax;
+      float ext = 0.f, vol = 1.f;
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
-        v[k] = vs[j * DIM + k];
-        blo[k] = __builtin_fminf(blo[k], v[k]);
-        bhi[k] = __builtin_fmaxf(bhi[k], v[k]);
-        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
+        ext = __builtin_fmaxf(ext, rg.bhi[k] - rg.blo[k]);
+        vol *= (rg.bhi[k] - rg.blo[k]);
       }
-#pragma unroll
-      for (int f = 0; f <= DIM; ++f) {
-        float dd = -po[f];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], v[k] - org[k], dd);
-        slo[f] = __builtin_fminf(slo[f], dd);
-        shi[f] = __builtin_fmaxf(shi[f], dd);
-      }
+      const float n0 = __builtin_fmaxf(w_s, 1.f);
+      const float h = DIM == 3 ? cbrtf(vol / n0) : __builtin_sqrtf(vol / n0);
+      c_max = __builtin_fminf(cmax_mult * h, cmax_ext * ext);
+      if (tid == 0) rg.store(s_rg);
     }
-    // (a sample is a rounded combination of the vertices: it may leave their box by a few ulps)
-    const float epsb = 8.f * 1.1920929e-7f * amax;
-    float ext = 0.f, vol = 1.f;
-#pragma unroll
-    for (int k = 0; k < DIM; ++k) {
-      ext = __builtin_fmaxf(ext, bhi[k] - blo[k]);
-      vol *= (bhi[k] - blo[k]);
-    }
-    const float n0 = __builtin_fmaxf(w_s, 1.f);
-    const float h = DIM == 3 ? cbrtf(vol / n0) : __builtin_sqrtf(vol / n0);
-    float c_max = __builtin_fminf(cmax_mult * h, 0.6f * ext);
-    if (!(c_max > 0.f) || !(c_max < 3.0e38f)) { ++n_over; continue; }
+    if (!(c_max > 0.f) || !(c_max < 3.0e38f)) { if (tid == 0) count(ST_OVER, 1); continue; }
+    __syncthreads();
 
-    // ---- gather: leaves of the box tree overlapping [qlo, qhi]; returns their number or -1 (overflow)
+    // ---- gather: leaves of the box tree overlapping [qlo, qhi] -> s_leaf, s_gn[0] of them; the frontier groups of a
+    // level are dealt to the four waves, every level ends with a barrier
     float qlo[DIM], qhi[DIM];
-    auto gather = [&]() -> int {
-      constexpr int GB = 4;
-      int* fa = s_front;
-      int* fb = s_front + WFRONT;
-      int na = 0, nb = 0, n_leaf = 0;
-      bool over = false;
-      auto test_children = [&](int lvl, const int (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
-        const int lvl_count = (int)lv.count[lvl], lvl_off = (int)lv.off[lvl];
-        bool hit[GB];
-        float lo[GB][DP], hi[GB][DP];
+    auto test_children = [&](int lvl, int grp, int* out_list, int* out_n, int cap) {
+      const int lvl_count = (int)lv.count[lvl], lvl_off = (int)lv.off[lvl];
+      const int idx = grp * FAN + lane;
+      bool hit = idx < lvl_count;
+      float lo[DP], hi[DP];
+      const uint32_t nb_ = (uint32_t)(lvl_off + (hit ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+      load_row_at<DP>(nodes, nb_, lo);
+      load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
-          const int idx = grp[u] * FAN + lane;
-          hit[u] = (u < ng) && (idx < lvl_count);
-          const uint32_t nb_ = (uint32_t)(lvl_off + (hit[u] ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
-          load_row_at<DP>(nodes, nb_, lo[u]);
-          load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-          if (u < ng) {
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) hit[u] = hit[u] && (lo[u][k] <= qhi[k]) && (hi[u][k] >= qlo[k]);
-            const unsigned long long m = __ballot(hit[u]);
-            const int cnt = __popcll(m);
-            if (out_n + cnt > cap) {
-              over = true;
-            } else {
-              if (hit[u]) out_list[out_n + lane_rank(m)] = grp[u] * FAN + lane;
-              out_n += cnt;
-            }
-          }
-        }
-        wave_lds_sync();
-      };
-      {
-        const int g0_[GB] = {};
-        if (top == 0) test_children(0, g0_, 1, s_leaf, n_leaf, WLEAF);
-        else test_children(top, g0_, 1, fa, na, WFRONT);
+      for (int k = 0; k < DIM; ++k) hit = hit && (lo[k] <= qhi[k]) && (hi[k] >= qlo[k]);
+      const unsigned long long m = __ballot(hit);
+      const int cnt = __popcll(m);
+      if (cnt == 0) return;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(out_n, cnt);
+      base = wave_uniform(base);
+      if (base + cnt > cap) {
+        if (lane == 0) s_gn[MAXL] = 1;
+      } else if (hit) {
+        out_list[base + lane_rank(m)] = idx;
       }
-      for (int lvl = top; lvl >= 1 && !over; --lvl) {
-        nb = 0;
-        for (int f = 0; f < na && !over; f += GB) {
-          int grp[GB];
-          const int ng = na - f < GB ? na - f : GB;
-#pragma unroll
-          for (int u = 0; u < GB; ++u) grp[u] = wave_uniform(fa[f + u < na ? f + u : f]);
-          if (lvl == 1) test_children(0, grp, ng, s_leaf, n_leaf, WLEAF);
-          else test_children(lvl - 1, grp, ng, fb, nb, WFRONT);
-        }
-        int* t = fa; fa = fb; fb = t;
-        na = nb;
-      }
-      return over ? -1 : n_leaf;
     };
-    int n_leaves = -1;
+    bool gathered = false;
     for (int att = 0; att < 3; ++att) {
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) { qlo[k] = blo[k] - epsb - c_max; qhi[k] = bhi[k] + epsb + c_max; }
-      n_leaves = gather();
-      if (n_leaves >= 0) break;
-      c_max *= 0.5f;
-    }
-    if (n_leaves < 0) { ++n_over; continue; }
-
-    // ---- excess of a point: the smallest c for which it counts as "within c of the simplex"
-    float blo_e[DIM], bhi_e[DIM], slo_t[DIM + 1], shi_t[DIM + 1], inv_den[DIM + 1];
-#pragma unroll
-    for (int k = 0; k < DIM; ++k) { blo_e[k] = blo[k] - epsb; bhi_e[k] = bhi[k] + epsb; }
-#pragma unroll
-    for (int f = 0; f <= DIM; ++f) {
-      const float tol = ps[f] * (sext + c_max);
-      slo_t[f] = slo[f] - tol;
-      shi_t[f] = shi[f] + tol;
-      inv_den[f] = 1.f / (1.001f + ps[f]);
-    }
-    auto excess = [&](const float (&x)[DP]) -> float {
-      float e = 0.f;
-      float xr[DIM];
-#pragma unroll
       for (int k = 0; k < DIM; ++k) {
-        e = __builtin_fmaxf(e, __builtin_fmaxf(x[k] - bhi_e[k], blo_e[k] - x[k]));
-        xr[k] = x[k] - org[k];
+        qlo[k] = s_rg[Region<DIM>::WORDS - 2 - 3 * DIM + 3 * k + 1] - s_rg[Region<DIM>::WORDS - 1] - c_max;
+        qhi[k] = s_rg[Region<DIM>::WORDS - 2 - 3 * DIM + 3 * k + 2] + s_rg[Region<DIM>::WORDS - 1] + c_max;
       }
-#pragma unroll
-      for (int f = 0; f <= DIM; ++f) {
-        float dd = -po[f];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], xr[k], dd);
-        e = __builtin_fmaxf(e, __builtin_fmaxf(dd - shi_t[f], slo_t[f] - dd) * inv_den[f]);
+      int* fa = s_front;
+      int* fb = s_front + WFRONT;
+      if (wv == 0) {
+        if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
+        else test_children(top, 0, fa, &s_gn[top], WFRONT);
       }
-      return e;
-    };
+      __syncthreads();
+      for (int lvl = top; lvl >= 1; --lvl) {
+        if (s_gn[MAXL] != 0) break;  // (overflow: the lists are incomplete - block-uniform, read behind a barrier)
+        const int na = s_gn[lvl];
+        for (int f = wv; f < na; f += WWAVES) {
+          const int grp = wave_uniform(fa[f]);
+          if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
+          else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
+        }
+        __syncthreads();
+        int* t = fa; fa = fb; fb = t;
+      }
+      if (s_gn[MAXL] == 0) { gathered = true; break; }
+      __syncthreads();  // (everybody has seen the overflow flag)
+      if (tid < MAXL + 2) s_gn[tid] = 0;
+      c_max *= 0.5f;
+      __syncthreads();
+    }
+    if (!gathered) { if (tid == 0) count(ST_OVER, 1); continue; }
+    const int n_leaves = s_gn[0];
+    WPHASE(1);
+
     const float bin_scale = (float)NBIN / c_max;
     const int n_cand = n_leaves * LEAF;
-    // ---- 2a. histogram of the excesses
-    s_hist[lane] = 0;
-    wave_lds_sync();
-    for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
+    int n_keep_bins, n_stage;
+    float c_sel;
+    {  // (scope of the region's registers)
+    Region<DIM> rg_;
+    rg_.load(s_rg);
+    const Excess<DIM> excess(rg_, c_max);
+    // ---- 2a. histogram of the excesses (LDS atomics)
+    for (int ib = 0; ib < n_cand; ib += WTHREADS * UNR) {
       float x[UNR][DP];
       bool in[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int idx = ib + u * 64 + lane;
+        const int idx = ib + u * WTHREADS + tid;
         in[u] = idx < n_cand;
         const uint32_t row = in[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
         load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
@@ -287,8 +385,8 @@ __global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
         if (in[u] && eb < (float)NBIN) atomicAdd(&s_hist[(int)eb], 1);
       }
     }
-    wave_lds_sync();
-    int n_keep_bins, n_stage;
+    __syncthreads();
+    WPHASE(2);
     {
       int cum = s_hist[lane];
 #pragma unroll
@@ -300,16 +398,16 @@ __global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
       n_keep_bins = __popcll(fit);
       n_stage = n_keep_bins > 0 ? __shfl(cum, n_keep_bins - 1) : 0;
     }
-    if (n_keep_bins < min_bins || n_stage == 0) { ++n_dense; continue; }   // too dense for one stage (or nothing near)
-    const float c_sel = (float)n_keep_bins / bin_scale;
-    // ---- 2b. stage the points of the kept bins
-    int n_st = 0;
-    for (int ib = 0; ib < n_cand; ib += 64 * UNR) {
+    if (n_keep_bins < min_bins || n_stage == 0) { if (tid == 0) count(ST_DENSE, 1); continue; }   // too dense for one stage (or nothing near)
+    c_sel = (float)n_keep_bins / bin_scale;
+    // ---- 2b. stage the points of the kept bins (any order: a minimum does not care)
+    __syncthreads();  // (the frontier inside the stage is dead)
+    for (int ib = 0; ib < n_cand; ib += WTHREADS * UNR) {
       float x[UNR][DP];
       bool in[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int idx = ib + u * 64 + lane;
+        const int idx = ib + u * WTHREADS + tid;
         in[u] = idx < n_cand;
         const uint32_t row = in[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
         load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
@@ -319,26 +417,33 @@ __global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
         const float eb = excess(x[u]) * bin_scale;
         const bool keep = in[u] && eb < (float)n_keep_bins;   // (the same test as the histogram's: bin < n_keep_bins)
         const unsigned long long m = __ballot(keep);
-        if (keep) {
-          float4 v;
-          v.x = x[u][0];
-          v.y = x[u][1];
-          v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-          v.w = 0.f;
-          s_pts[n_st + lane_rank(m)] = v;
+        if (m != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_ctr[0], __popcll(m));
+          base = wave_uniform(base);
+          if (keep) {
+            float4 v;
+            v.x = x[u][0];
+            v.y = x[u][1];
+            v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+            v.w = 0.f;
+            s_pts[base + lane_rank(m)] = v;
+          }
         }
-        n_st += __popcll(m);
       }
     }
-    if (lane < 4) s_pts[n_st + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
-    for (int i = lane; i < WROWS / 32; i += 64) s_unres[i] = 0u;
-    for (int i = lane; i < WROWS / 64; i += 64) s_tkey[i] = 0u;
-    wave_lds_sync();
-    n_staged += (unsigned long long)n_st;
-    n_bins += (unsigned long long)n_keep_bins;
-    const int K = n_st;
+    }
+    __syncthreads();
+    const int K = s_ctr[0];   // (= n_stage)
+    if (tid < 4) s_pts[K + tid] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    // running maxima of this simplex's faces as other workgroups have left them
+    if (tid < acc.n_faces)
+      s_mf[tid] = __hip_atomic_load(acc.face_bits + acc.slot_of(s, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) { count(ST_STAGED, (unsigned long long)K); count(ST_BINS, (unsigned long long)n_keep_bins); }
+    WPHASE(3);
 
-    // ---- helpers: a sample from its weight row; its inner slack; its certification limit
+    // ---- helpers: a sample from its weight row; its certification limit; delivery of certified values
     auto make_sample = [&](int r, float (&p)[DIM]) {
 #pragma unroll
       for (int k = 0; k < DIM; ++k) p[k] = 0.f;
@@ -358,150 +463,46 @@ __global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
         }
       }
     };
-    auto cert_limit = [&](const float (&p)[DIM]) -> float {
-      float dl = __builtin_inff();
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) dl = __builtin_fminf(dl, __builtin_fminf(p[k] - blo[k], bhi[k] - p[k]));
-#pragma unroll
-      for (int f = 0; f <= DIM; ++f) {
-        if (po[f] < 1.0e37f) {  // (wave-uniform: the plane is in use)
-          float dd = -po[f];
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) dd = __builtin_fmaf(pn[f][k], p[k] - org[k], dd);
-          dl = __builtin_fminf(dl, __builtin_fminf(shi[f] - dd, dd - slo[f]));
-        }
-      }
-      const float rr = 0.999f * (c_sel + __builtin_fmaxf(dl, 0.f));
-      return rr * rr;
-    };
-    // certified samples raise the running maxima of their faces (one integer atomic per face and call at most)
+    // certified samples raise the running maxima of their faces (per wave: one global atomic per face at most,
+    // and only when it can raise the value this workgroup has seen)
     auto deliver = [&](bool on, uint32_t mb, float val) {
       uint32_t um = wave_or_u32(on ? mb : 0u);
       while (um) {  // (wave-uniform)
         const int f = __builtin_ctz(um);
         um &= um - 1u;
         const uint32_t v = wave_max_u32((on && ((mb >> f) & 1u)) ? __float_as_uint(val) : 0u);
-        if (v > s_mf[f]) {
-          if (lane == 0) {
-            atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
-            s_mf[f] = v;
-          }
+        if (lane == 0 && v > s_mf[f]) {
+          atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
+          atomicMax(&s_mf[f], v);
         }
       }
-      wave_lds_sync();
     };
-    // running maxima of this simplex's faces as other waves have left them
-    if (lane < acc.n_faces)
-      s_mf[lane] = __hip_atomic_load(acc.face_bits + acc.slot_of(s, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wave_lds_sync();
-
-    // ---- 3. coarse samples (four per lane) against the stage, with witnesses
-    {
-      constexpr int CPL = WCOARSE / 64;
-      float p[CPL][DIM], best[CPL];
-      int wj[CPL], crow[CPL];
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int c = i * 64 + lane;
-        crow[i] = c < plan.n_coarse ? plan.coarse_rows[c] : -1;
-        make_sample(crow[i] < 0 ? 0 : crow[i], p[i]);
-        best[i] = __builtin_inff();
-        wj[i] = 0;
-      }
-      for (int j = 0; j < K; j += 4) {
-        float4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          float d[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            float t0 = p[i][0] - x[u].x;
-            float d2 = t0 * t0;
-            t0 = p[i][1] - x[u].y;
-            d2 = __builtin_fmaf(t0, t0, d2);
-            if constexpr (DIM == 3) {
-              t0 = p[i][2] - x[u].z;
-              d2 = __builtin_fmaf(t0, t0, d2);
-            }
-            d[u] = d2;
-          }
-          const float m = __builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3]));
-          if (m < best[i]) { best[i] = m; wj[i] = j; }
-        }
-      }
-      if (stats) n_pairs += (unsigned long long)K * CPL;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        // the witness: the first point of the winning group of four that attains the minimum
-        float4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = s_pts[wj[i] + u];
-        float4 w = x[3];
-#pragma unroll
-        for (int u = 2; u >= 0; --u) {
-          float t0 = p[i][0] - x[u].x;
-          float d2 = t0 * t0;
-          t0 = p[i][1] - x[u].y;
-          d2 = __builtin_fmaf(t0, t0, d2);
-          if constexpr (DIM == 3) {
-            t0 = p[i][2] - x[u].z;
-            d2 = __builtin_fmaf(t0, t0, d2);
-          }
-          if (d2 == best[i]) w = x[u];
-        }
-        const int c = i * 64 + lane;
-        s_wit[3 * c + 0] = w.x;
-        s_wit[3 * c + 1] = w.y;
-        s_wit[3 * c + 2] = w.z;
-      }
-      wave_lds_sync();
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const bool cert = crow[i] >= 0 && best[i] <= cert_limit(p[i]);
-        if (stats) n_ccert += (unsigned long long)__popcll(__ballot(cert));
-        deliver(cert, cert ? acc.memb[crow[i]] : 0u, best[i]);
-      }
-    }
-
-    // ---- 4. all samples: bound from the witnesses of the nearest coarse samples; live ones are queued and
-    // evaluated 64 at a time
-    int n_pend = 0;
-    auto run_round = [&]() {
-      const int n_take = n_pend < 64 ? n_pend : 64;
-      const bool mine = lane < n_take;
-      const int r = mine ? (int)s_prow[lane] : 0;
-      float best = mine ? __uint_as_float(s_pub[lane]) : 0.f;
-      // what is left of the queue moves to its front
-      const int n_rest = n_pend - n_take;
-      uint32_t mv_ub = 0u;
-      uint16_t mv_row = 0;
-      if (lane < n_rest) { mv_ub = s_pub[64 + lane]; mv_row = s_prow[64 + lane]; }
-      wave_lds_sync();
-      if (lane < n_rest) { s_pub[lane] = mv_ub; s_prow[lane] = mv_row; }
-      n_pend = n_rest;
-      float p[DIM];
-      make_sample(r, p);
-      const uint32_t mb = mine ? acc.memb[r] : 0u;
-      // still live?  (the maxima have risen since the sample was queued)
+    // threshold of a sample: the smallest running maximum among the faces it lies on
+    auto threshold = [&](uint32_t mb) -> uint32_t {
       uint32_t thr = 0xffffffffu;
-      {
-        uint32_t um = wave_or_u32(mb);
-        while (um) {
-          const int f = __builtin_ctz(um);
-          um &= um - 1u;
-          const uint32_t v = s_mf[f];
-          if ((mb >> f) & 1u) thr = v < thr ? v : thr;
-        }
+      uint32_t um = wave_or_u32(mb);
+      while (um) {  // (wave-uniform: the faces present among this wave's 64 rows)
+        const int f = __builtin_ctz(um);
+        um &= um - 1u;
+        const uint32_t v = s_mf[f];
+        if ((mb >> f) & 1u) thr = v < thr ? v : thr;
       }
-      const bool act = mine && __float_as_uint(best) > thr;
-      if (__ballot(act) == 0ull) { wave_lds_sync(); return; }
-      ++n_rounds;
+      return thr;
+    };
+    // ---- 3. coarse samples (one per thread) against the stage, with witnesses
+    {
+      const int c = tid;
+      const int crow = c < plan.n_coarse ? plan.coarse_rows[c] : -1;
+      float p[DIM];
+      make_sample(crow < 0 ? 0 : crow, p);
+      const uint32_t mb = crow >= 0 ? acc.memb[crow] : 0u;
+      float best = __builtin_inff();
+      int wj = 0;
       for (int j = 0; j < K; j += 4) {
         float4 x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];
+        float d[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           float t0 = p[0] - x[u].x;
@@ -512,123 +513,375 @@ __global__ __launch_bounds__(64, 12) void wit_sweep_kernel(
             t0 = p[2] - x[u].z;
             d2 = __builtin_fmaf(t0, t0, d2);
           }
-          best = __builtin_fminf(best, d2);
+          d[u] = d2;
         }
+        const float m = __builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3]));
+        if (m < best) { best = m; wj = j; }
       }
-      if (stats) n_pairs += (unsigned long long)K;
-      const bool cert = act && best <= cert_limit(p);
-      const bool unres = act && !cert;
-      if (unres) {
-        out.d2[s * (int64_t)R + r] = __float_as_uint(best);
-        atomicOr(&s_unres[r >> 5], 1u << (r & 31));
-        atomicMax(&s_tkey[r >> 6], __float_as_uint(best));
-      }
-      if (stats) n_unres += (unsigned long long)__popcll(__ballot(unres));
-      deliver(cert, mb, best);
-    };
-    for (int g0 = 0; g0 < R; g0 += 64) {
-      const int r = g0 + lane;
-      const bool valid = r < R;
-      const int rr = valid ? r : R - 1;
-      float p[DIM];
-      make_sample(rr, p);
-      const uint32_t par = plan.parents[rr];
-      const uint32_t mb = valid ? acc.memb[rr] : 0u;
-      float ub = __builtin_inff();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (int)((par >> (8 * j)) & 0xffu);
-        float t0 = p[0] - s_wit[3 * c + 0];
-        float d2 = t0 * t0;
-        t0 = p[1] - s_wit[3 * c + 1];
-        d2 = __builtin_fmaf(t0, t0, d2);
-        if constexpr (DIM == 3) {
-          t0 = p[2] - s_wit[3 * c + 2];
-          d2 = __builtin_fmaf(t0, t0, d2);
-        }
-        ub = __builtin_fminf(ub, d2);
-      }
-      uint32_t thr = 0xffffffffu;
+      if (lane == 0) count(ST_PAIRS, (unsigned long long)K * 64ull);
       {
-        uint32_t um = wave_or_u32(mb);
-        while (um) {  // (wave-uniform: the faces present in this group of 64 rows)
-          const int f = __builtin_ctz(um);
-          um &= um - 1u;
-          const uint32_t v = s_mf[f];
-          if ((mb >> f) & 1u) thr = v < thr ? v : thr;
-        }
-      }
-      const bool live = valid && __float_as_uint(ub) > thr;
-      const unsigned long long m = __ballot(live);
-      if (m != 0ull) {
-        if (live) {
-          const int pos = n_pend + lane_rank(m);
-          s_pub[pos] = __float_as_uint(ub);
-          s_prow[pos] = (uint16_t)r;
-        }
-        n_pend += __popcll(m);
-        if (stats) n_live += (unsigned long long)__popcll(m);
-        wave_lds_sync();
-        if (n_pend >= 64) run_round();
-      }
-    }
-    while (n_pend > 0) run_round();
-
-    // ---- tiles with unresolved samples go to the exact finish: the other rows of such a tile are marked settled
-    for (int t0 = 0; t0 < tiles64; t0 += 64) {
-      const int t = t0 + lane;
-      const uint32_t key = t < tiles64 ? s_tkey[t] : 0u;
-      const unsigned long long fm = __ballot(key != 0u);
-      if (fm == 0ull) continue;
-      const int nf = __popcll(fm);
-      int base = 0;
-      if (lane == 0) base = atomicAdd(out.flag_count, nf);
-      base = wave_uniform(base);
-      if (key != 0u) {
-        const int pos = base + lane_rank(fm);
-        const int item = (int)(s * tiles64 + t);
-        out.flag_list[pos] = item;
-        if (acc.flag_key) {
-          acc.flag_key[pos] = key;
-          atomicAdd(&acc.flag_hist[key >> 19], 1);
-        }
-        if (acc.top) {
-          const unsigned long long old = atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)item);
-          if (old == 0ull) acc.top_list[atomicAdd(acc.top_count, 1)] = (int)s;
-        }
-      }
-      n_flagged += (unsigned long long)nf;
-      unsigned long long rest = fm;
-      while (rest) {  // (wave-uniform)
-        const int tl = __builtin_ctzll(rest);
-        rest &= rest - 1ull;
-        const int r = (t0 + tl) * 64 + lane;
-        if (r < R && !((s_unres[r >> 5] >> (r & 31)) & 1u)) out.d2[s * (int64_t)R + r] = SETTLED_BIT;
-      }
-    }
-    if (lane == 0) out.weight[s] = -1.f;
-    ++n_handled;
-    wave_lds_sync();
-  }
-  if (stats) {
+        // the witness: the first point of the winning group of four that attains the minimum
+        float4 x[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      n_pairs += __shfl_xor(n_pairs, o);
+        for (int u = 0; u < 4; ++u) x[u] = s_pts[wj + u];
+        float4 w = x[3];
+#pragma unroll
+        for (int u = 2; u >= 0; --u) {
+          float t0 = p[0] - x[u].x;
+          float d2 = t0 * t0;
+          t0 = p[1] - x[u].y;
+          d2 = __builtin_fmaf(t0, t0, d2);
+          if constexpr (DIM == 3) {
+            t0 = p[2] - x[u].z;
+            d2 = __builtin_fmaf(t0, t0, d2);
+          }
+          if (d2 == best) w = x[u];
+        }
+        // (the leaf list is dead since the barrier behind the staging pass)
+        s_wit[3 * c + 0] = w.x;
+        s_wit[3 * c + 1] = w.y;
+        s_wit[3 * c + 2] = w.z;
+      }
+      Region<DIM> rg_;
+      rg_.load(s_rg);
+      const bool cert = crow >= 0 && best <= rg_.cert_limit(p, c_sel);
+      if (stats) { const unsigned long long mc_ = __ballot(cert); if (lane == 0) count(ST_CCERT, (unsigned long long)__popcll(mc_)); }
+      deliver(cert, mb, best);
     }
-    if (lane == 0) {
-      atomicAdd(&stats[0], n_handled);
-      atomicAdd(&stats[1], n_heavy);
-      atomicAdd(&stats[2], n_over);
-      atomicAdd(&stats[3], n_dense);
-      atomicAdd(&stats[4], n_staged);
-      atomicAdd(&stats[5], n_ccert);
-      atomicAdd(&stats[6], n_live);
-      atomicAdd(&stats[7], n_rounds);
-      atomicAdd(&stats[8], n_unres);
-      atomicAdd(&stats[9], n_flagged);
-      atomicAdd(&stats[10], n_pairs);
-      atomicAdd(&stats[11], n_bins);
+    __syncthreads();
+    WPHASE(4);
+
+    // ---- 4. all samples: bound from the witnesses of the nearest coarse samples; the live ones are queued.
+    // (the table rows of the next step are in flight while this one is worked on)
+    struct FineRows {
+      float4 w4[UNRF];
+      uint32_t par[UNRF], mb[UNRF];
+      int rr[UNRF];
+      bool valid[UNRF];
+    };
+    auto load_rows = [&](int g0, FineRows& fr) {
+#pragma unroll
+      for (int u = 0; u < UNRF; ++u) {
+        const int r = g0 + u * WTHREADS + tid;
+        fr.valid[u] = r < R;
+        fr.rr[u] = fr.valid[u] ? r : R - 1;
+        if (k1 == 4) fr.w4[u] = *reinterpret_cast<const float4*>(weights + (int64_t)fr.rr[u] * 4);
+        fr.par[u] = plan.parents[fr.rr[u]];
+        fr.mb[u] = fr.valid[u] ? acc.memb[fr.rr[u]] : 0u;
+      }
+    };
+    // a sample goes straight to the finish with its bound (queue or list full)
+    auto to_finish = [&](int r, float val) {
+      out.d2[s * (int64_t)R + r] = __float_as_uint(val);
+      atomicOr(&s_unres[r >> 5], 1u << (r & 31));
+      atomicMax(&s_tkey[r >> 6], __float_as_uint(val));
+    };
+    FineRows cur;
+    load_rows(0, cur);
+    for (int g0 = 0; g0 < R; g0 += WTHREADS * UNRF) {
+      FineRows nxt;
+      if (g0 + WTHREADS * UNRF < R) load_rows(g0 + WTHREADS * UNRF, nxt);
+#pragma unroll
+      for (int u = 0; u < UNRF; ++u) {
+        if (g0 + u * WTHREADS >= R) break;  // (block-uniform)
+        float p[DIM];
+        if (k1 == 4) {
+          const float wj[4] = {cur.w4[u].x, cur.w4[u].y, cur.w4[u].z, cur.w4[u].w};
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) p[k] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) p[k] = __builtin_fmaf(wj[j], vs[j * DIM + k], p[k]);
+          }
+        } else {
+          make_sample(cur.rr[u], p);
+        }
+        float ub = __builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (int)((cur.par[u] >> (8 * j)) & 0xffu);
+          float t0 = p[0] - s_wit[3 * c + 0];
+          float d2 = t0 * t0;
+          t0 = p[1] - s_wit[3 * c + 1];
+          d2 = __builtin_fmaf(t0, t0, d2);
+          if constexpr (DIM == 3) {
+            t0 = p[2] - s_wit[3 * c + 2];
+            d2 = __builtin_fmaf(t0, t0, d2);
+          }
+          ub = __builtin_fminf(ub, d2);
+        }
+        const uint32_t thr = threshold(cur.mb[u]);
+        const bool live = cur.valid[u] && __float_as_uint(ub) > thr;
+        const unsigned long long m = __ballot(live);
+        if (m != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_ctr[1], __popcll(m));
+          base = wave_uniform(base);
+          if (live) {
+            const int pos = base + lane_rank(m);
+            if (pos < WQ) {
+              s_qub[pos] = __float_as_uint(ub);
+              s_qrow[pos] = (uint16_t)cur.rr[u];
+            } else {
+              to_finish(cur.rr[u], ub);
+            }
+          }
+          if (lane == 0) count(ST_LIVE, (unsigned long long)__popcll(m));
+        }
+      }
+      cur = nxt;
     }
+    __syncthreads();
+    WPHASE(5);
+
+    // ---- 5. the queued samples against the stage: rounds of 64 samples; while there are fewer rounds than waves a
+    // round is shared by several waves, each taking a part of the stage (minima combined in the queue entry)
+    {
+      const int n_q = s_ctr[1] < WQ ? s_ctr[1] : WQ;
+      if (n_q < s_ctr[1] && tid == 0) count(ST_UNRES, (unsigned long long)(s_ctr[1] - n_q));
+      const int n_rounds_q = (n_q + 63) >> 6;
+      const int parts = (n_rounds_q >= WWAVES || (flags & 2)) ? 1 : (n_rounds_q >= 2 ? 2 : 4);
+      const int k_part = (((K + parts - 1) / parts) + 3) & ~3;
+      for (int t = wv; t < n_rounds_q * parts; t += WWAVES) {
+        const int rnd = t / parts, part = t - rnd * parts;
+        const int qi = rnd * 64 + lane;
+        const bool mine = qi < n_q;
+        const int r = mine ? (int)s_qrow[qi] : 0;
+        float best = mine ? __uint_as_float(s_qub[qi]) : 0.f;
+        float p[DIM];
+        make_sample(r, p);
+        const uint32_t mb = mine ? acc.memb[r] : 0u;
+        // still live?  (the maxima have risen since the sample was queued)
+        const uint32_t thr = threshold(mb);  // (every lane takes part: wave-wide reductions inside)
+        const bool act = mine && __float_as_uint(best) > thr;
+        if (__ballot(act) == 0ull) continue;
+        if (part == 0 && lane == 0) count(ST_ROUNDS, 1);
+        const int j1 = (part + 1) * k_part < K ? (part + 1) * k_part : K;
+        const float seed = best;
+        for (int j = part * k_part; j < j1; j += 4) {
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = s_pts[j + u];   // (entries behind K: +inf pads or real points - harmless)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float t0 = p[0] - x[u].x;
+            float d2 = t0 * t0;
+            t0 = p[1] - x[u].y;
+            d2 = __builtin_fmaf(t0, t0, d2);
+            if constexpr (DIM == 3) {
+              t0 = p[2] - x[u].z;
+              d2 = __builtin_fmaf(t0, t0, d2);
+            }
+            best = __builtin_fminf(best, d2);
+          }
+        }
+        if (lane == 0) count(ST_PAIRS, (unsigned long long)(j1 - part * k_part) * 64ull);
+        if (act && best < seed) atomicMin(&s_qub[qi], __float_as_uint(best));
+      }
+      __syncthreads();
+      Region<DIM> rg_;
+      rg_.load(s_rg);
+      for (int rnd = wv; rnd < n_rounds_q; rnd += WWAVES) {
+        const int qi = rnd * 64 + lane;
+        const bool mine = qi < n_q;
+        const int r = mine ? (int)s_qrow[qi] : 0;
+        const float best = mine ? __uint_as_float(s_qub[qi]) : 0.f;
+        float p[DIM];
+        make_sample(r, p);
+        const uint32_t mb = mine ? acc.memb[r] : 0u;
+        const uint32_t thr = threshold(mb);  // (every lane takes part: wave-wide reductions inside)
+        const bool act = mine && __float_as_uint(best) > thr;
+        const bool cert = act && best <= rg_.cert_limit(p, c_sel);
+        const bool unres = act && !cert;
+        const unsigned long long mu = __ballot(unres);
+        if (mu != 0ull) {  // open samples: on the list of the exact pass below (or, list full, to the finish)
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_ctr[3], __popcll(mu));
+          base = wave_uniform(base);
+          if (unres) {
+            const int pos = base + lane_rank(mu);
+            if (pos < WUR && !(flags & 1)) {
+              s_ur_row[pos] = (uint16_t)r;
+              s_ur_best[pos] = __float_as_uint(best);
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) s_ur_p[pos * 3 + k] = p[k];
+            } else {
+              to_finish(r, best);
+            }
+          }
+          if (lane == 0) count(ST_UNRES, (unsigned long long)__popcll(mu));
+        }
+        deliver(cert, mb, best);
+      }
+    }
+    __syncthreads();
+    WPHASE(6);
+
+    // ---- 5b. open samples (their nearest point may lie beyond the staged region): every point within the largest
+    // bound of their box is streamed through the stage and evaluated, lanes over points - exact by construction
+    {
+      const int n_ur = (flags & 1) ? 0 : (s_ctr[3] < WUR ? s_ctr[3] : WUR);
+      if (n_ur > 0) {
+        float rmax2 = 0.f;
+        {
+          const bool on = lane < n_ur;
+          rmax2 = wave_max_f32(on ? __uint_as_float(s_ur_best[on ? lane : 0]) : 0.f);
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float v = s_ur_p[(on ? lane : 0) * 3 + k];
+            qlo[k] = wave_min_f32(on ? v : __builtin_inff());
+            qhi[k] = wave_max_f32(on ? v : -__builtin_inff());
+          }
+        }
+        const float rho = __builtin_sqrtf(rmax2) * 1.00001f + 1e-30f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { qlo[k] -= rho; qhi[k] += rho; }
+        if (tid < MAXL + 2) s_gn[tid] = 0;
+        __syncthreads();
+        {
+          int* fa = s_front;
+          int* fb = s_front + WFRONT;
+          if (wv == 0) {
+            if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
+            else test_children(top, 0, fa, &s_gn[top], WFRONT);
+          }
+          __syncthreads();
+          for (int lvl = top; lvl >= 1; --lvl) {
+            if (s_gn[MAXL] != 0) break;
+            const int na = s_gn[lvl];
+            for (int f = wv; f < na; f += WWAVES) {
+              const int grp = wave_uniform(fa[f]);
+              if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
+              else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
+            }
+            __syncthreads();
+            int* t = fa; fa = fb; fb = t;
+          }
+        }
+        const bool fits = s_gn[MAXL] == 0;
+        if (fits) {
+          const int n_cand2 = s_gn[0] * LEAF;
+          constexpr int UB_ = 3;  // (candidate slots per batch: 768 <= WCAP)
+          static_assert(WTHREADS * UB_ <= WCAP, "a batch fits the stage");
+          for (int ib = 0; ib < n_cand2; ib += WTHREADS * UB_) {
+            __syncthreads();  // (the previous batch has been read; first batch: the frontier is dead)
+            if (tid == 0) s_ctr[0] = 0;
+            __syncthreads();
+            float x[UB_][DP];
+            bool in[UB_];
+#pragma unroll
+            for (int u = 0; u < UB_; ++u) {
+              const int idx = ib + u * WTHREADS + tid;
+              in[u] = idx < n_cand2;
+              const uint32_t row = in[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+              load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB_; ++u) {
+              bool keep = in[u];
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) keep = keep && (x[u][k] >= qlo[k]) && (x[u][k] <= qhi[k]);
+              const unsigned long long m = __ballot(keep);
+              if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ctr[0], __popcll(m));
+                base = wave_uniform(base);
+                if (keep) {
+                  float4 v;
+                  v.x = x[u][0];
+                  v.y = x[u][1];
+                  v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
+                  v.w = 0.f;
+                  s_pts[base + lane_rank(m)] = v;
+                }
+              }
+            }
+            __syncthreads();
+            const int nb = s_ctr[0];
+            for (int j = wv; j < n_ur; j += WWAVES) {  // (sample j belongs to this wave alone)
+              float pj[DIM];
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) pj[k] = s_ur_p[j * 3 + k];
+              float m2 = __builtin_inff();
+              for (int i = lane; i < nb; i += 64) {
+                const float4 xx = s_pts[i];
+                float t0 = pj[0] - xx.x;
+                float d2 = t0 * t0;
+                t0 = pj[1] - xx.y;
+                d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = pj[2] - xx.z;
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                m2 = __builtin_fminf(m2, d2);
+              }
+              m2 = wave_min_f32(m2);
+              if (lane == 0 && __float_as_uint(m2) < s_ur_best[j]) s_ur_best[j] = __float_as_uint(m2);
+            }
+            if (tid == 0) count(ST_PAIRS, (unsigned long long)nb * (unsigned long long)n_ur);
+          }
+          __syncthreads();
+          if (wv == 0) {  // every value is exact now
+            const bool on = lane < n_ur;
+            const int r = on ? (int)s_ur_row[lane] : 0;
+            deliver(on, on ? acc.memb[r] : 0u, on ? __uint_as_float(s_ur_best[lane]) : 0.f);
+            if (lane == 0) count(ST_EXACT, 1);
+          }
+        } else {
+          if (tid < n_ur) to_finish((int)s_ur_row[tid], __uint_as_float(s_ur_best[tid]));
+          if (tid == 0) count(ST_EXACT_OVER, 1);
+        }
+      }
+    }
+    __syncthreads();
+    WPHASE(9);
+
+    // ---- 6. tiles with samples still unresolved go to the exact finish: the other rows of such a tile are marked settled
+    for (int t = tid; t < tiles64; t += WTHREADS)
+      if (s_tkey[t] != 0u) s_ftile[atomicAdd(&s_ctr[2], 1)] = t;
+    __syncthreads();
+    {
+      const int n_ft = s_ctr[2];
+      if (n_ft > 0) {
+        if (wv == 0) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(out.flag_count, n_ft);
+          base = wave_uniform(base);
+          for (int i = lane; i < n_ft; i += 64) {
+            const int t = s_ftile[i];
+            const uint32_t key = s_tkey[t];
+            const int item = (int)(s * tiles64 + t);
+            out.flag_list[base + i] = item;
+            if (acc.flag_key) {
+              acc.flag_key[base + i] = key;
+              atomicAdd(&acc.flag_hist[key >> 19], 1);
+            }
+            if (acc.top) {
+              const unsigned long long old =
+                  atomicMax(&acc.top[s], ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)item);
+              if (old == 0ull) acc.top_list[atomicAdd(acc.top_count, 1)] = (int)s;
+            }
+          }
+          if (lane == 0) count(ST_FLAGGED, (unsigned long long)n_ft);
+        }
+        for (int i = wv; i < n_ft; i += WWAVES) {
+          const int r = s_ftile[i] * 64 + lane;
+          if (r < R && !((s_unres[r >> 5] >> (r & 31)) & 1u)) out.d2[s * (int64_t)R + r] = SETTLED_BIT;
+        }
+      }
+    }
+    if (tid == 0) out.weight[s] = -1.f;
+    if (tid == 0) count(ST_HANDLED, 1);
+    WPHASE(7);
+  }
+  __syncthreads();
+  if (stats) {
+#ifdef FLOODER_WIT_TIMERS
+    if (tid == 0)
+      for (int i = 0; i < 10; ++i) atomicAdd(&stats[12 + i], t_ph[i]);
+#endif
+    if (tid < 24 && (tid < 12 || tid >= 22) && s_stat[tid] != 0ull) atomicAdd(&stats[tid], s_stat[tid]);
   }
 }
 
@@ -641,8 +894,8 @@ struct WitOp {
       const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
       if (rc != FLOODER_OK) return rc;
       const int grid = (int)(ns < g_wit_grid ? ns : g_wit_grid);
-      hipLaunchKernelGGL((wit_sweep_kernel<DIM>), dim3(grid), dim3(64), 0, st, pts, nodes, lv, verts, plane_tab, weights, k1,
-                         R, ns, (float)g_wit_weight, 0.01f * (float)g_wit_cmax_pct, g_wit_min_bins, plan, queue, out, acc,
+      hipLaunchKernelGGL((wit_sweep_kernel<DIM>), dim3(grid), dim3(WTHREADS), 0, st, pts, nodes, lv, verts, plane_tab, weights, k1,
+                         R, ns, (float)g_wit_weight, 0.01f * (float)g_wit_cmax_pct, 0.01f * (float)g_wit_cmax_ext_pct, g_wit_min_bins, g_wit_flags, plan, queue, out, acc,
                          stats);
       return check_launch("wit_sweep");
     } else {

@@ -342,9 +342,9 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * simplex_weight (n_simplices floats of flooder_simplex_weight_f32, READ AND WRITTEN): simplices heavier than option
  * "wit_weight" (1500), or whose neighbourhood does not fit one LDS stage, are left alone; a simplex handled here gets
  * weight -1, which flooder_sweep_cell_faces_f32 skips.  R <= FLOODER_WIT_MAX_ROWS.  queue: FLOODER_QUEUE_WORDS zeroed
- * int32.  stats: NULL or 12 zeroed uint64 {simplices handled, too heavy, gather overflow, too dense for the stage,
+ * int32.  stats: NULL or 24 zeroed uint64 {simplices handled, too heavy, gather overflow, too dense for the stage,
  * points staged, coarse samples certified, samples live after the bound, evaluation rounds, samples handed to the
- * finish, tiles flagged, pairs evaluated, excess bins kept}.  Options: "wit_cmax_pct" (250: gather radius in percent of
+ * finish, tiles flagged, pairs evaluated, excess bins kept; [12:22] cycles per phase in builds with -DFLOODER_PHASE_TIMERS}.  Options: "wit_cmax_pct" (250: gather radius in percent of
  * the local point spacing), "wit_min_bins" (6), "wit_grid".
  */
 int flooder_wit_max_rows(void);

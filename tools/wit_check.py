@@ -4,7 +4,8 @@ import sys, time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flooder_amd as fa
 from flooder_amd import core, _native
 from flooder_amd import synthetic
@@ -46,7 +47,7 @@ print("S", S, "R", R, "coarse", plan.wit[2] if plan.wit else None)
 
 def run(wit, with_stats=False, shared=True):
     core.CELL_WITNESS = wit
-    st = torch.zeros(28, dtype=torch.int64, device=dev) if with_stats else None
+    st = torch.zeros(40, dtype=torch.int64, device=dev) if with_stats else None
     out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=st, plan=plan,
                                         face_slots=slots[:2] if shared else None)
     torch.cuda.synchronize()
@@ -69,6 +70,9 @@ for shared in (True, False):
     if w[0] > 0:
         print(f"  per handled simplex: staged {w[4] / w[0]:.0f} coarse_cert {w[5] / w[0]:.0f} live {w[6] / w[0]:.0f} rounds {w[7] / w[0]:.2f} "
               f"unresolved {w[8] / w[0]:.1f} tiles {w[9] / w[0]:.2f} bins {w[11] / w[0]:.1f}")
+    if st[28:38].sum() > 0:
+        ph = st[28:38].astype(float)
+        print("  wit phases % (setup, gather, hist, stage, coarse, fine, rounds, flag, pop, -):", [round(100 * v / ph.sum(), 1) for v in ph], "Mcycles/item", round(ph.sum() / max(w[0], 1) / 1e6, 3))
     print("  cell:", [int(v) for v in st[:9]], "finish:", [int(v) for v in st[9:16]])
 
 for wit in (False, True, False, True):
