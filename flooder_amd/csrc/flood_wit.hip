@@ -35,7 +35,7 @@ using namespace flooder;
 namespace flooder {
 int g_wit_weight = 1500;    // simplices with at most this many cloud points in their box (flooder_simplex_weight_f32) are tried
 int g_wit_cmax_pct = 250;   // c_max in percent of the local point spacing
-int g_wit_grid = 256 * 3;   // persistent workgroups (one simplex at a time each)
+int g_wit_grid = 256 * 4;   // persistent workgroups (one simplex at a time each)
 int g_wit_min_bins = 6;     // the stage must hold the points of at least this many of the 64 excess bins
 int g_wit_flags = 0;        // test switches: 1 = no exact pass for the open samples, 2 = rounds not shared between waves
 int g_wit_cmax_ext_pct = 60;  // ... and at most this share of the simplex's extent
@@ -43,20 +43,27 @@ int g_wit_cmax_ext_pct = 60;  // ... and at most this share of the simplex's ext
 
 namespace {
 
+#ifndef FLOODER_WIT_BLOCKS
+#define FLOODER_WIT_BLOCKS 4
+#endif
+constexpr int WBLOCKS = FLOODER_WIT_BLOCKS;  // workgroups per CU the register budget is set for
 constexpr int WTHREADS = 256;  // one workgroup of four waves per simplex
 constexpr int WWAVES = WTHREADS / 64;
 constexpr int WCAP = 960;      // points staged per item
 constexpr int WLEAF = 1024;    // leaves gathered per item (16 K candidate points)
 constexpr int WFRONT = 192;    // inner nodes per level of the gather
 constexpr int WCOARSE = FLOODER_WIT_MAX_COARSE;  // coarse samples per item (one per thread)
-constexpr int WUR = 64;        // open samples resolved by the exact pass per item (beyond: to the finish)
+constexpr int WFOCUS = 16;      // open samples settled per focus round of the exact pass
+constexpr int WROUNDS = 8;      // focus rounds per item at most
+constexpr int WUR = 256;        // open samples resolved by the exact pass per item (beyond: to the finish)
 constexpr int WQ = 768;        // queued live samples (beyond: handed to the finish with their bound)
 constexpr int WROWS = FLOODER_WIT_MAX_ROWS;      // samples per simplex at most
 constexpr int UNR = 4;         // candidate rows in flight per lane
-constexpr int UNRF = 2;        // groups of 256 rows in flight in the pass over all samples
+constexpr int UNRF = 1;        // groups of 256 rows in flight in the pass over all samples
 constexpr int NBIN = 64;
 constexpr int PLANE_ROW = 24;  // (layout of simplex_planes_kernel, flood_cell.hip)
 static_assert(WCOARSE == WTHREADS, "one coarse sample per thread");
+static_assert(WUR == WTHREADS, "one open sample per thread in the exact pass");
 
 template <int DP>
 __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint32_t byte_off, float (&out)[DP]) {
@@ -172,7 +179,7 @@ struct Excess {
 };
 
 template <int DIM>
-__global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
+__global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv, const float* __restrict__ verts,
     const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R, int64_t n_simplices,
     float w_limit, float cmax_mult, float cmax_ext, int min_bins, int flags, WitPlan plan, int32_t* __restrict__ queue, WitOut out, FaceAcc acc,
@@ -192,6 +199,8 @@ __global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
   __shared__ uint16_t s_ur_row[WUR];   // samples left open by the stage: row, bound, coordinates
   __shared__ uint32_t s_ur_best[WUR];
   __shared__ float s_ur_p[WUR * 3];
+  __shared__ uint16_t s_focus[WFOCUS];
+  __shared__ uint32_t s_fx[8];       // exact pass: [0] largest open bound, [1] focus samples
   __shared__ float s_rg[Region<DIM>::WORDS];
   __shared__ long long s_item;
   static_assert(2 * WFRONT * sizeof(int) <= WCAP * sizeof(float4), "the gather's frontier lives inside the empty stage");
@@ -718,49 +727,95 @@ __global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
     __syncthreads();
     WPHASE(6);
 
-    // ---- 5b. open samples (their nearest point may lie beyond the staged region): every point within the largest
-    // bound of their box is streamed through the stage and evaluated, lanes over points - exact by construction
+    // ---- 5b. open samples (their nearest point may lie beyond the staged region), in FOCUS ROUNDS: the open samples
+    // with the largest bounds (within focus_frac of the largest, at most WFOCUS) get every point within that bound of
+    // their box streamed through the stage, lanes over points - exact by construction; their values raise the face
+    // maxima, and most of the other open samples - the neighbours of the deepest one in a void - drop against those
+    // without a search of their own.  What is still open after WROUNDS rounds goes to the finish.
     {
       const int n_ur = (flags & 1) ? 0 : (s_ctr[3] < WUR ? s_ctr[3] : WUR);
       if (n_ur > 0) {
-        float rmax2 = 0.f;
-        {
-          const bool on = lane < n_ur;
-          rmax2 = wave_max_f32(on ? __uint_as_float(s_ur_best[on ? lane : 0]) : 0.f);
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) {
-            const float v = s_ur_p[(on ? lane : 0) * 3 + k];
-            qlo[k] = wave_min_f32(on ? v : __builtin_inff());
-            qhi[k] = wave_max_f32(on ? v : -__builtin_inff());
-          }
-        }
-        const float rho = __builtin_sqrtf(rmax2) * 1.00001f + 1e-30f;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) { qlo[k] -= rho; qhi[k] += rho; }
-        if (tid < MAXL + 2) s_gn[tid] = 0;
-        __syncthreads();
-        {
-          int* fa = s_front;
-          int* fb = s_front + WFRONT;
-          if (wv == 0) {
-            if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
-            else test_children(top, 0, fa, &s_gn[top], WFRONT);
+        const bool mine = tid < n_ur;
+        const int r = mine ? (int)s_ur_row[tid] : 0;
+        const uint32_t mb = mine ? acc.memb[r] : 0u;
+        bool done = !mine;
+        for (int round = 0; round <= WROUNDS; ++round) {
+          // who is still alive?  (every lane takes part in the threshold's wave-wide reductions)
+          const uint32_t thr = threshold(done ? 0u : mb);
+          const uint32_t bb = mine ? s_ur_best[tid] : 0u;
+          const bool alive = !done && bb > thr;
+          done = done || !alive;
+          if (tid < 8) s_fx[tid] = tid < 4 ? 0u : 0u;
+          __syncthreads();
+          {
+            const uint32_t wm = wave_max_u32(alive ? bb : 0u);
+            if (lane == 0 && wm != 0u) atomicMax(&s_fx[0], wm);
           }
           __syncthreads();
-          for (int lvl = top; lvl >= 1; --lvl) {
-            if (s_gn[MAXL] != 0) break;
-            const int na = s_gn[lvl];
-            for (int f = wv; f < na; f += WWAVES) {
-              const int grp = wave_uniform(fa[f]);
-              if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
-              else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
+          const uint32_t bmax = s_fx[0];
+          if (bmax == 0u) break;                       // (block-uniform) nothing left
+          if (round == WROUNDS) {                      // out of rounds: the rest goes to the finish
+            if (alive) to_finish(r, __uint_as_float(bb));
+            break;
+          }
+          // focus set: the largest bounds, compacted (at most WFOCUS)
+          bool focus = alive && __uint_as_float(bb) >= 0.97f * __uint_as_float(bmax);
+          {
+            const unsigned long long mf_ = __ballot(focus);
+            if (mf_ != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd((int*)&s_fx[1], __popcll(mf_));
+              base = wave_uniform(base);
+              const int pos = base + lane_rank(mf_);
+              focus = focus && pos < WFOCUS;
+              if (focus) s_focus[pos] = (uint16_t)tid;
+            }
+          }
+          __syncthreads();
+          const int n_f = (int)s_fx[1] < WFOCUS ? (int)s_fx[1] : WFOCUS;
+          // box of the focus samples and their largest bound (every wave computes the same from the list)
+          float rmax2 = 0.f;
+          {
+            const bool on = lane < n_f;
+            const int e = on ? (int)s_focus[lane] : 0;
+            rmax2 = wave_max_f32(on ? __uint_as_float(s_ur_best[e]) : 0.f);
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float v = s_ur_p[e * 3 + k];
+              qlo[k] = wave_min_f32(on ? v : __builtin_inff());
+              qhi[k] = wave_max_f32(on ? v : -__builtin_inff());
+            }
+          }
+          const float rho = __builtin_sqrtf(rmax2) * 1.00001f + 1e-30f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) { qlo[k] -= rho; qhi[k] += rho; }
+          if (tid < MAXL + 2) s_gn[tid] = 0;
+          __syncthreads();
+          {
+            int* fa = s_front;
+            int* fb = s_front + WFRONT;
+            if (wv == 0) {
+              if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
+              else test_children(top, 0, fa, &s_gn[top], WFRONT);
             }
             __syncthreads();
-            int* t = fa; fa = fb; fb = t;
+            for (int lvl = top; lvl >= 1; --lvl) {
+              if (s_gn[MAXL] != 0) break;
+              const int na = s_gn[lvl];
+              for (int f = wv; f < na; f += WWAVES) {
+                const int grp = wave_uniform(fa[f]);
+                if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
+                else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
+              }
+              __syncthreads();
+              int* t = fa; fa = fb; fb = t;
+            }
           }
-        }
-        const bool fits = s_gn[MAXL] == 0;
-        if (fits) {
+          if (s_gn[MAXL] != 0) {  // too many points within the bound: the tree search of the finish is the better tool
+            if (alive) to_finish(r, __uint_as_float(bb));
+            if (tid == 0) count(ST_EXACT_OVER, 1);
+            break;
+          }
           const int n_cand2 = s_gn[0] * LEAF;
           constexpr int UB_ = 3;  // (candidate slots per batch: 768 <= WCAP)
           static_assert(WTHREADS * UB_ <= WCAP, "a batch fits the stage");
@@ -799,10 +854,11 @@ __global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
             }
             __syncthreads();
             const int nb = s_ctr[0];
-            for (int j = wv; j < n_ur; j += WWAVES) {  // (sample j belongs to this wave alone)
+            for (int j = wv; j < n_f; j += WWAVES) {  // (focus sample j belongs to this wave alone)
+              const int e = (int)s_focus[j];
               float pj[DIM];
 #pragma unroll
-              for (int k = 0; k < DIM; ++k) pj[k] = s_ur_p[j * 3 + k];
+              for (int k = 0; k < DIM; ++k) pj[k] = s_ur_p[e * 3 + k];
               float m2 = __builtin_inff();
               for (int i = lane; i < nb; i += 64) {
                 const float4 xx = s_pts[i];
@@ -817,20 +873,16 @@ __global__ __launch_bounds__(WTHREADS, 3) void wit_sweep_kernel(
                 m2 = __builtin_fminf(m2, d2);
               }
               m2 = wave_min_f32(m2);
-              if (lane == 0 && __float_as_uint(m2) < s_ur_best[j]) s_ur_best[j] = __float_as_uint(m2);
+              if (lane == 0 && __float_as_uint(m2) < s_ur_best[e]) s_ur_best[e] = __float_as_uint(m2);
             }
-            if (tid == 0) count(ST_PAIRS, (unsigned long long)nb * (unsigned long long)n_ur);
+            if (tid == 0) count(ST_PAIRS, (unsigned long long)nb * (unsigned long long)n_f);
           }
           __syncthreads();
-          if (wv == 0) {  // every value is exact now
-            const bool on = lane < n_ur;
-            const int r = on ? (int)s_ur_row[lane] : 0;
-            deliver(on, on ? acc.memb[r] : 0u, on ? __uint_as_float(s_ur_best[lane]) : 0.f);
-            if (lane == 0) count(ST_EXACT, 1);
-          }
-        } else {
-          if (tid < n_ur) to_finish((int)s_ur_row[tid], __uint_as_float(s_ur_best[tid]));
-          if (tid == 0) count(ST_EXACT_OVER, 1);
+          // the focus samples are exact now: deliver them (all lanes of every wave take part in the reductions)
+          deliver(focus, mb, __uint_as_float(focus ? s_ur_best[tid] : 0u));
+          done = done || focus;
+          if (tid == 0) count(ST_EXACT, 1);
+          __syncthreads();
         }
       }
     }

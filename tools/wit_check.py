@@ -66,6 +66,7 @@ for shared in (True, False):
     names = ["handled", "too_heavy", "gather_over", "too_dense", "staged", "coarse_cert", "live", "rounds", "unresolved",
              "tiles_flagged", "pairs", "bins"]
     w = st[16:28]
+    print("  exact passes", int(st[38]), "gather overflow there", int(st[39]))
     print("  wit:", {n: int(v) for n, v in zip(names, w)})
     if w[0] > 0:
         print(f"  per handled simplex: staged {w[4] / w[0]:.0f} coarse_cert {w[5] / w[0]:.0f} live {w[6] / w[0]:.0f} rounds {w[7] / w[0]:.2f} "
@@ -75,6 +76,7 @@ for shared in (True, False):
         print("  wit phases % (setup, gather, hist, stage, coarse, fine, rounds, flag, pop, -):", [round(100 * v / ph.sum(), 1) for v in ph], "Mcycles/item", round(ph.sum() / max(w[0], 1) / 1e6, 3))
     print("  cell:", [int(v) for v in st[:9]], "finish:", [int(v) for v in st[9:16]])
 
+res = {}
 for wit in (False, True, False, True):
     core.CELL_WITNESS = wit
     tm = core._KernelTimer()
@@ -86,4 +88,6 @@ for wit in (False, True, False, True):
         ev[i + 1].record()
     torch.cuda.synchronize()
     ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+    res[wit] = (ms.mean(), ms.min(), {k: round(v / steps, 4) for k, v in tm.totals_ms().items()})
     print(f"witness={wit}: sweep-only step {ms.mean():.4f} ms (min {ms.min():.4f})", {k: round(v / steps, 4) for k, v in tm.totals_ms().items()})
+print("SUMMARY", wl, " ".join(opts), f"| wit {res[True][0]:.4f} (min {res[True][1]:.4f}) {res[True][2]} | off {res[False][0]:.4f}")
