@@ -60,7 +60,7 @@ WORKLOADS = {
                     cpu_sample=400),
 }
 
-KERNEL_OF_SPAN = {"sweep": "cell_sweep_kernel", "sweep_bvh": "sweep_bvh_kernel / sample_keys + radix sort + sweep_sorted_kernel", "sweep_ball": "sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
+KERNEL_OF_SPAN = {"sweep": "wit_sweep_kernel + cell_sweep_kernel", "sweep_bvh": "sweep_bvh_kernel / sample_keys + radix sort + sweep_sorted_kernel", "sweep_ball": "sweep_kernel", "fallback": "finish_faces_kernel (exact finish: top + rest pass)",
                   "face_max": "face_values_kernel", "reduce": "all_reduce(MIN)",
                   "index": "index build (bbox, curve codes, rocprim radix sort, gather, box tree)",
                   "ball_count": "ball_scan_kernel<count>", "ball_fill": "ball_scan_kernel<fill>"}
@@ -123,6 +123,7 @@ def parse_args():
     ap.add_argument("--units", default=None, help="cut sizes of the sample bisection, e.g. 1024/256/64/16")
     ap.add_argument("--no-slots", action="store_true", help="one face-maximum word per (simplex, face) instead of per distinct face")
     ap.add_argument("--no-super", action="store_true", help="cell sweep chunk by chunk (no shared stage per run of four)")
+    ap.add_argument("--no-witness", action="store_true", help="no witness sweep: every simplex goes through the cell sweep")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
     return ap.parse_args()
@@ -187,6 +188,8 @@ def main():
         core.FUSED_FACES = False
     if args.no_super:
         core.CELL_SUPER = False
+    if args.no_witness:
+        core.CELL_WITNESS = False
     if args.units:
         core.SAMPLE_UNITS = tuple(int(v) for v in args.units.split("/"))
     w = WORKLOADS[args.workload]
@@ -319,7 +322,7 @@ def main():
     else:
         P_local = int(cnt0.sum().item()) if not (world > 1 and args.shard == "points") else int(cnt0.sum().item()) // world
     del cnt0
-    stats = torch.zeros(16, dtype=torch.int64, device=dev)
+    stats = torch.zeros(40, dtype=torch.int64, device=dev)   # [0:9] cell sweep, [9:16] finish, [16:40] witness sweep
     plan = core.SamplePlan(weights, faces)
     # one running maximum per DISTINCT face of the complex, as flood_complex uses on one GPU (shards keep (S, F))
     slots = None
@@ -461,10 +464,19 @@ def main():
     elif args.method == "cell":
         sh = stats.cpu().tolist()
         tiles_total = S * ((R + 63) // 64)
-        flagged = sh[2]
-        per_kernel["sweep"] = dict(pairs=sh[0], share=(tiles_total - flagged) / max(tiles_total, 1))
+        wit = sh[16:40]
+        # pairs the witness sweep evaluates: stage x samples (coarse, rounds, exact pass) + the four witness distances of
+        # every sample of a simplex it handles
+        wit_pairs = wit[10] + 4 * wit[0] * R
+        flagged = sh[2] + wit[9]
+        per_kernel["sweep"] = dict(pairs=sh[0] + wit_pairs, share=(tiles_total - flagged) / max(tiles_total, 1))
         per_kernel["fallback"] = dict(pairs=sh[9] * 16 * 64, share=flagged / max(tiles_total, 1))
-        st_h = {"cell_pairs": sh[0], "points_staged": sh[1], "tiles_flagged": sh[2],
+        st_h = {"witness": {"simplices_handled": wit[0], "too_heavy": wit[1], "gather_overflow": wit[2], "too_dense": wit[3],
+                            "points_staged": wit[4], "coarse_certified": wit[5], "samples_live_after_bound": wit[6],
+                            "rounds": wit[7], "samples_open_after_stage": wit[8], "tiles_flagged": wit[9],
+                            "pairs_stage": wit[10], "pairs_bound": 4 * wit[0] * R, "focus_rounds": wit[22],
+                            "focus_gather_overflow": wit[23], "enabled": bool(core.CELL_WITNESS)},
+                "cell_pairs": sh[0], "points_staged": sh[1], "tiles_flagged": sh[2],
                 "restage_rounds": sh[3], "tiles_total": tiles_total,
                 "chunks_total": S * ((R + 255) // 256),
                 "giveup_gather_density": sh[4], "giveup_gather_stage": sh[5], "giveup_lds_full": sh[6],

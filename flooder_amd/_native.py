@@ -70,7 +70,7 @@ SIGNATURES = {
     "flooder_wit_max_coarse": (c_int, []),
     "flooder_sweep_witness_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_finish_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

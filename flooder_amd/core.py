@@ -1013,7 +1013,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                     qwit.data_ptr(), _native.ptr(d2), _native.ptr(plan.memb_all), F, _native.ptr(face_bits),
                     _native.ptr(slot_t), _native.ptr(flags[0]), ctl[1:].data_ptr(), _native.ptr(flags[1]),
                     ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list), fctl[3:].data_ptr(),
-                    _native.ptr(wgt), _native.ptr(planes), _native.ptr(wst), st), "flooder_sweep_witness_f32")
+                    _native.ptr(wgt), _native.ptr(split[0]), _native.ptr(planes), _native.ptr(wst), st),
+                    "flooder_sweep_witness_f32")   # (split[0]: scratch until the cell sweep's entry fills it)
             _native.check(lib.flooder_sweep_cell_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
                 _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),

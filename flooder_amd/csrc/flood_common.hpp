@@ -54,6 +54,12 @@ extern int g_wit_cmax_pct;  // ... its gather radius in percent of the local poi
 extern int g_wit_grid;      // ... its persistent one-wave workgroups
 extern int g_wit_cmax_ext_pct;
 extern int g_wit_flags;
+extern int g_wit_adaptive;
+extern int g_wit_max_open;
+extern int g_wit_max_eval;
+extern int g_wit_max_leaves;
+extern int g_wit_max_in_pct;
+extern int g_wit_max_live_pct;
 extern int g_wit_min_bins;  // ... excess bins (of 64) the stage must hold at least
 // face planes of every simplex (flood_cell.hip: simplex_planes_kernel), 24 floats per simplex
 int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st);

@@ -707,6 +707,30 @@ int flooder_set_option(const char* name, int value) {
     g_wit_cmax_ext_pct = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "wit_max_in_pct") == 0 && value >= 0) {
+    g_wit_max_in_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_max_leaves") == 0 && value >= 1) {
+    g_wit_max_leaves = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_max_eval") == 0 && value >= 0) {
+    g_wit_max_eval = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_max_open") == 0 && value >= 0) {
+    g_wit_max_open = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_max_live_pct") == 0 && value >= 0 && value <= 100) {
+    g_wit_max_live_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "wit_adaptive") == 0 && (value == 0 || value == 1)) {
+    g_wit_adaptive = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "wit_flags") == 0 && value >= 0) {
     g_wit_flags = value;
     return FLOODER_OK;

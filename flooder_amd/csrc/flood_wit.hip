@@ -33,10 +33,17 @@
 using namespace flooder;
 
 namespace flooder {
-int g_wit_weight = 1500;    // simplices with at most this many cloud points in their box (flooder_simplex_weight_f32) are tried
+int g_wit_weight = 800;     // simplices with at most this many cloud points in their box (flooder_simplex_weight_f32) are tried
 int g_wit_cmax_pct = 250;   // c_max in percent of the local point spacing
 int g_wit_grid = 256 * 4;   // persistent workgroups (one simplex at a time each)
-int g_wit_min_bins = 6;     // the stage must hold the points of at least this many of the 64 excess bins
+int g_wit_min_bins = 48;    // (measured: sparse simplices of a Gaussian keep 50 - 64 bins, the slivers along a surface 10 - 25)
+//    // the stage must hold the points of at least this many of the 64 excess bins
+int g_wit_max_in_pct = 8;   // points inside the simplex itself, in percent of its samples, it may hold at most (denser: every sample has a nearest point of its own, nothing to share)
+int g_wit_max_leaves = 400; // leaves (16 points each) the region around a simplex may overlap; more: too dense around it, no attempt
+int g_wit_max_eval = 768;   // queued samples an item evaluates against its stage at most (the rest: to the finish)
+int g_wit_max_open = 48;    // coarse samples the stage may leave open; more: far field, the simplex is left to the cell sweep
+int g_wit_max_live_pct = 12; // ... and the share of all samples that may survive the bound
+int g_wit_adaptive = 0;     // 1: once half of the simplices tried had to be abandoned, only every 16th is still tried
 int g_wit_flags = 0;        // test switches: 1 = no exact pass for the open samples, 2 = rounds not shared between waves
 int g_wit_cmax_ext_pct = 60;  // ... and at most this share of the simplex's extent
 }  // namespace flooder
@@ -63,7 +70,7 @@ constexpr int UNRF = 1;        // groups of 256 rows in flight in the pass over 
 constexpr int NBIN = 64;
 constexpr int PLANE_ROW = 24;  // (layout of simplex_planes_kernel, flood_cell.hip)
 static_assert(WCOARSE == WTHREADS, "one coarse sample per thread");
-static_assert(WUR == WTHREADS, "one open sample per thread in the exact pass");
+static_assert(WUR == WTHREADS && WUR >= WCOARSE, "one open sample per thread in the exact pass");
 
 template <int DP>
 __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint32_t byte_off, float (&out)[DP]) {
@@ -182,13 +189,14 @@ template <int DIM>
 __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv, const float* __restrict__ verts,
     const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R, int64_t n_simplices,
-    float w_limit, float cmax_mult, float cmax_ext, int min_bins, int flags, WitPlan plan, int32_t* __restrict__ queue, WitOut out, FaceAcc acc,
+    float w_limit, float cmax_mult, float cmax_ext, int min_bins, int flags, int max_open, int max_live, int max_in, int adaptive, int leaf_cap, int max_eval, const int32_t* __restrict__ item_list, const int32_t* __restrict__ item_count, WitPlan plan, int32_t* __restrict__ queue, WitOut out, FaceAcc acc,
     unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
   __shared__ float4 s_pts[WCAP + 4];
   __shared__ int s_leaf[WLEAF];
-  __shared__ uint32_t s_qub[WQ];
-  __shared__ uint16_t s_qrow[WQ];
+  __shared__ uint32_t s_qbuf[WQ + WQ / 2];  // queue of live samples: bounds, then rows (16 bit); focus rounds: point batches
+  __shared__ int s_front[2 * WFRONT];       // gather: frontier of the current and the next tree level
+  __shared__ float s_wit[3 * WCOARSE];      // witness of every coarse sample
   __shared__ int s_hist[NBIN];
   __shared__ uint32_t s_mf[32];
   __shared__ uint32_t s_unres[WROWS / 32];
@@ -198,15 +206,20 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
   __shared__ int s_ctr[4];        // [0] points staged, [1] samples queued, [2] tiles flagged, [3] open samples
   __shared__ uint16_t s_ur_row[WUR];   // samples left open by the stage: row, bound, coordinates
   __shared__ uint32_t s_ur_best[WUR];
+  __shared__ int16_t s_ur_slot[WUR];   // coarse slot of the entry (-1: not a coarse sample)
   __shared__ float s_ur_p[WUR * 3];
   __shared__ uint16_t s_focus[WFOCUS];
   __shared__ uint32_t s_fx[8];       // exact pass: [0] largest open bound, [1] focus samples
   __shared__ float s_rg[Region<DIM>::WORDS];
   __shared__ long long s_item;
-  static_assert(2 * WFRONT * sizeof(int) <= WCAP * sizeof(float4), "the gather's frontier lives inside the empty stage");
-  static_assert(WCOARSE * 3 * sizeof(float) <= WLEAF * sizeof(int), "the witness table takes the place of the leaf list");
-  int* s_front = reinterpret_cast<int*>(s_pts);
-  float* s_wit = reinterpret_cast<float*>(s_leaf);  // (after staging the leaf list is dead)
+  __shared__ int s_off;            // the sweep has switched itself off (see below)
+  uint32_t* s_qub = s_qbuf;
+  uint16_t* s_qrow = reinterpret_cast<uint16_t*>(s_qbuf + WQ);
+  // (the focus rounds run while the queue is empty - before the pass over all samples, after the rounds - and stream
+  // their candidate points through its storage: the stage itself stays intact for the rounds in between)
+  float4* s_xb = reinterpret_cast<float4*>(s_qbuf);
+  constexpr int XB = 256;  // points per batch
+  static_assert(XB * sizeof(float4) <= sizeof(uint32_t) * (WQ + WQ / 2) && XB == WTHREADS, "a batch fits the queue's storage");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
@@ -234,8 +247,14 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     WPHASE(8);
     __syncthreads();  // (the previous item's LDS is free)
     if (wv == 0) {
-      const int64_t it = queue_pop(queue, q_shard, q_tried, n_simplices, lane);
-      if (lane == 0) s_item = (long long)it;
+      const int64_t it = queue_pop(queue, q_shard, q_tried, (int64_t)item_count[0], lane);
+      if (lane == 0) {
+        s_item = (long long)it;
+        // (one reading for the whole workgroup: its waves must agree)
+        const int tried = __hip_atomic_load(&queue[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int dropped = __hip_atomic_load(&queue[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_off = (adaptive && tried >= 8 && 2 * dropped > tried) ? 1 : 0;
+      }
     }
     if (tid < MAXL + 2) s_gn[tid] = 0;
     if (tid < 4) s_ctr[tid] = 0;
@@ -243,10 +262,22 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     for (int i = tid; i < WROWS / 32; i += WTHREADS) s_unres[i] = 0u;
     for (int i = tid; i < WROWS / 64; i += WTHREADS) s_tkey[i] = 0u;
     __syncthreads();
-    const int64_t s = (int64_t)s_item;
-    if (s < 0) break;
+    if (s_item < 0) break;
+    const int64_t s = (int64_t)item_list[s_item];   // (wit_list_kernel: the simplices light enough, heaviest class first)
     const float w_s = out.weight[s];
-    if (!(w_s <= w_limit) || w_s < 0.f) { if (tid == 0) count(ST_HEAVY, 1); continue; }
+    // the sweep watches its own success: a cloud whose light simplices are mostly abandoned again (a surface: few
+    // points per box but dense where they are; voids of a dense cloud) is not worth the attempts - only every 16th
+    // is still made, which keeps the counters alive.  (Racy reads, any outcome: the values do not depend on who
+    // sweeps a simplex.)
+    if (s_off != 0 && (s & 15) != 0) { if (tid == 0) count(ST_HEAVY, 1); continue; }
+#ifdef FLOODER_WIT_TIMERS
+    const unsigned long long t_item0 = __builtin_amdgcn_s_memrealtime();
+#define WIT_REC(slot, val) do { if (stats && tid == 0) stats[64 + 12 * s + (slot)] = (unsigned long long)(val); } while (0)
+#else
+#define WIT_REC(slot, val) do {} while (0)
+#endif
+    WIT_REC(0, __float_as_uint(w_s));
+#define WIT_ABANDON(what) { WIT_REC(10, 100 + what); WIT_REC(11, __builtin_amdgcn_s_memrealtime() - t_item0); if (tid == 0) { count(what, 1); if ((s & 7) == 0) { atomicAdd(&queue[8], 1); atomicAdd(&queue[9], 1); } } continue; }  // (every 8th simplex is counted: same-address atomics are slow)
     const float* vs = verts + s * (int64_t)k1 * DIM;
     WPHASE(0);
 
@@ -306,36 +337,68 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       c_max = __builtin_fminf(cmax_mult * h, cmax_ext * ext);
       if (tid == 0) rg.store(s_rg);
     }
-    if (!(c_max > 0.f) || !(c_max < 3.0e38f)) { if (tid == 0) count(ST_OVER, 1); continue; }
+    if (!(c_max > 0.f) || !(c_max < 3.0e38f)) WIT_ABANDON(ST_OVER)
     __syncthreads();
 
     // ---- gather: leaves of the box tree overlapping [qlo, qhi] -> s_leaf, s_gn[0] of them; the frontier groups of a
     // level are dealt to the four waves, every level ends with a barrier
     float qlo[DIM], qhi[DIM];
-    auto test_children = [&](int lvl, int grp, int* out_list, int* out_n, int cap) {
+    // children of up to GB frontier nodes per call: their boxes are loaded together (a call is a memory round trip)
+    constexpr int GB = 4;
+    auto test_children = [&](int lvl, const int (&grp)[GB], int ng, int* out_list, int* out_n, int cap) {
       const int lvl_count = (int)lv.count[lvl], lvl_off = (int)lv.off[lvl];
-      const int idx = grp * FAN + lane;
-      bool hit = idx < lvl_count;
-      float lo[DP], hi[DP];
-      const uint32_t nb_ = (uint32_t)(lvl_off + (hit ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
-      load_row_at<DP>(nodes, nb_, lo);
-      load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
+      bool hit[GB];
+      float lo[GB][DP], hi[GB][DP];
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) hit = hit && (lo[k] <= qhi[k]) && (hi[k] >= qlo[k]);
-      const unsigned long long m = __ballot(hit);
-      const int cnt = __popcll(m);
-      if (cnt == 0) return;
-      int base = 0;
-      if (lane == 0) base = atomicAdd(out_n, cnt);
-      base = wave_uniform(base);
-      if (base + cnt > cap) {
-        if (lane == 0) s_gn[MAXL] = 1;
-      } else if (hit) {
-        out_list[base + lane_rank(m)] = idx;
+      for (int u = 0; u < GB; ++u) {
+        const int idx = grp[u] * FAN + lane;
+        hit[u] = u < ng && idx < lvl_count;
+        const uint32_t nb_ = (uint32_t)(lvl_off + (hit[u] ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+        load_row_at<DP>(nodes, nb_, lo[u]);
+        load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        if (u < ng) {
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) hit[u] = hit[u] && (lo[u][k] <= qhi[k]) && (hi[u][k] >= qlo[k]);
+          const unsigned long long m = __ballot(hit[u]);
+          const int cnt = __popcll(m);
+          if (cnt != 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(out_n, cnt);
+            base = wave_uniform(base);
+            if (base + cnt > cap) {
+              if (lane == 0) s_gn[MAXL] = 1;
+            } else if (hit[u]) {
+              out_list[base + lane_rank(m)] = grp[u] * FAN + lane;
+            }
+          }
+        }
+      }
+    };
+    // one level of the walk: the frontier's groups dealt to the waves, GB at a time; stops at an overflow
+    auto walk_level = [&](int lvl, const int* fa, int* fb, int leaf_cap_) {
+      const int na = s_gn[lvl];
+      for (int f = wv * GB; f < na; f += WWAVES * GB) {
+        if (*(volatile int*)&s_gn[MAXL] != 0) break;
+        int grp[GB];
+        const int ng = na - f < GB ? na - f : GB;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) grp[u] = wave_uniform(fa[f + u < na ? f + u : f]);
+        if (lvl == 1) test_children(0, grp, ng, s_leaf, &s_gn[0], leaf_cap_);
+        else test_children(lvl - 1, grp, ng, fb, &s_gn[lvl - 1], WFRONT);
+      }
+    };
+    auto walk_top = [&](int* fa, int leaf_cap_) {
+      if (wv == 0) {
+        const int g0_[GB] = {};
+        if (top == 0) test_children(0, g0_, 1, s_leaf, &s_gn[0], leaf_cap_);
+        else test_children(top, g0_, 1, fa, &s_gn[top], WFRONT);
       }
     };
     bool gathered = false;
-    for (int att = 0; att < 3; ++att) {
+    for (int att = 0; att < 1; ++att) {  // (one try: a region with more leaves than the cap is no case for this sweep)
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
         qlo[k] = s_rg[Region<DIM>::WORDS - 2 - 3 * DIM + 3 * k + 1] - s_rg[Region<DIM>::WORDS - 1] - c_max;
@@ -343,19 +406,11 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       }
       int* fa = s_front;
       int* fb = s_front + WFRONT;
-      if (wv == 0) {
-        if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
-        else test_children(top, 0, fa, &s_gn[top], WFRONT);
-      }
+      walk_top(fa, leaf_cap);
       __syncthreads();
       for (int lvl = top; lvl >= 1; --lvl) {
         if (s_gn[MAXL] != 0) break;  // (overflow: the lists are incomplete - block-uniform, read behind a barrier)
-        const int na = s_gn[lvl];
-        for (int f = wv; f < na; f += WWAVES) {
-          const int grp = wave_uniform(fa[f]);
-          if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
-          else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
-        }
+        walk_level(lvl, fa, fb, leaf_cap);
         __syncthreads();
         int* t = fa; fa = fb; fb = t;
       }
@@ -365,8 +420,9 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       c_max *= 0.5f;
       __syncthreads();
     }
-    if (!gathered) { if (tid == 0) count(ST_OVER, 1); continue; }
+    if (!gathered) WIT_ABANDON(ST_OVER)
     const int n_leaves = s_gn[0];
+    WIT_REC(1, n_leaves);
     WPHASE(1);
 
     const float bin_scale = (float)NBIN / c_max;
@@ -407,7 +463,10 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       n_keep_bins = __popcll(fit);
       n_stage = n_keep_bins > 0 ? __shfl(cum, n_keep_bins - 1) : 0;
     }
-    if (n_keep_bins < min_bins || n_stage == 0) { if (tid == 0) count(ST_DENSE, 1); continue; }   // too dense for one stage (or nothing near)
+    WIT_REC(2, s_hist[0]); WIT_REC(3, n_stage); WIT_REC(4, n_keep_bins);
+    // (bin 0: the points inside the simplex or within c_max / 64 of it)
+    if (s_hist[0] > max_in) WIT_ABANDON(ST_DENSE)
+    if (n_keep_bins < min_bins || n_stage == 0) WIT_ABANDON(ST_DENSE)   // too dense for one stage (or nothing near)
     c_sel = (float)n_keep_bins / bin_scale;
     // ---- 2b. stage the points of the kept bins (any order: a minimum does not care)
     __syncthreads();  // (the frontier inside the stage is dead)
@@ -498,6 +557,174 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       }
       return thr;
     };
+    // a sample goes straight to the finish with its bound (queue or list full)
+    auto to_finish = [&](int r, float val) {
+      out.d2[s * (int64_t)R + r] = __float_as_uint(val);
+      atomicOr(&s_unres[r >> 5], 1u << (r & 31));
+      atomicMax(&s_tkey[r >> 6], __float_as_uint(val));
+    };
+    // ---- open samples (their nearest point may lie beyond the staged region) are settled in FOCUS ROUNDS: the open samples
+    // with the largest bounds (within focus_frac of the largest, at most WFOCUS) get every point within that bound of
+    // their box streamed through the stage, lanes over points - exact by construction; their values raise the face
+    // maxima, and most of the other open samples - the neighbours of the deepest one in a void - drop against those
+    // without a search of their own.  What is still open after WROUNDS rounds goes to the finish.
+    // Returns false when `give_up` is set and samples are left open (too many points within their bounds, or out of
+    // rounds): the caller abandons the item - nothing has been handed to the finish then.
+    auto focus_rounds = [&](int n_ur, bool give_up) -> bool {
+      bool all_settled = true;
+      if (n_ur > 0) {
+        const bool mine = tid < n_ur;
+        const int r = mine ? (int)s_ur_row[tid] : 0;
+        const uint32_t mb = mine ? acc.memb[r] : 0u;
+        bool done = !mine;
+        for (int round = 0; round <= WROUNDS; ++round) {
+          // who is still alive?  (every lane takes part in the threshold's wave-wide reductions)
+          const uint32_t thr = threshold(done ? 0u : mb);
+          const uint32_t bb = mine ? s_ur_best[tid] : 0u;
+          const bool alive = !done && bb > thr;
+          done = done || !alive;
+          if (tid < 8) s_fx[tid] = tid < 4 ? 0u : 0u;
+          __syncthreads();
+          {
+            const uint32_t wm = wave_max_u32(alive ? bb : 0u);
+            if (lane == 0 && wm != 0u) atomicMax(&s_fx[0], wm);
+          }
+          __syncthreads();
+          const uint32_t bmax = s_fx[0];
+          if (bmax == 0u) break;                       // (block-uniform) nothing left
+          if (round == WROUNDS) {                      // out of rounds: the rest goes to the finish
+            if (alive && !give_up) to_finish(r, __uint_as_float(bb));
+            all_settled = false;
+            break;
+          }
+          // focus set: the largest bounds, compacted (at most WFOCUS)
+          bool focus = alive && __uint_as_float(bb) >= 0.97f * __uint_as_float(bmax);
+          {
+            const unsigned long long mf_ = __ballot(focus);
+            if (mf_ != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd((int*)&s_fx[1], __popcll(mf_));
+              base = wave_uniform(base);
+              const int pos = base + lane_rank(mf_);
+              focus = focus && pos < WFOCUS;
+              if (focus) s_focus[pos] = (uint16_t)tid;
+            }
+          }
+          __syncthreads();
+          const int n_f = (int)s_fx[1] < WFOCUS ? (int)s_fx[1] : WFOCUS;
+          // box of the focus samples and their largest bound (every wave computes the same from the list)
+          float rmax2 = 0.f;
+          {
+            const bool on = lane < n_f;
+            const int e = on ? (int)s_focus[lane] : 0;
+            rmax2 = wave_max_f32(on ? __uint_as_float(s_ur_best[e]) : 0.f);
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float v = s_ur_p[e * 3 + k];
+              qlo[k] = wave_min_f32(on ? v : __builtin_inff());
+              qhi[k] = wave_max_f32(on ? v : -__builtin_inff());
+            }
+          }
+          const float rho = __builtin_sqrtf(rmax2) * 1.00001f + 1e-30f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) { qlo[k] -= rho; qhi[k] += rho; }
+          if (tid < MAXL + 2) s_gn[tid] = 0;
+          __syncthreads();
+          {
+            int* fa = s_front;
+            int* fb = s_front + WFRONT;
+            walk_top(fa, WLEAF);
+            __syncthreads();
+            for (int lvl = top; lvl >= 1; --lvl) {
+              if (s_gn[MAXL] != 0) break;
+              walk_level(lvl, fa, fb, WLEAF);
+              __syncthreads();
+              int* t = fa; fa = fb; fb = t;
+            }
+          }
+          if (s_gn[MAXL] != 0) {  // too many points within the bound: the tree search of the finish is the better tool
+            if (alive && !give_up) to_finish(r, __uint_as_float(bb));
+            if (tid == 0) count(ST_EXACT_OVER, 1);
+            all_settled = false;
+            break;
+          }
+          const int n_cand2 = s_gn[0] * LEAF;
+          for (int ib = 0; ib < n_cand2; ib += XB) {
+            __syncthreads();  // (the previous batch has been read)
+            if (tid == 0) s_ctr[0] = 0;
+            __syncthreads();
+            {
+              float x[DP];
+              const int idx = ib + tid;
+              bool keep = idx < n_cand2;
+              const uint32_t row = keep ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
+              load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x);
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) keep = keep && (x[k] >= qlo[k]) && (x[k] <= qhi[k]);
+              const unsigned long long m = __ballot(keep);
+              if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ctr[0], __popcll(m));
+                base = wave_uniform(base);
+                if (keep) {
+                  float4 v;
+                  v.x = x[0];
+                  v.y = x[1];
+                  v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
+                  v.w = 0.f;
+                  s_xb[base + lane_rank(m)] = v;
+                }
+              }
+            }
+            __syncthreads();
+            const int nb = s_ctr[0];
+            for (int j = wv; j < n_f; j += WWAVES) {  // (focus sample j belongs to this wave alone)
+              const int e = (int)s_focus[j];
+              float pj[DIM];
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) pj[k] = s_ur_p[e * 3 + k];
+              float m2 = __builtin_inff();
+              int bi = 0;
+              for (int i = lane; i < nb; i += 64) {
+                const float4 xx = s_xb[i];
+                float t0 = pj[0] - xx.x;
+                float d2 = t0 * t0;
+                t0 = pj[1] - xx.y;
+                d2 = __builtin_fmaf(t0, t0, d2);
+                if constexpr (DIM == 3) {
+                  t0 = pj[2] - xx.z;
+                  d2 = __builtin_fmaf(t0, t0, d2);
+                }
+                if (d2 < m2) { m2 = d2; bi = i; }
+              }
+              const float wm = wave_min_f32(m2);
+              if (__float_as_uint(wm) < s_ur_best[e]) {  // (wave-uniform) a nearer point: new minimum, new witness
+                const int lw = __builtin_ctzll(__ballot(m2 == wm));
+                if (lane == lw) {
+                  s_ur_best[e] = __float_as_uint(wm);
+                  const int slot = (int)s_ur_slot[e];
+                  if (slot >= 0) {
+                    const float4 xx = s_xb[bi];
+                    s_wit[3 * slot + 0] = xx.x;
+                    s_wit[3 * slot + 1] = xx.y;
+                    s_wit[3 * slot + 2] = xx.z;
+                  }
+                }
+              }
+            }
+            if (tid == 0) count(ST_PAIRS, (unsigned long long)nb * (unsigned long long)n_f);
+          }
+          __syncthreads();
+          // the focus samples are exact now: deliver them (all lanes of every wave take part in the reductions)
+          deliver(focus, mb, __uint_as_float(focus ? s_ur_best[tid] : 0u));
+          done = done || focus;
+          if (tid == 0) count(ST_EXACT, 1);
+          __syncthreads();
+        }
+      }
+      return all_settled;
+    };
+
     // ---- 3. coarse samples (one per thread) against the stage, with witnesses
     {
       const int c = tid;
@@ -556,9 +783,38 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
       const bool cert = crow >= 0 && best <= rg_.cert_limit(p, c_sel);
       if (stats) { const unsigned long long mc_ = __ballot(cert); if (lane == 0) count(ST_CCERT, (unsigned long long)__popcll(mc_)); }
       deliver(cert, mb, best);
+      // coarse samples the stage leaves open: on the list of the focus rounds below
+      const bool open_c = crow >= 0 && !cert;
+      const unsigned long long mo = __ballot(open_c);
+      if (mo != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_ctr[3], __popcll(mo));
+        base = wave_uniform(base);
+        if (open_c) {
+          const int pos = base + lane_rank(mo);   // (< WCOARSE = WUR)
+          s_ur_row[pos] = (uint16_t)crow;
+          s_ur_slot[pos] = (int16_t)c;
+          s_ur_best[pos] = __float_as_uint(best);
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) s_ur_p[pos * 3 + k] = p[k];
+        }
+      }
     }
     __syncthreads();
     WPHASE(4);
+    // ---- 3b. the face maxima must be (close to) final BEFORE the other samples are bounded against them: a face
+    // whose deepest coarse sample is still open would let every sample of its void through.  Focus rounds settle
+    // the open coarse samples that matter; a simplex where that takes too many points or rounds - far field: the
+    // inside of a tube, a void - is left to the cell sweep and the tree search of the finish.
+    WIT_REC(5, s_ctr[3]);
+    if (!(flags & 4)) {
+      if (s_ctr[3] > max_open) WIT_ABANDON(ST_DENSE)
+      const bool ok = focus_rounds(s_ctr[3], true);
+      if (!ok) WIT_ABANDON(ST_DENSE)
+      __syncthreads();
+    }
+    if (tid == 0) s_ctr[3] = 0;
+    __syncthreads();
 
     // ---- 4. all samples: bound from the witnesses of the nearest coarse samples; the live ones are queued.
     // (the table rows of the next step are in flight while this one is worked on)
@@ -578,12 +834,6 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
         fr.par[u] = plan.parents[fr.rr[u]];
         fr.mb[u] = fr.valid[u] ? acc.memb[fr.rr[u]] : 0u;
       }
-    };
-    // a sample goes straight to the finish with its bound (queue or list full)
-    auto to_finish = [&](int r, float val) {
-      out.d2[s * (int64_t)R + r] = __float_as_uint(val);
-      atomicOr(&s_unres[r >> 5], 1u << (r & 31));
-      atomicMax(&s_tkey[r >> 6], __float_as_uint(val));
     };
     FineRows cur;
     load_rows(0, cur);
@@ -643,12 +893,21 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     }
     __syncthreads();
     WPHASE(5);
+    WIT_REC(6, s_ctr[1]);
+    // too many samples survive the bound (a ridge of the distance function - the axis of a tube, a medial surface:
+    // whole patches of samples within a lattice step of the maximum): no gain here, the simplex goes to the cell sweep
+    if (s_ctr[1] > max_live && s_ctr[2] == 0 && !(flags & 8)) WIT_ABANDON(ST_OVER)
 
     // ---- 5. the queued samples against the stage: rounds of 64 samples; while there are fewer rounds than waves a
     // round is shared by several waves, each taking a part of the stage (minima combined in the queue entry)
     {
-      const int n_q = s_ctr[1] < WQ ? s_ctr[1] : WQ;
-      if (n_q < s_ctr[1] && tid == 0) count(ST_UNRES, (unsigned long long)(s_ctr[1] - n_q));
+      const int n_q_all = s_ctr[1] < WQ ? s_ctr[1] : WQ;
+      if (n_q_all < s_ctr[1] && tid == 0) count(ST_UNRES, (unsigned long long)(s_ctr[1] - n_q_all));
+      // (an item's time is bounded: at most max_eval queued samples are evaluated here - a round per wave -, the rest
+      // goes to the finish with its bound; a simplex with hundreds of live samples used to be the tail of the launch)
+      const int n_q = n_q_all < max_eval ? n_q_all : max_eval;
+      for (int qi = n_q + tid; qi < n_q_all; qi += WTHREADS) to_finish((int)s_qrow[qi], __uint_as_float(s_qub[qi]));
+      if (n_q < n_q_all && tid == 0) count(ST_UNRES, (unsigned long long)(n_q_all - n_q));
       const int n_rounds_q = (n_q + 63) >> 6;
       const int parts = (n_rounds_q >= WWAVES || (flags & 2)) ? 1 : (n_rounds_q >= 2 ? 2 : 4);
       const int k_part = (((K + parts - 1) / parts) + 3) & ~3;
@@ -712,6 +971,7 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
             const int pos = base + lane_rank(mu);
             if (pos < WUR && !(flags & 1)) {
               s_ur_row[pos] = (uint16_t)r;
+              s_ur_slot[pos] = (int16_t)-1;
               s_ur_best[pos] = __float_as_uint(best);
 #pragma unroll
               for (int k = 0; k < DIM; ++k) s_ur_p[pos * 3 + k] = p[k];
@@ -727,165 +987,8 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
     __syncthreads();
     WPHASE(6);
 
-    // ---- 5b. open samples (their nearest point may lie beyond the staged region), in FOCUS ROUNDS: the open samples
-    // with the largest bounds (within focus_frac of the largest, at most WFOCUS) get every point within that bound of
-    // their box streamed through the stage, lanes over points - exact by construction; their values raise the face
-    // maxima, and most of the other open samples - the neighbours of the deepest one in a void - drop against those
-    // without a search of their own.  What is still open after WROUNDS rounds goes to the finish.
-    {
-      const int n_ur = (flags & 1) ? 0 : (s_ctr[3] < WUR ? s_ctr[3] : WUR);
-      if (n_ur > 0) {
-        const bool mine = tid < n_ur;
-        const int r = mine ? (int)s_ur_row[tid] : 0;
-        const uint32_t mb = mine ? acc.memb[r] : 0u;
-        bool done = !mine;
-        for (int round = 0; round <= WROUNDS; ++round) {
-          // who is still alive?  (every lane takes part in the threshold's wave-wide reductions)
-          const uint32_t thr = threshold(done ? 0u : mb);
-          const uint32_t bb = mine ? s_ur_best[tid] : 0u;
-          const bool alive = !done && bb > thr;
-          done = done || !alive;
-          if (tid < 8) s_fx[tid] = tid < 4 ? 0u : 0u;
-          __syncthreads();
-          {
-            const uint32_t wm = wave_max_u32(alive ? bb : 0u);
-            if (lane == 0 && wm != 0u) atomicMax(&s_fx[0], wm);
-          }
-          __syncthreads();
-          const uint32_t bmax = s_fx[0];
-          if (bmax == 0u) break;                       // (block-uniform) nothing left
-          if (round == WROUNDS) {                      // out of rounds: the rest goes to the finish
-            if (alive) to_finish(r, __uint_as_float(bb));
-            break;
-          }
-          // focus set: the largest bounds, compacted (at most WFOCUS)
-          bool focus = alive && __uint_as_float(bb) >= 0.97f * __uint_as_float(bmax);
-          {
-            const unsigned long long mf_ = __ballot(focus);
-            if (mf_ != 0ull) {
-              int base = 0;
-              if (lane == 0) base = atomicAdd((int*)&s_fx[1], __popcll(mf_));
-              base = wave_uniform(base);
-              const int pos = base + lane_rank(mf_);
-              focus = focus && pos < WFOCUS;
-              if (focus) s_focus[pos] = (uint16_t)tid;
-            }
-          }
-          __syncthreads();
-          const int n_f = (int)s_fx[1] < WFOCUS ? (int)s_fx[1] : WFOCUS;
-          // box of the focus samples and their largest bound (every wave computes the same from the list)
-          float rmax2 = 0.f;
-          {
-            const bool on = lane < n_f;
-            const int e = on ? (int)s_focus[lane] : 0;
-            rmax2 = wave_max_f32(on ? __uint_as_float(s_ur_best[e]) : 0.f);
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-              const float v = s_ur_p[e * 3 + k];
-              qlo[k] = wave_min_f32(on ? v : __builtin_inff());
-              qhi[k] = wave_max_f32(on ? v : -__builtin_inff());
-            }
-          }
-          const float rho = __builtin_sqrtf(rmax2) * 1.00001f + 1e-30f;
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) { qlo[k] -= rho; qhi[k] += rho; }
-          if (tid < MAXL + 2) s_gn[tid] = 0;
-          __syncthreads();
-          {
-            int* fa = s_front;
-            int* fb = s_front + WFRONT;
-            if (wv == 0) {
-              if (top == 0) test_children(0, 0, s_leaf, &s_gn[0], WLEAF);
-              else test_children(top, 0, fa, &s_gn[top], WFRONT);
-            }
-            __syncthreads();
-            for (int lvl = top; lvl >= 1; --lvl) {
-              if (s_gn[MAXL] != 0) break;
-              const int na = s_gn[lvl];
-              for (int f = wv; f < na; f += WWAVES) {
-                const int grp = wave_uniform(fa[f]);
-                if (lvl == 1) test_children(0, grp, s_leaf, &s_gn[0], WLEAF);
-                else test_children(lvl - 1, grp, fb, &s_gn[lvl - 1], WFRONT);
-              }
-              __syncthreads();
-              int* t = fa; fa = fb; fb = t;
-            }
-          }
-          if (s_gn[MAXL] != 0) {  // too many points within the bound: the tree search of the finish is the better tool
-            if (alive) to_finish(r, __uint_as_float(bb));
-            if (tid == 0) count(ST_EXACT_OVER, 1);
-            break;
-          }
-          const int n_cand2 = s_gn[0] * LEAF;
-          constexpr int UB_ = 3;  // (candidate slots per batch: 768 <= WCAP)
-          static_assert(WTHREADS * UB_ <= WCAP, "a batch fits the stage");
-          for (int ib = 0; ib < n_cand2; ib += WTHREADS * UB_) {
-            __syncthreads();  // (the previous batch has been read; first batch: the frontier is dead)
-            if (tid == 0) s_ctr[0] = 0;
-            __syncthreads();
-            float x[UB_][DP];
-            bool in[UB_];
-#pragma unroll
-            for (int u = 0; u < UB_; ++u) {
-              const int idx = ib + u * WTHREADS + tid;
-              in[u] = idx < n_cand2;
-              const uint32_t row = in[u] ? (uint32_t)s_leaf[idx / LEAF] * LEAF + (uint32_t)(idx % LEAF) : 0u;
-              load_row_at<DP>(pts, row * (uint32_t)(DP * sizeof(float)), x[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UB_; ++u) {
-              bool keep = in[u];
-#pragma unroll
-              for (int k = 0; k < DIM; ++k) keep = keep && (x[u][k] >= qlo[k]) && (x[u][k] <= qhi[k]);
-              const unsigned long long m = __ballot(keep);
-              if (m != 0ull) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ctr[0], __popcll(m));
-                base = wave_uniform(base);
-                if (keep) {
-                  float4 v;
-                  v.x = x[u][0];
-                  v.y = x[u][1];
-                  v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-                  v.w = 0.f;
-                  s_pts[base + lane_rank(m)] = v;
-                }
-              }
-            }
-            __syncthreads();
-            const int nb = s_ctr[0];
-            for (int j = wv; j < n_f; j += WWAVES) {  // (focus sample j belongs to this wave alone)
-              const int e = (int)s_focus[j];
-              float pj[DIM];
-#pragma unroll
-              for (int k = 0; k < DIM; ++k) pj[k] = s_ur_p[e * 3 + k];
-              float m2 = __builtin_inff();
-              for (int i = lane; i < nb; i += 64) {
-                const float4 xx = s_pts[i];
-                float t0 = pj[0] - xx.x;
-                float d2 = t0 * t0;
-                t0 = pj[1] - xx.y;
-                d2 = __builtin_fmaf(t0, t0, d2);
-                if constexpr (DIM == 3) {
-                  t0 = pj[2] - xx.z;
-                  d2 = __builtin_fmaf(t0, t0, d2);
-                }
-                m2 = __builtin_fminf(m2, d2);
-              }
-              m2 = wave_min_f32(m2);
-              if (lane == 0 && __float_as_uint(m2) < s_ur_best[e]) s_ur_best[e] = __float_as_uint(m2);
-            }
-            if (tid == 0) count(ST_PAIRS, (unsigned long long)nb * (unsigned long long)n_f);
-          }
-          __syncthreads();
-          // the focus samples are exact now: deliver them (all lanes of every wave take part in the reductions)
-          deliver(focus, mb, __uint_as_float(focus ? s_ur_best[tid] : 0u));
-          done = done || focus;
-          if (tid == 0) count(ST_EXACT, 1);
-          __syncthreads();
-        }
-      }
-    }
+    // ---- 5b. the samples the stage left open: focus rounds (above); what they cannot settle goes to the finish
+    if (!(flags & 1)) focus_rounds(s_ctr[3] < WUR ? s_ctr[3] : WUR, false);
     __syncthreads();
     WPHASE(9);
 
@@ -923,7 +1026,8 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
         }
       }
     }
-    if (tid == 0) out.weight[s] = -1.f;
+    WIT_REC(10, 1); WIT_REC(11, __builtin_amdgcn_s_memrealtime() - t_item0); WIT_REC(7, s_ctr[2]);
+    if (tid == 0) { out.weight[s] = -1.f; if ((s & 7) == 0) atomicAdd(&queue[8], 1); }
     if (tid == 0) count(ST_HANDLED, 1);
     WPHASE(7);
   }
@@ -937,17 +1041,86 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
   }
 }
 
+// The simplices the witness sweep tries (0 <= weight <= limit), heaviest class first (the long items - time goes with
+// the points around a simplex - start first, the light ones fill the tail): one block, ballot scans.  A persistent
+// workgroup that pops a simplex only to find it too heavy pays an atomic round trip and two barriers for nothing -
+// 77 us per launch where every simplex is heavy.
+constexpr int WCLASSES = 4;
+__global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict__ weight, int n, float limit,
+                                                        int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ int s_cnt[WCLASSES][16];
+  __shared__ int s_base[WCLASSES + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto cls = [&](float w) -> int {  // 0 = heaviest; -1: not for this sweep
+    if (!(w >= 0.f) || !(w <= limit)) return -1;
+    return w > 0.5f * limit ? 0 : (w > 0.25f * limit ? 1 : (w > 0.125f * limit ? 2 : 3));
+  };
+  // totals per class
+  int tot[WCLASSES];
+#pragma unroll
+  for (int c = 0; c < WCLASSES; ++c) tot[c] = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int c = cls(weight[i]);
+#pragma unroll
+    for (int k = 0; k < WCLASSES; ++k) tot[k] += c == k ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < WCLASSES; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot[k] += __shfl_xor(tot[k], o);
+    if (lane == 0) s_cnt[k][wv] = tot[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < WCLASSES; ++k) {
+      s_base[k] = run;
+      for (int w = 0; w < 16; ++w) run += s_cnt[k][w];
+    }
+    s_base[WCLASSES] = run;
+    count[0] = run;
+  }
+  __syncthreads();
+  int pos[WCLASSES];
+#pragma unroll
+  for (int k = 0; k < WCLASSES; ++k) pos[k] = s_base[k];
+  for (int base = 0; base < n; base += 1024) {  // (order kept inside a class)
+    const int i = base + threadIdx.x;
+    const int c = i < n ? cls(weight[i]) : -1;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WCLASSES; ++k) {
+      const unsigned long long m = __ballot(c == k);
+      if (lane == 0) s_cnt[k][wv] = __popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WCLASSES; ++k) {
+      int before = 0, total = 0;
+      for (int w = 0; w < 16; ++w) {
+        before += w < wv ? s_cnt[k][w] : 0;
+        total += s_cnt[k][w];
+      }
+      const unsigned long long m = __ballot(c == k);
+      if (c == k) list[pos[k] + before + lane_rank(m)] = i;
+      pos[k] += total;
+    }
+  }
+}
+
 template <int DIM>
 struct WitOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, float* plane_tab,
-                 const float* weights, int k1, int R, int64_t ns, WitPlan plan, int32_t* queue, WitOut out, FaceAcc acc,
-                 unsigned long long* stats, hipStream_t st) {
+                 const float* weights, int k1, int R, int64_t ns, WitPlan plan, int32_t* queue, int32_t* item_list,
+                 int32_t* item_count, WitOut out, FaceAcc acc, unsigned long long* stats, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
       if (rc != FLOODER_OK) return rc;
+      hipLaunchKernelGGL(wit_list_kernel, dim3(1), dim3(1024), 0, st, out.weight, (int)ns, (float)g_wit_weight, item_list,
+                         item_count);
       const int grid = (int)(ns < g_wit_grid ? ns : g_wit_grid);
       hipLaunchKernelGGL((wit_sweep_kernel<DIM>), dim3(grid), dim3(WTHREADS), 0, st, pts, nodes, lv, verts, plane_tab, weights, k1,
-                         R, ns, (float)g_wit_weight, 0.01f * (float)g_wit_cmax_pct, 0.01f * (float)g_wit_cmax_ext_pct, g_wit_min_bins, g_wit_flags, plan, queue, out, acc,
+                         R, ns, (float)g_wit_weight, 0.01f * (float)g_wit_cmax_pct, 0.01f * (float)g_wit_cmax_ext_pct, g_wit_min_bins, g_wit_flags, g_wit_max_open, (int)((int64_t)R * g_wit_max_live_pct / 100), (int)((int64_t)R * g_wit_max_in_pct / 100), g_wit_adaptive, g_wit_max_leaves < WLEAF ? g_wit_max_leaves : WLEAF, g_wit_max_eval, item_list, item_count, plan, queue, out, acc,
                          stats);
       return check_launch("wit_sweep");
     } else {
@@ -969,10 +1142,10 @@ int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, c
                               const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
                               int32_t* flag_list, int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist,
                               uint64_t* top, int32_t* top_list, int32_t* top_count, float* simplex_weight,
-                              float* plane_scratch, uint64_t* stats, void* stream) {
+                              int32_t* item_list, float* plane_scratch, uint64_t* stats, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !coarse_rows || !parents || !queue || !d2_scratch || !memb ||
-      !face_bits || !flag_list || !flag_count || !simplex_weight || !plane_scratch || n_pts < 1 || k1 < 1 ||
+      !face_bits || !flag_list || !flag_count || !simplex_weight || !item_list || !plane_scratch || n_pts < 1 || k1 < 1 ||
       k1 > FLOODER_MAX_VERTS || R < 1 || R > WROWS || n_coarse < 1 || n_coarse > WCOARSE || n_faces < 1 || n_faces > 32 ||
       (top && (!top_list || !top_count)) || (flag_key && !flag_hist) || n_simplices > 0x7fffffffLL)
     return fail(FLOODER_E_ARG, "flooder_sweep_witness_f32: bad argument");
@@ -986,7 +1159,7 @@ int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, c
   FaceAcc acc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list, top_count, face_slot,
               flag_key, flag_hist};
   return dispatch_dim<WitOp>(dim, pts_sorted, nodes, lv, verts, plane_scratch, weights, k1, R, n_simplices,
-                             WitPlan{coarse_rows, parents, n_coarse}, queue,
+                             WitPlan{coarse_rows, parents, n_coarse}, queue, item_list, queue + FLOODER_QUEUE_WORDS - 1,
                              WitOut{d2_scratch, flag_list, flag_count, simplex_weight}, acc,
                              reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
 }

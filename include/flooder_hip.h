@@ -340,9 +340,9 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
  * flag_hist / top (as the cell sweep's open tiles; their rows of d2_scratch hold the bound, the other rows of such a
  * tile are marked settled).  Face values are bit-identical to the exhaustive result.
  * simplex_weight (n_simplices floats of flooder_simplex_weight_f32, READ AND WRITTEN): simplices heavier than option
- * "wit_weight" (1500), or whose neighbourhood does not fit one LDS stage, are left alone; a simplex handled here gets
+ * "wit_weight" (800), or whose neighbourhood does not fit one LDS stage, are left alone; a simplex handled here gets
  * weight -1, which flooder_sweep_cell_faces_f32 skips.  R <= FLOODER_WIT_MAX_ROWS.  queue: FLOODER_QUEUE_WORDS zeroed
- * int32.  stats: NULL or 24 zeroed uint64 {simplices handled, too heavy, gather overflow, too dense for the stage,
+ * int32.  item_list: n_simplices int32 of scratch (the simplices light enough, heaviest class first).  stats: NULL or 24 zeroed uint64 {simplices handled, too heavy, gather overflow, too dense for the stage,
  * points staged, coarse samples certified, samples live after the bound, evaluation rounds, samples handed to the
  * finish, tiles flagged, pairs evaluated, excess bins kept; [12:22] cycles per phase in builds with -DFLOODER_PHASE_TIMERS}.  Options: "wit_cmax_pct" (250: gather radius in percent of
  * the local point spacing), "wit_min_bins" (6), "wit_grid".
@@ -355,7 +355,7 @@ int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, c
                               const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
                               int32_t* flag_list, int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist,
                               uint64_t* top, int32_t* top_list, int32_t* top_count, float* simplex_weight,
-                              float* plane_scratch, uint64_t* stats, void* stream);
+                              int32_t* item_list, float* plane_scratch, uint64_t* stats, void* stream);
 
 /*
  * Exact finish of the flagged tiles when only the face maxima are wanted.  A sample whose upper bound does not

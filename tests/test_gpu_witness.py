@@ -1,0 +1,142 @@
+"""Witness sweep (csrc/flood_wit.hip): face values must equal the cell sweep's and the tree sweep's bit for bit,
+whatever it decides to handle, drop, settle itself or hand on.  Runs on a real MI355X only (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import flooder_amd as fa
+from flooder_amd import _native, core
+from oracle import flood_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+WIT_DEFAULTS = {"wit_max_eval": 768, "wit_max_leaves": 400, "wit_adaptive": 0, "wit_weight": 800, "wit_cmax_pct": 250, "wit_cmax_ext_pct": 60, "wit_min_bins": 48, "wit_flags": 0,
+                "wit_max_open": 48, "wit_max_live_pct": 12, "wit_max_in_pct": 8}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    _native.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def restore_options():
+    yield
+    lib = _native.load()
+    for k, v in WIT_DEFAULTS.items():
+        assert lib.flooder_set_option(k.encode(), v) == 0
+    core.CELL_WITNESS = True
+
+
+def set_options(**kw):
+    lib = _native.load()
+    for k, v in kw.items():
+        assert lib.flooder_set_option(k.encode(), int(v)) == 0, k
+
+
+def clouds(name, n):
+    g = torch.Generator().manual_seed(7)
+    if name == "gauss":
+        return torch.randn(n, 3, generator=g)
+    if name == "torus":
+        return torch.as_tensor(fo.noisy_torus(n, seed=3))
+    if name == "cube":
+        return torch.rand(n, 3, generator=g)
+    if name == "two_blobs":   # a dense and a sparse cluster far apart: long empty simplices between them
+        a = torch.randn(n // 2, 3, generator=g) * 0.05
+        b = torch.randn(n - n // 2, 3, generator=g) + torch.tensor([6.0, 0.0, 0.0])
+        return torch.cat([a, b])
+    raise ValueError(name)
+
+
+def run(points, lms, witness, **kw):
+    core.CELL_WITNESS = witness
+    return fa.flood_complex(points, lms, method="cell", **kw)
+
+
+def assert_same(a, b, what):
+    assert set(a) == set(b), what
+    keys = sorted(a)
+    va = np.array([a[k] for k in keys], dtype=np.float32)
+    vb = np.array([b[k] for k in keys], dtype=np.float32)
+    bad = va.view(np.uint32) != vb.view(np.uint32)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values differ, worst {np.abs(va - vb).max():.3e}"
+
+
+def sweep_stats(points, lms, ppe=30):
+    """Counters of the witness sweep for the top simplices of a complex (through the sweep entry the product uses)."""
+    dev = points.device
+    d = points.shape[1]
+    stree, simplices = core._build_complex(lms, d)
+    verts = lms[torch.as_tensor(simplices[d], device=dev)].contiguous()
+    weights, vertex_idxs, face_idxs = core.generate_grid(ppe, d, dev, torch.float32)
+    faces = core._FaceTable(face_idxs, weights.shape[0], dev)
+    st = torch.zeros(40, dtype=torch.int64, device=dev)
+    core._sweep_dimension_cell(core.PointIndex(points), verts, weights, faces, None, stats=st)
+    torch.cuda.synchronize()
+    return st[16:40].cpu().numpy()
+
+
+@pytest.mark.parametrize("name,n,n_lms", [("gauss", 200_000, 400), ("torus", 150_000, 300), ("cube", 100_000, 250),
+                                          ("two_blobs", 120_000, 300)])
+def test_witness_sweep_changes_nothing(name, n, n_lms, dev):
+    pts = clouds(name, n).to(dev)
+    lms = fa.generate_landmarks(pts, n_lms, start_idx=0)
+    on = run(pts, lms, True)
+    off = run(pts, lms, False)
+    assert_same(on, off, f"{name}: witness sweep on / off")
+    tree = fa.flood_complex(pts, lms, method="bvh")
+    assert_same(on, tree, f"{name}: witness sweep / tree sweep")
+
+
+def test_witness_sweep_takes_the_sparse_simplices_and_leaves_the_dense_ones(dev):
+    pts = clouds("gauss", 300_000).to(dev)
+    lms = fa.generate_landmarks(pts, 500, start_idx=0)
+    st = sweep_stats(pts, lms)
+    handled = int(st[0])
+    n_top = core._build_complex(lms, 3)[1][3].shape[0]
+    assert 0 < handled < n_top, (handled, n_top)   # the dense core of the cloud is the cell sweep's
+    assert st[5] > 0.9 * 242 * handled, "coarse samples of a sparse simplex are (almost) all certified by the stage"
+    assert st[6] < 0.1 * 4960 * handled, "more than a tenth of the samples survive the bound"
+    dense = clouds("cube", 2_000_000).to(dev)
+    lms_d = fa.generate_landmarks(dense, 300, start_idx=0)
+    st_d = sweep_stats(dense, lms_d)
+    assert int(st_d[0]) == 0, "a dense uniform cloud has nothing for the witness sweep"
+
+
+def test_witness_sweep_random_weights_and_off_cloud_landmarks(dev):
+    pts = clouds("gauss", 100_000).to(dev)
+    lms = fa.generate_landmarks(pts, 200, start_idx=0)
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        on = run(pts, lms, True, num_rand=3000, max_dimension=3)
+        torch.manual_seed(seed)
+        off = run(pts, lms, False, num_rand=3000, max_dimension=3)
+        assert_same(on, off, "random weights")
+    g = torch.Generator().manual_seed(5)
+    off_cloud = (torch.randn(150, 3, generator=g) * 1.5).to(dev)   # landmarks that are no cloud points
+    assert_same(run(pts, off_cloud, True), run(pts, off_cloud, False), "landmarks off the cloud")
+
+
+@pytest.mark.parametrize("opts", [
+    dict(wit_weight=1_000_000, wit_max_in_pct=100000),            # every simplex is tried, however dense
+    dict(wit_cmax_pct=60), dict(wit_cmax_pct=1200, wit_cmax_ext_pct=400),   # tiny / huge staged region
+    dict(wit_flags=1), dict(wit_flags=2), dict(wit_flags=4), dict(wit_flags=8), dict(wit_flags=15),
+    dict(wit_max_open=0), dict(wit_max_live_pct=0), dict(wit_min_bins=64), dict(wit_min_bins=1, wit_max_eval=0),
+    dict(wit_min_bins=1, wit_max_eval=64, wit_weight=5000), dict(wit_min_bins=1, wit_max_leaves=1024, wit_weight=3000),
+    dict(wit_max_open=100000, wit_max_live_pct=100, wit_flags=8),  # nothing is abandoned: queue / list overflow paths
+])
+def test_witness_sweep_options_change_nothing(opts, dev):
+    pts = clouds("two_blobs", 150_000).to(dev)
+    lms = fa.generate_landmarks(pts, 300, start_idx=0)
+    ref = run(pts, lms, False)
+    set_options(**opts)
+    assert_same(run(pts, lms, True), ref, str(opts))
+    tor = clouds("torus", 100_000).to(dev)
+    lms_t = fa.generate_landmarks(tor, 200, start_idx=0)
+    set_options(**WIT_DEFAULTS)
+    ref_t = run(tor, lms_t, False)
+    set_options(**opts)
+    assert_same(run(tor, lms_t, True), ref_t, f"torus {opts}")

@@ -244,3 +244,30 @@ def test_lazy_tree_from_cells_equals_eager_tree():
         for j, cmb in enumerate(combos):
             b.assign_filtration_bulk(cells[:, list(cmb)], vals[:, j])
         assert np.array_equal(np.isnan(a.filtrations_of_dimension(dim - 1)), np.isnan(b.filtrations_of_dimension(dim - 1)))
+
+
+def test_witness_plan_tables():
+    """Coarse level of the witness sweep: valid slots, a coarse row first among its own parents, the lattice rule's
+    count at the reference's default lattice, farthest-point samples for random weights, nothing for small tables."""
+    from flooder_amd import core
+
+    w, _, _ = core.generate_grid(30, 3, "cpu", torch.float32)
+    perm = core.sample_order(w)
+    rows, par, n_c = core.witness_plan(w, perm)
+    assert n_c == 242 and rows.shape == (core.WIT_MAX_COARSE,) and par.shape == (w.shape[0],)
+    assert (rows[:n_c] >= 0).all() and (rows[n_c:] == -1).all() and len(set(rows[:n_c].tolist())) == n_c
+    slots = np.stack([(par >> (8 * j)) & 0xFF for j in range(4)], axis=1)
+    assert (slots < n_c).all()
+    assert (slots[rows[:n_c], 0] == np.arange(n_c)).all()
+    # every face of the simplex holds coarse samples (its running maximum needs exact values of its own)
+    wp = w.numpy()[perm]
+    for face in [(0,), (1, 2), (0, 1, 3), (0, 1, 2, 3)]:
+        others = [j for j in range(4) if j not in face]
+        on_face = (wp[rows[:n_c]][:, others] == 0).all(axis=1) & (wp[rows[:n_c]][:, list(face)] > 0).all(axis=1)
+        assert on_face.any(), face
+    torch.manual_seed(0)
+    wr = core.generate_uniform_weights(3000, 3, "cpu", torch.float32)
+    rows_r, par_r, n_r = core.witness_plan(wr, core.sample_order(wr))
+    assert 16 <= n_r <= core.WIT_MAX_COARSE and (((par_r >> 24) & 0xFF) < n_r).all()
+    small, _, _ = core.generate_grid(8, 3, "cpu", torch.float32)
+    assert core.witness_plan(small, core.sample_order(small)) is None
