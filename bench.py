@@ -107,7 +107,7 @@ def parse_args():
                     help="simplices in the 1-core CPU baseline sample (default: 1200, or the workload's own)")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the workers=-1 leg of the CPU baseline")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache steps (512 MB flush before each)")
-    ap.add_argument("--shard", default="simplices", choices=["simplices", "points"],
+    ap.add_argument("--shard", default="simplices", choices=["simplices", "points", "blocks"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
     ap.add_argument("--emulate-shard", default=None, metavar="r/W",
@@ -305,12 +305,16 @@ def main():
         hook = min_reduce_hook()
     else:
         shard_raw = pts_full.contiguous()                          # whole cloud on every rank
-        mine = torch.arange(rank, S_all, world, device=dev) if world > 1 else None
+        if args.shard == "blocks":   # contiguous block of the axis-ordered queue; index over the block's sub-cloud only
+            mine = torch.arange(S_all * rank // world, S_all * (rank + 1) // world, device=dev) if world > 1 else None
+        else:
+            mine = torch.arange(rank, S_all, world, device=dev) if world > 1 else None
         hook = None
     face_hook = min_reduce_hook() if (world > 1 and mine is not None) else None
     if args.emulate_shard and world == 1:
         er, ew = (int(v) for v in args.emulate_shard.split("/"))
-        mine = torch.arange(er, S_all, ew, device=dev)
+        mine = (torch.arange(S_all * er // ew, S_all * (er + 1) // ew, device=dev) if args.shard == "blocks"
+                else torch.arange(er, S_all, ew, device=dev))
         face_hook = lambda t: t  # noqa: E731  (the 360 KB all_reduce is not emulated)
     if mine is not None:
         verts, centers, radii = verts[mine].contiguous(), centers[mine].contiguous(), radii[mine].contiguous()
@@ -330,7 +334,16 @@ def main():
         rows = stree._locate(d, np.sort(simp.cpu().numpy(), axis=1))      # rows of the top table, in sweep order
         slots = core.shared_face_slots(stree, d, rows, [v.cpu().numpy() for v in vertex_idxs], dev)
 
+    sub_rows = []   # (block-sharded: rows of the sub-cloud this rank indexes)
+    cloud_box_full = core.cloud_box(shard_raw) if args.shard == "blocks" else None
+
     def build_index(timer=None):
+        if args.shard == "blocks" and mine is not None and args.method in ("cell", "bvh"):
+            with core._span(timer, "select"):   # the part of the cloud inside the block's bounding balls
+                sub = core.block_subcloud(shard_raw, verts, d, box=cloud_box_full)
+            sub_rows.append(sub.shape[0])
+            with core._span(timer, "index"):
+                return core.PointIndex(sub)
         with core._span(timer, "index"):
             if args.method in ("cell", "bvh"):
                 return core.PointIndex(shard_raw)
@@ -556,6 +569,7 @@ def main():
             "pair_evals_rank0": pair_evals,
             "parallelism": (f"{args.shard}-shard x{world} ({backend})" if world > 1 else "single GPU"),
             "method": args.method, "pair_evals_done_rank0": int(done_evals),
+            "sub_cloud_rows_rank0": (sub_rows[-1] if sub_rows else None),
             "sweep_stats_rank0": st_h,
             "sweep_stats_note": "work counters come from one extra untimed step (the timed steps run without them, as flood_complex does)",
             "h2d_ms": round(h2d_ms, 3), "h2d_streamed": h2d_stream,

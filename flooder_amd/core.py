@@ -244,7 +244,7 @@ def _build_complex(landmarks: torch.Tensor, max_dimension: int):
     ``flooder_amd.SimplexTree``.
     """
     lm = landmarks.detach().cpu().numpy()
-    if HAS_GUDHI:  # pragma: no cover - not present in the build image
+    if HAS_GUDHI:  # (gudhi is absent from the build image: exercised with a stub module, tests/test_host.py)
         import gudhi
 
         stree = gudhi.DelaunayComplex(lm).create_simplex_tree()
@@ -607,6 +607,35 @@ def h2d_ms_of(index: "PointIndex") -> Optional[float]:
         return None
     torch.cuda.synchronize()
     return float(ev[0].elapsed_time(ev[1]))
+
+
+def block_subcloud(points32: torch.Tensor, verts: torch.Tensor, d: int, box: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The part of the cloud a block of ``d``-simplices (``verts``: (S, d+1, dim)) can see when the landmarks are
+    points of the cloud: every nearest neighbour of a sample lies in its simplex's bounding ball (the reference's own
+    pruning bound, ``core.py:156-172``: centre = midpoint of the longest edge, radius = 1.42 x the largest vertex
+    distance + 1e-3).  The rows inside the union of the balls - taken on a coarse grid over the cloud's box ``box``
+    (2D / 3D; other dimensions: the balls' common bounding box) - are compacted by ``flooder_box_select_f32`` (any
+    order).  One host synchronisation (the row count).  A rank of a block-sharded run builds its ``PointIndex`` over
+    this sub-cloud instead of the whole cloud."""
+    lib = _native.load()
+    dev = points32.device
+    centers, radii = _ball_prep(verts.to(torch.float32), d)
+    centers, radii = centers.contiguous(), radii.contiguous()
+    lo = (centers - radii[:, None]).min(dim=0).values
+    hi = (centers + radii[:, None]).max(dim=0).values
+    bbox = torch.cat([lo, hi]).to(torch.float32).contiguous()
+    pts = points32.contiguous()
+    n, dim = pts.shape
+    out = torch.empty_like(pts)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    grid_bytes = int(lib.flooder_select_grid_bytes(dim))
+    flags = torch.zeros(grid_bytes, dtype=torch.uint8, device=dev) if grid_bytes > 0 else None
+    cbox = (box if box is not None else cloud_box(pts)) if flags is not None else None
+    _native.check(lib.flooder_box_select_f32(_native.ptr(pts), n, dim, dim, _native.ptr(bbox), _native.ptr(cbox),
+                                             _native.ptr(centers), _native.ptr(radii), centers.shape[0],
+                                             _native.ptr(flags), _native.ptr(out), _native.ptr(count),
+                                             _native.current_stream_ptr(dev)), "flooder_box_select_f32")
+    return out[:int(count.item())]
 
 
 def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.ndarray], device):
@@ -1106,6 +1135,7 @@ def flood_complex(
     simplex_shard: Optional[Tuple[int, int]] = None,
     face_reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
     index: Optional["PointIndex"] = None,
+    shard_blocks: bool = False,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -1131,7 +1161,12 @@ def flood_complex(
     reference's CPU path.  ``index`` (keyword-only): a ``PointIndex`` built from these very ``points`` (ROCm
     tensors, methods ``"cell"``/``"bvh"``) - the curve-sorted copy and box tree are reused instead of rebuilt
     (callers that sweep one cloud several times, and every rank of a multi-GPU run; the caller vouches that
-    ``points`` has not changed since: only the shape is checked).
+    ``points`` has not changed since: only the shape is checked).  ``simplex_shard=(rank, world)`` sweeps this rank's
+    share of the simplices only (the other rows of the (S, F) values are +inf until ``face_reduce_hook`` combines
+    them): every ``world``-th simplex of the queue, or - ``shard_blocks=True``, float32 ROCm tensors, methods
+    ``"cell"``/``"bvh"``, landmarks that are POINTS OF THE CLOUD (the caller vouches; true for every
+    ``generate_landmarks`` result) - a contiguous block of the queue, swept against an index of the sub-cloud inside
+    the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too.
     """
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
@@ -1196,7 +1231,12 @@ def flood_complex(
     index = None
     use_f64 = on_gpu and dtype is torch.float64 and method != "ball"
     pts64_sorted = None
-    if on_gpu and method != "ball":
+    blocks = bool(shard_blocks) and simplex_shard is not None and on_gpu and method != "ball" and not use_f64
+    block_box = None
+    if blocks:
+        pts32 = points.to(torch.float32).contiguous()
+        block_box = shared_index.box if shared_index is not None else cloud_box(pts32)
+    elif on_gpu and method != "ball":
         # the curve sort + box tree run on the GPU while the host triangulates the landmarks
         pts32 = points.to(torch.float32)
         index = shared_index if shared_index is not None else PointIndex(pts32)
@@ -1215,7 +1255,7 @@ def flood_complex(
     if sort_axis is not None:
         axis = int(sort_axis)
     elif on_gpu:
-        box = (index.box if index is not None else cloud_box(points)).cpu()
+        box = (block_box if block_box is not None else (index.box if index is not None else cloud_box(points))).cpu()
         axis = int(torch.argmax(box[8:8 + dim] - box[:dim]).item())
     else:
         axis = int(torch.argmax(points.max(dim=0).values - points.min(dim=0).values).item())
@@ -1271,11 +1311,20 @@ def flood_complex(
 
         if simplex_shard is not None:
             sh_rank, sh_world = simplex_shard
-            mine = torch.arange(sh_rank, num_simplices, sh_world, device=device)
+            if blocks:   # a contiguous block of the queue (the simplices are ordered along the widest axis)
+                mine = torch.arange(num_simplices * sh_rank // sh_world, num_simplices * (sh_rank + 1) // sh_world,
+                                    device=device)
+            else:
+                mine = torch.arange(sh_rank, num_simplices, sh_world, device=device)
         else:
             mine = None
         sv = simplex_vertices if mine is None else simplex_vertices[mine]
-        if on_gpu:
+        if blocks and sv.shape[0] > 0:
+            index = PointIndex(block_subcloud(pts32, sv, d, box=block_box))
+        if on_gpu and blocks and sv.shape[0] == 0:   # (more ranks than simplices)
+            slots = None
+            face_dev = torch.empty((0, faces.n_faces), dtype=torch.float32, device=device)
+        elif on_gpu:
             if method == "ball":
                 face_dev, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, sv,
                                                    centers if mine is None else centers[mine],
@@ -1342,7 +1391,7 @@ def flood_complex(
                 stree.assign_cell_faces(item[1], item[2], item[3], item[4])
             else:
                 stree.assign_filtration_bulk(item[0], item[1])
-    else:  # pragma: no cover - gudhi tree
+    else:  # a gudhi tree (core.py:278-280 of the reference)
         for simp, vals in results:
             for s, v in zip(simp.tolist(), vals.tolist()):
                 stree.assign_filtration(s, v)

@@ -16,6 +16,15 @@ The reduction has to happen on the per-sample minima, BEFORE the per-face maximu
 (``min_g max_r`` is not ``max_r min_g``), which is what the ``reduce_hook`` of
 ``flood_complex`` provides.
 
+``mode="blocks"``: as ``"simplices"``, but rank r takes a CONTIGUOUS block of the simplex queue (the simplices are
+ordered along the widest axis of the cloud: a slab of space) and builds its index over the part of the cloud inside
+the bounding balls of its block only (``core.block_subcloud``) - with landmarks that are cloud points (every
+``generate_landmarks`` result; the precondition of the reference's own GPU path, ``core.py:156-172``) every witness
+of a simplex lies in its ball.  The index build, which every rank of the other two modes repeats over the whole
+cloud, shrinks with the share; the values are produced whole by one rank each and ``all_reduce(MIN)`` on the (S, F)
+matrix completes them - BASELINE.json's "the point cloud shards ... all-reduce(min) on the per-simplex filtration
+values".  Blocks are not work-balanced (a slab through the dense core of a Gaussian holds the expensive simplices).
+
 Shards are interleaved (rank r takes sorted rows r, r+W, r+2W, ...): every rank then sees 1/W of
 each simplex's candidates, so the heavy-tailed per-simplex work balances without any planning.
 """
@@ -88,7 +97,8 @@ def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, 
     """``flood_complex`` over all ranks of ``group``; every rank returns the full result.
 
     ``mode="simplices"``: ``points`` is the FULL cloud on every rank, simplices are interleaved over the
-    ranks.  ``mode="points"``: ``points`` is this rank's shard of the cloud (``shard_points``).  The
+    ranks.  ``mode="blocks"``: the FULL cloud on every rank, contiguous blocks of simplices, each rank indexes only the
+    sub-cloud its block can see (landmarks must be points of the cloud).  ``mode="points"``: ``points`` is this rank's shard of the cloud (``shard_points``).  The
     landmark tensor must be identical on every rank.  Other arguments as ``flood_complex``.
 
     With ``num_rand`` the sample weights come from the global CPU generator; rank 0's generator state is
@@ -104,11 +114,11 @@ def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, 
         axis = global_widest_axis(points, group)
         return flood_complex(points, landmarks, *args, reduce_hook=min_reduce_hook(group), sort_axis=axis,
                              **kwargs)
-    if mode != "simplices":
-        raise ValueError("mode must be 'simplices' or 'points'")
+    if mode not in ("simplices", "blocks"):
+        raise ValueError("mode must be 'simplices', 'blocks' or 'points'")
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    return flood_complex(points, landmarks, *args, simplex_shard=(rank, world),
+    return flood_complex(points, landmarks, *args, simplex_shard=(rank, world), shard_blocks=(mode == "blocks"),
                          face_reduce_hook=min_reduce_hook(group), **kwargs)

@@ -182,6 +182,18 @@ int64_t flooder_index_sort_bytes(int64_t n_pts);
 int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
                        void* tmp, int64_t tmp_bytes, void* stream);
 
+/* Sub-cloud of a block of simplices (block-sharded runs): the rows of pts (n_pts x dim floats, row stride ld) that lie
+ * inside the box (box: 2 * dim device floats, lo then hi, bounds inclusive) AND - dim 2 / 3, with cell_flags
+ * (flooder_select_grid_bytes(dim) zeroed bytes), cloud_box (the 16 floats of flooder_bbox_f32) and n_balls bounding
+ * balls (centers n_balls x dim, radii) given - in a cell of a coarse grid over the cloud's box that one of the balls
+ * reaches; compacted into out (room for n_pts rows of dim floats; any order), their number in *count (zeroed by the
+ * caller).  With landmarks that are cloud points every witness of a simplex lies in its bounding ball
+ * (core.py:156-172), so the sweep of the block against this sub-cloud gives the values of the whole cloud. */
+int64_t flooder_select_grid_bytes(int dim);
+int flooder_box_select_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, const float* cloud_box,
+                           const float* centers, const float* radii, int64_t n_balls, uint8_t* cell_flags, float* out,
+                           int32_t* count, void* stream);
+
 /* out (n_pad x flooder_padded_dim(dim) floats) = rows order[0], order[1], ... of pts, padding columns 0, then
  * +inf rows up to n_pad (a multiple of FLOODER_BVH_LEAF).  Replaces points[indices] of core.py:143. */
 int flooder_gather_rows_f32(const float* pts, int64_t n_pts, int dim, int ld, const int32_t* order, float* out,

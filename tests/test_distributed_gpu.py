@@ -48,13 +48,13 @@ def _worker(rank, world, port, name, out_dir, mode):
         if mode == "points":
             fc = flood_complex_sharded(shard_points(pts, rank, world), lms, mode="points", **kw)
         else:
-            fc = flood_complex_sharded(pts, lms, mode="simplices", **kw)
+            fc = flood_complex_sharded(pts, lms, mode=mode, **kw)
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([fc[k] for k in keys]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["simplices", "points"])
+@pytest.mark.parametrize("mode", ["simplices", "points", "blocks"])
 @pytest.mark.parametrize("name", ["torus3d_grid30", "eight2d_rand", "gauss6d_maxdim2"])
 def test_two_ranks_one_gpu_match_unsharded(name, mode, tmp_path):
     import flooder_amd as fa
@@ -71,3 +71,55 @@ def test_two_ranks_one_gpu_match_unsharded(name, mode, tmp_path):
     assert np.array_equal(r0, r1)      # every rank returns the full result
     assert np.array_equal(r0, want)    # and it is the unsharded result, bit for bit
     assert np.abs(r0 - z["filtration_f32"]).max() < 5e-6 * max(1.0, float(np.abs(z["points"]).max()))
+
+
+@pytest.mark.parametrize("cloud,world", [("gauss", 3), ("torus", 8), ("gauss", 700)])
+def test_block_shards_one_after_the_other_equal_unsharded(cloud, world):
+    """``shard_blocks``: every rank's block swept against the index of ITS sub-cloud (the rows inside the block's
+    bounding balls) - all ranks of a ``world``-rank run one after the other on this GPU, combined by the minimum that
+    ``all_reduce(MIN)`` would take.  Landmarks are cloud points (FPS), so the values must be the unsharded ones bit
+    for bit; a rank sees only part of the cloud; more ranks than simplices leaves some without work."""
+    import flooder_amd as fa
+    from flooder_amd import core
+    from oracle import flood_oracle as fo
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.randn(150_000, 3, generator=g) if cloud == "gauss" else torch.as_tensor(fo.noisy_torus(150_000, seed=5))).to(dev)
+    lms = fa.generate_landmarks(pts, 120 if world > 100 else 300, start_idx=0)
+    full = fa.flood_complex(pts, lms)
+    keys = sorted(full)
+    want = np.array([full[k] for k in keys], dtype=np.float32)
+    got = np.full(len(keys), np.inf, dtype=np.float32)
+    rows_seen = []
+    orig = core.block_subcloud
+
+    def spy(points32, verts, d, box=None):
+        sub = orig(points32, verts, d, box=box)
+        rows_seen.append(sub.shape[0])
+        return sub
+
+    core.block_subcloud = spy
+    parts = []   # every rank's (S, F) matrix as it would enter the all-reduce
+
+    def collect(full):
+        parts.append(full.clone())
+
+    def reduced(full):   # what all_reduce(MIN) leaves on every rank
+        full.copy_(torch.stack(parts + [full]).amin(dim=0))
+
+    try:
+        ranks = list(range(world)) if world <= 8 else [0, 1, world // 2, world - 1]
+        for r in ranks[1:]:
+            fa.flood_complex(pts, lms, simplex_shard=(r, world), shard_blocks=True, face_reduce_hook=collect)
+        part = fa.flood_complex(pts, lms, simplex_shard=(ranks[0], world), shard_blocks=True, face_reduce_hook=reduced)
+        assert sorted(part) == keys
+        got = np.array([part[k] for k in keys], dtype=np.float32)
+    finally:
+        core.block_subcloud = orig
+    if world <= 8:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert min(rows_seen) < pts.shape[0], "every block saw the whole cloud"
+    else:   # a few ranks of many: what they produced is final, the rest still +inf
+        done = np.isfinite(got)
+        assert done.any() and np.array_equal(got[done].view(np.uint32), want[done].view(np.uint32))

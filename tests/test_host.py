@@ -271,3 +271,70 @@ def test_witness_plan_tables():
     assert 16 <= n_r <= core.WIT_MAX_COARSE and (((par_r >> 24) & 0xFF) < n_r).all()
     small, _, _ = core.generate_grid(8, 3, "cpu", torch.float32)
     assert core.witness_plan(small, core.sample_order(small)) is None
+
+
+def test_gudhi_branches_with_a_stub_module(monkeypatch):
+    """``_build_complex`` and the hand-off of ``flood_complex`` take the reference's own route when gudhi is importable
+    (``gudhi.DelaunayComplex(...).create_simplex_tree()``, ``assign_filtration`` per simplex,
+    ``make_filtration_non_decreasing``, ``get_simplices``: core.py:130-138, 278-288).  gudhi is absent from the build
+    image, so a stub with that call surface (Qhull underneath) stands in: the result must be the one of the
+    array-backed tree."""
+    import itertools
+    import sys
+    import types
+
+    from scipy.spatial import Delaunay
+
+    import flooder_amd as fa
+    from flooder_amd import core
+
+    class StubTree:
+        def __init__(self, simplices):
+            self.f = {s: float("nan") for s in simplices}
+            self.assigned = 0
+
+        def get_simplices(self):
+            for s in sorted(self.f, key=lambda t: (len(t), t)):
+                yield list(s), self.f[s]
+
+        def assign_filtration(self, simplex, value):
+            self.f[tuple(simplex)] = float(value)
+            self.assigned += 1
+
+        def make_filtration_non_decreasing(self):
+            for s in sorted(self.f, key=len):
+                for j in range(len(s)):
+                    if len(s) > 1:
+                        self.f[s] = max(self.f[s], self.f[s[:j] + s[j + 1:]])
+
+    class StubDelaunay:
+        def __init__(self, points):
+            cells = Delaunay(np.asarray(points, dtype=np.float64)).simplices
+            self.simplices = set()
+            for c in cells:
+                c = tuple(sorted(int(v) for v in c))
+                for k in range(1, len(c) + 1):
+                    self.simplices.update(itertools.combinations(c, k))
+
+        def create_simplex_tree(self):
+            return StubTree(self.simplices)
+
+    torch.manual_seed(3)
+    pts = torch.randn(3000, 3)
+    lms = fa.generate_landmarks(pts, 40, start_idx=0)
+    want = fa.flood_complex(pts, lms, points_per_edge=6)
+    stub = types.ModuleType("gudhi")
+    stub.DelaunayComplex = StubDelaunay
+    monkeypatch.setitem(sys.modules, "gudhi", stub)
+    monkeypatch.setattr(core, "HAS_GUDHI", True)
+    got = fa.flood_complex(pts, lms, points_per_edge=6)
+    assert set(got) == set(want)
+    assert all(abs(got[k] - want[k]) <= 1e-12 for k in want)
+    tree = fa.flood_complex(pts, lms, points_per_edge=6, return_simplex_tree=True)
+    assert isinstance(tree, StubTree) and tree.assigned >= len(want)   # (a face is assigned from every simplex that holds it, as in the reference)
+    torch.manual_seed(1)
+    got_r = fa.flood_complex(pts, lms, num_rand=50)
+    monkeypatch.setattr(core, "HAS_GUDHI", False)
+    torch.manual_seed(1)
+    want_r = fa.flood_complex(pts, lms, num_rand=50)
+    assert set(got_r) == set(want_r) and all(abs(got_r[k] - want_r[k]) <= 1e-12 for k in want_r)
