@@ -123,6 +123,7 @@ def parse_args():
     ap.add_argument("--units", default=None, help="cut sizes of the sample bisection, e.g. 1024/256/64/16")
     ap.add_argument("--no-slots", action="store_true", help="one face-maximum word per (simplex, face) instead of per distinct face")
     ap.add_argument("--no-super", action="store_true", help="cell sweep chunk by chunk (no shared stage per run of four)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end flood_complex timing")
     ap.add_argument("--no-witness", action="store_true", help="no witness sweep: every simplex goes through the cell sweep")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
@@ -236,6 +237,15 @@ def main():
 
     lms, t_fps_cold = timed_fps()
     lms, t_fps = timed_fps()
+    # the brute-force sweep (one full pass over the cloud per landmark: fps_fast_kernel) on a bounded number of
+    # landmarks: the one genuinely bandwidth-bound kernel of the path, priced at its own bytes
+    n_brute = min(w["n_lms"], 128)
+    core.fps_indices(pts_full, n_brute, 0, method="brute")
+    torch.cuda.synchronize()
+    t0_b = time.perf_counter()
+    core.fps_indices(pts_full, n_brute, 0, method="brute")
+    torch.cuda.synchronize()
+    t_brute = time.perf_counter() - t0_b
     fps_bucketed = w["dim"] <= core.FPS_BUCKET_MAX_DIM and w["n"] >= core.FPS_BUCKET_MIN_POINTS and w["n_lms"] > 64
     t_fps_ready = None
     if fps_bucketed:
@@ -437,6 +447,35 @@ def main():
         cold_ms = float(np.median(cold))
         del flush
 
+    # end to end, the reference's protocol (examples/example_01_cheese_3d.py:75-94: warm-up call on the first 10 000
+    # points, synchronize, perf_counter around flood_complex and around the persistence computation; docs/index.md:44-49
+    # publishes 1.4 +- 0.3 s for it on an H100 NVL with a 1 M-point swiss cheese, gudhi PH in dimensions 0 - 2): wall
+    # clock of flood_complex(points, n_landmarks) -> simplex tree (FPS + index + Delaunay + sweep + hand-off), of the
+    # dict output, and of the persistence computation; landmarks given: the same without the landmark selection
+    e2e = None
+    if world == 1 and not args.emulate_shard and not args.no_e2e and args.method == "cell" and w.get("max_dim", w["dim"]) == w["dim"]:
+        def wall(fn, reps=3):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                r_ = fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0_)
+            return r_, float(np.median(ts)) * 1e3
+        fa.flood_complex(shard_raw[:10000], min(w["n_lms"], 10000), points_per_edge=w["ppe"])
+        st_, ms_tree = wall(lambda: fa.flood_complex(shard_raw, w["n_lms"], points_per_edge=w["ppe"], return_simplex_tree=True))
+        _, ms_dict = wall(lambda: fa.flood_complex(shard_raw, w["n_lms"], points_per_edge=w["ppe"]))
+        _, ms_tree_lms = wall(lambda: fa.flood_complex(shard_raw, lms, points_per_edge=w["ppe"], return_simplex_tree=True))
+        t0_ = time.perf_counter()
+        st_.compute_persistence()
+        ms_ph = (time.perf_counter() - t0_) * 1e3
+        e2e = {"protocol": "examples/flood_ph_timing.py = reference examples/example_01_cheese_3d.py:75-94 (median of 3 calls)",
+               "flood_complex_tree_ms": round(ms_tree, 2), "flood_complex_dict_ms": round(ms_dict, 2),
+               "flood_complex_tree_landmarks_given_ms": round(ms_tree_lms, 2), "persistence_ms": round(ms_ph, 2),
+               "device_step_ms": round(ms_per_step, 3), "simplices": int(st_.num_simplices()),
+               "reference_published": "1.4 +- 0.3 s complex + PH, 1 M-point swiss cheese, H100 NVL (docs/index.md:44-49; context only)"}
+
     out = step(None, with_stats=True)  # untimed: work counters for the report
     torch.cuda.synchronize()
     if slots is not None:
@@ -606,13 +645,23 @@ def main():
         },
         "kernels": kernels,
         "emulated_shard": args.emulate_shard,
+        "e2e": e2e,
         # landmark selection (generate_landmarks, outside the step): algorithmic bytes of the brute-force
         # formulation = (4*dim + 8) B per point and iteration
         "fps": {"points": w["n"], "landmarks": w["n_lms"], "path": "bucketed" if fps_bucketed else "brute",
                 "ms": round(t_fps * 1e3, 3), "ms_cold_first_call": round(t_fps_cold * 1e3, 3),
                 "ms_index_ready": None if t_fps_ready is None else round(t_fps_ready * 1e3, 3),
                 "us_per_landmark": round(t_fps / w["n_lms"] * 1e6, 3),
-                "algorithmic_GBs": round((4 * w["dim"] + 8) * w["n"] * w["n_lms"] / t_fps / 1e9, 1),
+                # (NOT a bandwidth: the rate a sweep over all points per landmark would need to be this fast - the
+                # bucketed selection touches a few buckets per landmark)
+                "brute_force_equivalent_GBs": round((4 * w["dim"] + 8) * w["n"] * w["n_lms"] / t_fps / 1e9, 1),
+                "brute_sweep": {"landmarks": n_brute, "us_per_landmark": round(t_brute / n_brute * 1e6, 3),
+                                "bytes_per_landmark": (4 * w["dim"] + 8) * w["n"],
+                                "GBs": round((4 * w["dim"] + 8) * w["n"] * n_brute / t_brute / 1e9, 1),
+                                "frac_of_hbm_peak": round((4 * w["dim"] + 8) * w["n"] * n_brute / t_brute / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "flooder_fps_f32: coordinates + running minimum read, minimum written, per point "
+                                        "and landmark (SURVEY.md 8d); wall clock incl. launches; a working set below "
+                                        "256 MB is served by the Infinity Cache, not HBM"},
                 "hbm_peak_GBs": HBM_PEAK_GBS},
     }
 

@@ -943,6 +943,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 # tree sweep over spatially sorted samples (csrc/flood_sorted.hip): None = above 3 dimensions, True / False = always / never
 BVH_SORTED_SAMPLES: Optional[bool] = None
 BVH_SORTED_MIN_SAMPLES = 64 * 1024   # below this the sort costs more than it saves
+EMPTY_CACHE_ABOVE_BYTES = 1 << 30   # flood_complex releases the allocator's cache when more than this is cached unused
 CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spacing
 # Per-face maxima folded into the cell sweep and its exact finish (only when neither the per-sample distances nor
 # a cross-shard reduction of them is wanted): no (S, R) store, no face-max pass, and the finish skips every sample
@@ -1396,7 +1397,10 @@ def flood_complex(
             for s, v in zip(simp.tolist(), vals.tolist()):
                 stree.assign_filtration(s, v)
     stree.make_filtration_non_decreasing()
-    if on_gpu:
+    if on_gpu and torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device) > EMPTY_CACHE_ABOVE_BYTES:
+        # (core.py:281 of the reference empties the allocator's cache after every call - it has just dropped several GB
+        # of masks and index pairs; here a call leaves tens of MB behind and the release costs a millisecond of an 11 ms
+        # call, so it is done only when there is something worth releasing)
         torch.cuda.empty_cache()
     if return_simplex_tree:
         return stree
