@@ -54,6 +54,11 @@ SIGNATURES = {
     "flooder_sample_key_bits": (c_int, [c_int]),
     "flooder_sorted_tile_samples": (c_int, []),
     "flooder_sample_keys_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_sample_keys_late_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
+    "flooder_sweep_bvh_sorted_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                   c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p]),
     "flooder_sweep_bvh_sorted_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -827,6 +827,18 @@ class SamplePlan:
             for f in range(n_faces):
                 memb_all[inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]] |= np.uint32(1 << f)
             self.memb_all = torch.as_tensor(memb_all.view(np.int32), device=dev)
+        # fused sorted sweep (above 3D): every row but one PILOT per face - the row nearest to the centre of the
+        # face's rows - sorts behind the pilots, whose values bring the face maxima close to final first
+        self.late_rows = None
+        if n_faces <= 32:
+            late = np.ones(R, dtype=np.uint8)
+            wn = weights.detach().cpu().numpy().astype(np.float64)[perm]
+            for f in range(n_faces):
+                rows_f = inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]
+                if rows_f.size > 2:
+                    c = wn[rows_f].mean(axis=0)
+                    late[rows_f[np.argmin(((wn[rows_f] - c) ** 2).sum(axis=1))]] = 0
+            self.late_rows = torch.as_tensor(late, device=dev)
         # coarse level of the witness sweep (None: not applicable to this table)
         self.wit = None
         wp = witness_plan(weights, perm) if self.memb_all is not None else None
@@ -896,9 +908,37 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     plan = plan if plan is not None else SamplePlan(weights, faces)
     w_perm, rows_perm = plan.w_perm, plan.rows_perm
 
-    d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     queue = torch.zeros(QUEUE_WORDS, dtype=torch.int32, device=dev)   # sharded work-queue heads
     sorted_samples = bvh_sorts_samples(index.dim, S, R)
+    if (sorted_samples and SORTED_FUSED_FACES and not want_dist and reduce_hook is None and plan.memb_all is not None
+            and plan.late_rows is not None):
+        # ---- only the face maxima are wanted: the sorted sweep delivers them itself (no (S, R) buffer, no face-max
+        # pass) and drops every sample that cannot raise one - csrc/flood_sorted.hip, FUSED
+        n_s = S * R
+        F = faces.n_faces
+        keys = torch.empty(n_s, dtype=torch.int32, device=dev)
+        keys_sorted = torch.empty(n_s, dtype=torch.int32, device=dev)
+        order = torch.empty(n_s, dtype=torch.int32, device=dev)
+        tmp_bytes = int(lib.flooder_index_sort_bytes(n_s))
+        tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+        face_bits = torch.zeros(S * F, dtype=torch.int32, device=dev)
+        with _span(timer, "sweep"):
+            _native.check(lib.flooder_sample_keys_late_f32(_native.ptr(verts), _native.ptr(w_perm), k1, R, S, index.dim,
+                                                           _native.ptr(index.box), _native.ptr(plan.late_rows),
+                                                           _native.ptr(keys), st), "flooder_sample_keys_late_f32")
+            _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, 32, _native.ptr(keys_sorted), _native.ptr(order),
+                                                 _native.ptr(tmp), tmp_bytes, st), "flooder_index_sort (samples)")
+            _native.check(lib.flooder_sweep_bvh_sorted_faces_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, _native.ptr(order), _native.ptr(queue), _native.ptr(plan.memb_all), F,
+                _native.ptr(face_bits), None, _native.ptr(stats), st), "flooder_sweep_bvh_sorted_faces_f32")
+        del keys, keys_sorted, tmp
+        out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
+        with _span(timer, "face_max"):
+            _native.check(lib.flooder_face_values_f32(_native.ptr(face_bits), S * F, _native.ptr(out_face), st),
+                          "flooder_face_values_f32")
+        return out_face, None
+    d2 = torch.empty((S, R), dtype=torch.int32, device=dev)
     with _span(timer, "sweep"):
         if sorted_samples:
             # tiles of 64 spatially consecutive samples of ALL simplices (Z-order keys, one radix sort) instead of
@@ -942,6 +982,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 
 # tree sweep over spatially sorted samples (csrc/flood_sorted.hip): None = above 3 dimensions, True / False = always / never
 BVH_SORTED_SAMPLES: Optional[bool] = None
+SORTED_FUSED_FACES = False  # the sorted sweep delivers the face maxima itself and drops what cannot raise one (measured SLOWER at cfg 4: 116 vs 87 ms - in 6-D the distances of a triangle's samples concentrate, 83 % of the leaves are still evaluated; kept as an option)
 BVH_SORTED_MIN_SAMPLES = 64 * 1024   # below this the sort costs more than it saves
 EMPTY_CACHE_ABOVE_BYTES = 1 << 30   # flood_complex releases the allocator's cache when more than this is cached unused
 CELL_ALPHA = 1.35   # cell size of the LDS grid in units of the local point spacing

@@ -715,6 +715,10 @@ int flooder_set_option(const char* name, int value) {
     g_wit_max_leaves = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "sorted_refresh") == 0 && value >= 1) {
+    g_sorted_refresh = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "wit_max_eval") == 0 && value >= 0) {
     g_wit_max_eval = value;
     return FLOODER_OK;

@@ -20,7 +20,7 @@
 
 using namespace flooder;
 
-namespace flooder { int g_sorted_ks = 1; }  // samples per lane of the sorted sweep (option "sorted_ks": 1 or 2)
+namespace flooder { int g_sorted_ks = 1; int g_sorted_refresh = 4; }  // samples per lane of the sorted sweep (option "sorted_ks": 1 or 2)
 
 namespace {
 
@@ -30,7 +30,8 @@ template <int DIM>
 __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restrict__ verts,
                                                           const float* __restrict__ weights, int k1, int R,
                                                           int64_t n_samples, const float* __restrict__ dbox,
-                                                          uint32_t* __restrict__ keys, int hilbert) {
+                                                          uint32_t* __restrict__ keys, int hilbert,
+                                                          const uint8_t* __restrict__ late) {
   constexpr int BITS = 32 / DIM > 10 ? 10 : 32 / DIM;
   float lo[DIM], scale[DIM];
 #pragma unroll
@@ -95,16 +96,41 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restric
 #pragma unroll
         for (int b = 0; b < BITS; ++b) code |= ((q[k] >> b) & 1u) << (b * DIM + k);
     }
+    // fused sweep: the PILOT rows of every simplex (one sample near the centre of each face) sort ahead of all other
+    // rows (late[r] != 0: top key bit set), so that the running face maxima are close to final when the bulk arrives
+    if (late != nullptr) {
+      if (BITS * DIM >= 32) code >>= 1;
+      if (late[r]) code |= 0x80000000u;
+    }
     keys[i] = code;
   }
 }
 
-template <int DIM, int KS>
+// FUSED: only the per-face maxima are wanted (core.py:251-276 folded in).  A sample whose running minimum - the
+// distance to a real point, an upper bound of its nearest-neighbour distance - does not exceed the running maximum
+// of any face it lies on can never raise a face value: it leaves the tile's pruning radius M and the per-leaf tests
+// ("dead"), and the traversal ends when the LIVE samples are exact.  Those deliver their values (integer atomic
+// max on face_bits); a dead sample delivers nothing.  face_bits only ever receives exact values, so the face values
+// equal the exhaustive result bit for bit.  Proving a minimum exact costs most of a traversal (every leaf whose box
+// is nearer than the minimum found must be looked at); seeing that a sample is out of the running takes the first
+// one or two leaves.
+struct SortedFaces {
+  const uint32_t* memb;     // per row: bit f set = the row lies on face f
+  uint32_t* face_bits;      // running maxima (d2 bits), zeroed by the caller
+  const int32_t* slot;      // NULL, or slot[s * n_faces + f]
+  int n_faces;
+  int refresh;              // the face maxima are re-read every so many evaluated leaves
+  __device__ __forceinline__ int64_t slot_of(int64_t s, int f) const {
+    return slot ? (int64_t)slot[s * (int64_t)n_faces + f] : s * (int64_t)n_faces + f;
+  }
+};
+
+template <int DIM, int KS, bool FUSED>
 __global__ __launch_bounds__(256) void sweep_sorted_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_samples, const uint32_t* __restrict__ order, int32_t* __restrict__ queue,
-    uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct) {
+    uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct, SortedFaces sf) {
   // KS samples per lane: a tile is 64 * KS consecutive samples of the sorted order (lane l holds l, l + 64, ...)
   constexpr int DP = padded_dim(DIM);
   constexpr int TILE = 64 * KS;
@@ -143,6 +169,34 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       }
       best[i] = __builtin_inff();
     }
+    // FUSED: faces of this lane's samples, the smallest running maximum among them, who is still in the running
+    uint32_t mb[KS], thr[KS];
+    bool alive[KS];
+    auto read_thr = [&]() {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        uint32_t t = 0xffffffffu, m = mb[i];
+        const int64_t s_i = (int64_t)(id[i] / (uint32_t)R);
+        while (m) {  // (per lane: at most dimension + 1 faces for a vertex, one for an interior sample)
+          const int f = __builtin_ctz(m);
+          m &= m - 1u;
+          const uint32_t v = __hip_atomic_load(sf.face_bits + sf.slot_of(s_i, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t = v < t ? v : t;
+        }
+        thr[i] = t;
+      }
+    };
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) mb[i] = live[i] ? sf.memb[id[i] - (id[i] / (uint32_t)R) * (uint32_t)R] : 0u;
+      read_thr();
+#pragma unroll
+      for (int i = 0; i < KS; ++i) alive[i] = live[i] && mb[i] != 0u;
+    } else {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) { alive[i] = true; mb[i] = 0u; thr[i] = 0u; }
+    }
+    int evals_since = 0;
     float tlo[DIM], thi[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
@@ -229,7 +283,7 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
                   const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - pk, pk - c_hi[k]), 0.f);
                   lbp = __builtin_fmaf(gap, gap, lbp);
                 }
-                const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best[i]), src));
+                const float bi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alive[i] ? best[i] : -1.f), src));
                 need = need || (lbp * SAFE < bi);
               }
             }
@@ -264,7 +318,7 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
           const float gap = __builtin_fmaxf(__builtin_fmaxf(blo[k] - p[i][k], p[i][k] - bhi[k]), 0.f);
           lbp = __builtin_fmaf(gap, gap, lbp);
         }
-        need = need || (lbp * SAFE < best[i]);
+        need = need || (alive[i] && lbp * SAFE < best[i]);
       }
       if (__ballot(need) == 0ull) continue;
       ++n_leaf_eval;
@@ -298,14 +352,40 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
           }
         }
       }
-      float bm = best[0];
+      if constexpr (FUSED) {
+        if (++evals_since >= sf.refresh) {  // (wave-uniform counter) the maxima have risen meanwhile
+          evals_since = 0;
+          read_thr();
+        }
 #pragma unroll
-      for (int i = 1; i < KS; ++i) bm = __builtin_fmaxf(bm, best[i]);
-      M = wave_max_f32(bm);
+        for (int i = 0; i < KS; ++i) alive[i] = alive[i] && __float_as_uint(best[i]) > thr[i];
+      }
+      float bm = -1.f;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) bm = __builtin_fmaxf(bm, alive[i] ? best[i] : -1.f);
+      M = wave_max_f32(bm);   // (nobody left alive: M = -1, every remaining bound test fails, the walk unwinds)
     }
+    if constexpr (FUSED) {
+      // the samples still alive are exact: deliver (only where the value can raise the maximum last seen or read now)
 #pragma unroll
-    for (int i = 0; i < KS; ++i)
-      if (live[i]) out_d2[id[i]] = __float_as_uint(best[i]);
+      for (int i = 0; i < KS; ++i) {
+        if (alive[i]) {
+          uint32_t m = mb[i];
+          const int64_t s_i = (int64_t)(id[i] / (uint32_t)R);
+          const uint32_t bb = __float_as_uint(best[i]);
+          while (m) {
+            const int f = __builtin_ctz(m);
+            m &= m - 1u;
+            uint32_t* w = sf.face_bits + sf.slot_of(s_i, f);
+            if (bb > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bb);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KS; ++i)
+        if (live[i]) out_d2[id[i]] = __float_as_uint(best[i]);
+    }
     const unsigned long long item_tests = n_leaf_test + n_node_test - tests_before;
     max_item_tests = item_tests > max_item_tests ? item_tests : max_item_tests;
   }
@@ -320,40 +400,42 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
 template <int DIM>
 struct SampleKeysOp {
   static int run(const float* verts, const float* weights, int k1, int R, int64_t n_samples, const float* box,
-                 uint32_t* keys, hipStream_t st) {
+                 uint32_t* keys, const uint8_t* late, hipStream_t st) {
     int64_t blocks = (n_samples + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((sample_keys_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, verts, weights, k1, R,
-                       n_samples, box, keys, g_curve);
+                       n_samples, box, keys, g_curve, late);
     return check_launch("sample_keys");
   }
 };
 
 template <int DIM>
 struct SweepSortedOp {
-  template <int KS>
+  template <int KS, bool FUSED>
   static int launch(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                     int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
-                    unsigned long long* stats, hipStream_t st) {
+                    unsigned long long* stats, SortedFaces sf, hipStream_t st) {
     // persistent blocks of 4 independent waves, as many as the registers let a CU hold (asked once per instantiation)
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM, KS>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM, KS, FUSED>, 256, 0) != hipSuccess || nb < 1) nb = 4;
       blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int64_t n_tiles = (n_samples + 64 * KS - 1) / (64 * KS);
     int64_t grid = (int64_t)blocks_per_cu * 256;
     if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
-    hipLaunchKernelGGL((sweep_sorted_kernel<DIM, KS>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                       weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct);
+    hipLaunchKernelGGL((sweep_sorted_kernel<DIM, KS, FUSED>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts,
+                       weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct, sf);
     return check_launch("sweep_sorted");
   }
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                  int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
-                 unsigned long long* stats, hipStream_t st) {
-    if (g_sorted_ks == 2) return launch<2>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, st);
-    return launch<1>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, st);
+                 unsigned long long* stats, SortedFaces sf, hipStream_t st) {
+    if (sf.face_bits != nullptr)
+      return launch<1, true>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
+    if (g_sorted_ks == 2) return launch<2, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
+    return launch<1, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
   }
 };
 
@@ -376,6 +458,16 @@ int flooder_sample_keys_f32(const float* verts, const float* weights, int k1, in
       n_simplices * (int64_t)R > 0xfffffffeLL)
     return fail(FLOODER_E_ARG, "flooder_sample_keys_f32: bad argument (or more than 2^32 - 2 samples)");
   return dispatch_dim<SampleKeysOp>(dim, verts, weights, k1, R, n_simplices * (int64_t)R, box, keys,
+                                    (const uint8_t*)nullptr, (hipStream_t)stream);
+}
+
+int flooder_sample_keys_late_f32(const float* verts, const float* weights, int k1, int R, int64_t n_simplices, int dim,
+                                 const float* box, const uint8_t* late_rows, uint32_t* keys, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!verts || !weights || !box || !keys || !late_rows || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || n_simplices < 0 ||
+      n_simplices * (int64_t)R > 0xfffffffeLL)
+    return fail(FLOODER_E_ARG, "flooder_sample_keys_late_f32: bad argument (or more than 2^32 - 2 samples)");
+  return dispatch_dim<SampleKeysOp>(dim, verts, weights, k1, R, n_simplices * (int64_t)R, box, keys, late_rows,
                                     (hipStream_t)stream);
 }
 
@@ -390,7 +482,23 @@ int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim
   const Levels lv = make_levels(n_pts);
   return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
                                      reinterpret_cast<const uint32_t*>(sample_order), queue, out_d2,
-                                     reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
+                                     reinterpret_cast<unsigned long long*>(stats), SortedFaces{nullptr, nullptr, nullptr, 0, 0},
+                                     (hipStream_t)stream);
+}
+
+int flooder_sweep_bvh_sorted_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                       const int32_t* sample_order, int32_t* queue, const uint32_t* memb, int n_faces,
+                                       uint32_t* face_bits, const int32_t* face_slot, uint64_t* stats, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !sample_order || !queue || !memb || !face_bits || n_pts < 1 || k1 < 1 ||
+      k1 > FLOODER_MAX_VERTS || R < 0 || n_faces < 1 || n_faces > 32 || n_simplices * (int64_t)R > 0xfffffffeLL)
+    return fail(FLOODER_E_ARG, "flooder_sweep_bvh_sorted_faces_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
+                                     reinterpret_cast<const uint32_t*>(sample_order), queue, (uint32_t*)nullptr,
+                                     reinterpret_cast<unsigned long long*>(stats),
+                                     SortedFaces{memb, face_bits, face_slot, n_faces, g_sorted_refresh}, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -242,6 +242,23 @@ int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  const int32_t* sample_order, int32_t* queue, uint32_t* out_d2, uint64_t* stats,
                                  void* stream);
 
+/* The sorted sweep fused with the per-face maxima (core.py:251-276 folded in; the default above 3 dimensions when only
+ * the face values are wanted): no (S, R) buffer.  A sample whose running minimum - the distance to a real point - does
+ * not exceed the running maximum of any face it lies on (memb[r]: bit f = row r lies on face f, n_faces <= 32;
+ * face_bits: n_simplices x n_faces zeroed uint32, or as many words as face_slot addresses) leaves the tile's pruning
+ * radius; the samples still in the running at the end of a traversal are exact and raise face_bits (integer atomic
+ * max on the d2 bits).  Values equal the exhaustive result bit for bit; flooder_face_values_f32 takes the roots.
+ * flooder_sample_keys_late_f32: as flooder_sample_keys_f32, but the rows with late_rows[r] != 0 sort behind all
+ * others (top key bit) - the caller marks every row except one PILOT near the centre of each face, so the face
+ * maxima are close to final when the bulk of the samples is swept.  Sort over 32 key bits.  Option "sorted_refresh"
+ * (4): evaluated leaves between two readings of the face maxima. */
+int flooder_sample_keys_late_f32(const float* verts, const float* weights, int k1, int R, int64_t n_simplices, int dim,
+                                 const float* box, const uint8_t* late_rows, uint32_t* keys, void* stream);
+int flooder_sweep_bvh_sorted_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                       const int32_t* sample_order, int32_t* queue, const uint32_t* memb, int n_faces,
+                                       uint32_t* face_bits, const int32_t* face_slot, uint64_t* stats, void* stream);
+
 /* Same sweep restricted to an explicit work list and SEEDED with the minima already in out_d2 (upper
  * bounds from an earlier pass): item_list[i] = simplex * ceil(R/64) + tile, tiles are 64 consecutive
  * samples; *n_items (device int32) entries.  Finishes what flooder_sweep_cell_f32 could not verify.

@@ -137,6 +137,32 @@ def test_sorted_sample_sweep_is_bit_identical(name, dev, monkeypatch):
     assert_close_filtration(dict_values(res[True], keys), z["filtration_f32"], z["points"], name)
 
 
+@pytest.mark.parametrize("refresh", [1, 4, 1000])
+def test_fused_sorted_sweep_equals_unfused(refresh, dev, monkeypatch):
+    """The sorted sweep that delivers the face maxima itself and drops every sample that cannot raise one (default
+    above 3D) against the sorted sweep that stores all per-sample minima and takes the maxima afterwards: grid and
+    random weights, 4-D and 6-D, however often the running maxima are re-read."""
+    lib = _native.load()
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    rng = np.random.default_rng(5)
+    assert lib.flooder_set_option(b"sorted_refresh", refresh) == 0
+    try:
+        for dim, n, k, kw in ((6, 40_000, 24, dict(max_dimension=2, points_per_edge=6)),
+                              (4, 30_000, 30, dict(max_dimension=3, points_per_edge=4)),
+                              (5, 20_000, 20, dict(max_dimension=2, num_rand=40))):
+            P = rng.normal(size=(n, dim)).astype(np.float32)
+            L = P[fo.exact_fps(P, k, 0)]
+            tp, tl = torch.as_tensor(P, device=dev), torch.as_tensor(L, device=dev)
+            out = {}
+            for fused in (True, False):
+                monkeypatch.setattr(core, "SORTED_FUSED_FACES", fused)
+                torch.manual_seed(2)
+                out[fused] = fa.flood_complex(tp, tl, method="bvh", **kw)
+            assert out[True] == out[False], (dim, kw)
+    finally:
+        assert lib.flooder_set_option(b"sorted_refresh", 4) == 0
+
+
 def test_sorted_sample_sweep_random_dimensions(dev, monkeypatch):
     """Dimensions 4, 5, 7 and 8 (one key width each), ragged sample counts (R not a multiple of 64, last tile partly
     dead), duplicated points: sorted-sample sweep == per-simplex tree sweep == kd-tree."""

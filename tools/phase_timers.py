@@ -5,6 +5,7 @@ sys.path.insert(0, '.')
 import flooder_amd as fa
 from flooder_amd import _native, core
 lib = _native.load()
+core.CELL_WITNESS = False   # (its counters share stats[16:40] with the phase sums read below)
 core.CELL_SUPER = len(sys.argv) > 2 and sys.argv[2] == 'super'  # (per-chunk records assume one work item per chunk; the phase sums do not)
 torch.manual_seed(42)
 dev = torch.device('cuda:0')
