@@ -129,6 +129,8 @@ struct DeferList {
   int32_t* tile_count = nullptr;
   int64_t tail_items = INT64_MAX;  // only the last so many items of the chunk launch hand dense chunks on to the tiles
   int listed_first = 1;  // chunk launch: the deferred chunks ahead of the heavy simplices (0: behind them)
+  int chunk_major = 0;   // chunk launch: heavy items ordered chunk by chunk instead of simplex by simplex
+  int drop = 0;          // cell query: interior samples whose running minimum cannot raise the simplex's maximum stop early
 };
 
 // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
@@ -328,9 +330,18 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       if (dl.light) s = dl.light[s];
     } else if (use_lists && (lfirst ? g >= n_listed : g < n_heavy_items)) {
       const int64_t gh = lfirst ? g - n_listed : g;
-      s = gh / chunks;
-      q = (int)(gh - s * chunks);
-      s = dl.heavy[s];
+      if (dl.chunk_major) {
+        // chunk-major: chunk 0 of every heavy simplex, then chunk 1, ... - by the time the later chunks of a simplex
+        // are swept its first ones have raised the running maximum of the full simplex, against which interior
+        // samples are dropped in the cell query (below)
+        const int64_t nh = (int64_t)dl.split[1];
+        q = (int)(gh / nh);
+        s = dl.heavy[gh - (int64_t)q * nh];
+      } else {
+        s = gh / chunks;
+        q = (int)(gh - s * chunks);
+        s = dl.heavy[s];
+      }
     } else if (use_lists) {
       const int64_t gl = lfirst ? g : g - n_heavy_items;
       const int e = item_list[gl];
@@ -1275,11 +1286,20 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
 
       PHASE(7);
       // 3. query the open samples of the current chunk
+      // Only face MAXIMA are wanted: an INTERIOR sample (it lies on the full simplex alone: memb == 1) whose running
+      // minimum - the distance to a real point - has fallen to the running maximum of the simplex can never raise it.
+      // It is dropped on the spot: its minimum becomes 0, which skips its remaining rows of cells (no slab is nearer
+      // than 0), counts as verified, and delivers nothing.  In a dense region the first row of cells (own cell and its
+      // two x-neighbours, ~7 points) usually suffices where the exact query looks at all 27 cells (~66 points).
+      uint32_t thr_top = 0u;
+      if (dl.drop && acc.face_bits)
+        thr_top = __hip_atomic_load(acc.face_bits + acc.slot_of(s, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       auto query_cells = [&]() -> bool {
         bool any_open = false;
   #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           if (open[i]) {
+            const uint32_t thr_i = (thr_top != 0u && acc.memb[row[i]] == 1u) ? thr_top : 0u;
             int ck[DIM];
             float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
   #pragma unroll
@@ -1343,6 +1363,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
                   b = __builtin_fminf(b, d2);
                 }
               }
+              if (__float_as_uint(b) <= thr_i) b = 0.f;  // (dropped: cannot raise the simplex's maximum)
             }
             best[i] = b;
             open[i] = !(b <= c_ok);
@@ -1459,6 +1480,10 @@ struct CellOp {
       // (2: only where an exhaustive evaluation by ONE wave - 150 us and more - would be the tail of the launch)
       if (g_cell_tiles == 2) dl.tail_items = (int64_t)g_cell_tail_waves * grid * 4 / 100;
       dl.listed_first = g_cell_listed_first;
+      // (chunk-major order costs the L2 locality of a simplex's neighbouring chunks: measured a gain on queues up to
+      // ~100 k chunks - cfg 2: 1.290 -> 1.246 ms per step, cfg 3: 4.72 -> 4.69 -, a small loss at cfg 5's 504 k)
+      dl.chunk_major = (g_cell_chunk_major && n_chunks <= (int64_t)g_cell_chunk_major_max) ? 1 : 0;
+      dl.drop = g_cell_drop;
 #define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
   hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
                      k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \

@@ -32,6 +32,9 @@ extern int g_cell_chunks_per_block;  // cell sweep: chunks per persistent workgr
 extern int g_cell_weight_classes;   // cell sweep: the simplex lists in descending weight class (0: in the given order)
 extern int g_cell_listed_first;     // cell sweep, chunk launch: deferred chunks ahead of the heavy simplices
 extern int g_cell_tail_waves;       // cell_tiles = 2: the tail = the last (this percentage of the launch's waves) items
+extern int g_cell_chunk_major;    // cell sweep, chunk launch: heavy simplices chunk by chunk (all first chunks, then all second ones ...)
+extern int g_cell_chunk_major_max;  // ... for queues of at most this many chunks
+extern int g_cell_drop;           // cell query drops interior samples that cannot raise the simplex's maximum
 extern int g_cell_one_pass;         // cell sweep: dense chunks are classified and evaluated in ONE pass over their candidates
 extern int g_cell_min_grid;          // ... and the smallest launch  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
 extern int g_sorted_ks;

@@ -715,6 +715,14 @@ int flooder_set_option(const char* name, int value) {
     g_wit_max_leaves = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_chunk_major") == 0 && (value == 0 || value == 1)) {
+    g_cell_chunk_major = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_drop") == 0 && (value == 0 || value == 1)) {
+    g_cell_drop = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "sorted_refresh") == 0 && value >= 1) {
     g_sorted_refresh = value;
     return FLOODER_OK;

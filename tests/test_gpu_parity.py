@@ -244,14 +244,16 @@ def test_cell_sweep_queue_and_pass_options_change_nothing(dev):
         ref = fa.flood_complex(tp, tl, points_per_edge=ppe)
         for opts in ({b"cell_one_pass": 0}, {b"cell_one_pass": 100000}, {b"cell_weight_classes": 0},
                      {b"cell_listed_first": 0}, {b"cell_chunks_per_block": 48, b"cell_min_grid": 64},
-                     {b"cell_super_min_chunks": 0}):
+                     {b"cell_super_min_chunks": 0}, {b"cell_drop": 0}, {b"cell_chunk_major": 0},
+                     {b"cell_drop": 0, b"cell_chunk_major": 0}):
             try:
                 for k, v in opts.items():
                     assert lib.flooder_set_option(k, v) == 0
                 got = fa.flood_complex(tp, tl, points_per_edge=ppe)
             finally:
                 for k, v in ((b"cell_one_pass", 125), (b"cell_weight_classes", 1), (b"cell_listed_first", 1),
-                             (b"cell_chunks_per_block", 12), (b"cell_min_grid", 384), (b"cell_super_min_chunks", 49152)):
+                             (b"cell_chunks_per_block", 12), (b"cell_min_grid", 384), (b"cell_super_min_chunks", 49152),
+                             (b"cell_drop", 1), (b"cell_chunk_major", 1)):
                     lib.flooder_set_option(k, v)
             assert got == ref, opts
 
