@@ -67,6 +67,10 @@ constexpr int WQ = 768;        // queued live samples (beyond: handed to the fin
 constexpr int WROWS = FLOODER_WIT_MAX_ROWS;      // samples per simplex at most
 constexpr int UNR = 4;         // candidate rows in flight per lane
 constexpr int UNRF = 1;        // groups of 256 rows in flight in the pass over all samples
+#ifndef FLOODER_WIT_FDEPTH
+#define FLOODER_WIT_FDEPTH 1
+#endif
+constexpr int FDEPTH = FLOODER_WIT_FDEPTH;  // steps of the pass over all samples whose table rows are in flight
 constexpr int NBIN = 64;
 constexpr int PLANE_ROW = 24;  // (layout of simplex_planes_kernel, flood_cell.hip)
 static_assert(WCOARSE == WTHREADS, "one coarse sample per thread");
@@ -835,11 +839,16 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
         fr.mb[u] = fr.valid[u] ? acc.memb[fr.rr[u]] : 0u;
       }
     };
-    FineRows cur;
-    load_rows(0, cur);
+    // (FDEPTH steps ahead: a step is an L2 round trip - ~1 us - for a few hundred instructions of work)
+    FineRows ring[FDEPTH];
+#pragma unroll
+    for (int a = 0; a < FDEPTH; ++a)
+      if (a * WTHREADS * UNRF < R) load_rows(a * WTHREADS * UNRF, ring[a]);
     for (int g0 = 0; g0 < R; g0 += WTHREADS * UNRF) {
-      FineRows nxt;
-      if (g0 + WTHREADS * UNRF < R) load_rows(g0 + WTHREADS * UNRF, nxt);
+      const FineRows cur = ring[0];
+#pragma unroll
+      for (int a = 0; a + 1 < FDEPTH; ++a) ring[a] = ring[a + 1];
+      if (g0 + FDEPTH * WTHREADS * UNRF < R) load_rows(g0 + FDEPTH * WTHREADS * UNRF, ring[FDEPTH - 1]);
 #pragma unroll
       for (int u = 0; u < UNRF; ++u) {
         if (g0 + u * WTHREADS >= R) break;  // (block-uniform)
@@ -889,7 +898,6 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
           if (lane == 0) count(ST_LIVE, (unsigned long long)__popcll(m));
         }
       }
-      cur = nxt;
     }
     __syncthreads();
     WPHASE(5);

@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from bench import kernel_source_sha
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-name = sys.argv[2] if len(sys.argv) > 2 else f"r3_{tag}"
+name = sys.argv[2] if len(sys.argv) > 2 else f"r4_{tag}"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 FROM_PMC = "--from-pmc" in sys.argv   # recompute traffic.json from the committed summaries (no raw profiler output)
@@ -48,7 +48,9 @@ traffic = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/t
 sha = kernel_source_sha()
 # span of bench.py -> the kernels launched under it (the cell sweep is two launches: runs of four chunks, then chunk by chunk)
 # (method, span, ((kernel, launches per step), ...))
-SPANS = (("cell", "sweep", (("cell_sweep_kernel<3, true, 4>", 1), ("cell_sweep_kernel<3, false, 4>", 1))),
+# (round 4: the witness sweep - its list kernel and the sweep itself - runs ahead of the two cell-sweep launches)
+SPANS = (("cell", "sweep", (("wit_sweep_kernel<3>", 1), ("wit_list_kernel", 1), ("cell_sweep_kernel<3, true, 4>", 1),
+                            ("cell_sweep_kernel<3, false, 4>", 1))),
          # the pass over the flagged tiles, its hard tiles (one workgroup each), the ordering of the flagged tiles:
          # one launch each per step (the "top pass" that doubled the first two is off by default since round 2)
          ("cell", "fallback", (("finish_faces_kernel<3, false>", 1), ("finish_faces_kernel<3, true>", 1),

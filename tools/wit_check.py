@@ -47,7 +47,7 @@ print("S", S, "R", R, "coarse", plan.wit[2] if plan.wit else None)
 
 def run(wit, with_stats=False, shared=True):
     core.CELL_WITNESS = wit
-    st = torch.zeros(40, dtype=torch.int64, device=dev) if with_stats else None
+    st = torch.zeros(96 + 12 * S, dtype=torch.int64, device=dev) if with_stats else None   # (timer builds also keep a record per simplex)
     out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=st, plan=plan,
                                         face_slots=slots[:2] if shared else None)
     torch.cuda.synchronize()
