@@ -1461,8 +1461,9 @@ struct CellOp {
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
-      hipLaunchKernelGGL((simplex_planes_kernel<DIM>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, verts, k1, ns,
-                         plane_tab);
+      if (!planes_are_done(verts, plane_tab, ns, st))
+        hipLaunchKernelGGL((simplex_planes_kernel<DIM>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, verts, k1, ns,
+                           plane_tab);
       constexpr int CHUNK = 64 * SPL_CHUNK;
       const int64_t n_chunks = ns * ((R + CHUNK - 1) / CHUNK);
       int64_t want = n_chunks / (g_cell_chunks_per_block > 0 ? g_cell_chunks_per_block : 48);
@@ -1510,6 +1511,19 @@ struct CellOp {
 }  // namespace
 
 namespace flooder {
+namespace {
+struct PlanesDone { const float* verts; const float* tab; int64_t ns; hipStream_t st; };
+thread_local PlanesDone g_planes_done = {nullptr, nullptr, 0, nullptr};
+}  // namespace
+void planes_done_for(const float* verts, const float* tab, int64_t n_simplices, hipStream_t st) {
+  g_planes_done = PlanesDone{verts, tab, n_simplices, st};
+}
+bool planes_are_done(const float* verts, const float* tab, int64_t n_simplices, hipStream_t st) {
+  const bool hit = g_planes_done.verts == verts && g_planes_done.tab == tab && g_planes_done.ns == n_simplices &&
+                   g_planes_done.st == st && verts != nullptr;
+  g_planes_done = PlanesDone{nullptr, nullptr, 0, nullptr};
+  return hit;
+}
 int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st) {
   if (dim == 2)
     hipLaunchKernelGGL((simplex_planes_kernel<2>), dim3((unsigned)((n_simplices + 255) / 256)), dim3(256), 0, st, verts, k1,

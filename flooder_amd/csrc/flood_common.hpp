@@ -67,6 +67,10 @@ extern int g_wit_max_live_pct;
 extern int g_wit_min_bins;  // ... excess bins (of 64) the stage must hold at least
 // face planes of every simplex (flood_cell.hip: simplex_planes_kernel), 24 floats per simplex
 int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st);
+// the witness sweep's entry has just filled `tab` for these simplices on this stream: the cell sweep's entry, called
+// next with the same buffers, skips its own launch (consumed by the first match; any other call clears it)
+void planes_done_for(const float* verts, const float* tab, int64_t n_simplices, hipStream_t st);
+bool planes_are_done(const float* verts, const float* tab, int64_t n_simplices, hipStream_t st);
 char* err_buf();
 int fail(int code, const char* msg);
 int check_launch(const char* what);

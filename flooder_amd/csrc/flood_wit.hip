@@ -1054,6 +1054,7 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
 // workgroup that pops a simplex only to find it too heavy pays an atomic round trip and two barriers for nothing -
 // 77 us per launch where every simplex is heavy.
 constexpr int WCLASSES = 4;
+constexpr int WLIST_PER = 8;  // simplices per thread held in registers (n <= 8192: one global round trip in all)
 __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict__ weight, int n, float limit,
                                                         int32_t* __restrict__ list, int32_t* __restrict__ count) {
   __shared__ int s_cnt[WCLASSES][16];
@@ -1063,12 +1064,29 @@ __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict_
     if (!(w >= 0.f) || !(w <= limit)) return -1;
     return w > 0.5f * limit ? 0 : (w > 0.25f * limit ? 1 : (w > 0.125f * limit ? 2 : 3));
   };
+  const int steps = (n + 1023) / 1024;
+  const bool in_regs = steps <= WLIST_PER;
+  int c_reg[WLIST_PER];
+#pragma unroll
+  for (int u = 0; u < WLIST_PER; ++u) {   // (all loads in flight together)
+    const int i = u * 1024 + (int)threadIdx.x;
+    c_reg[u] = (in_regs && i < n) ? cls(weight[i]) : -1;
+  }
+  auto class_of = [&](int step, int i) -> int {
+    if (in_regs) {
+      int c = -1;
+#pragma unroll
+      for (int u = 0; u < WLIST_PER; ++u) c = step == u ? c_reg[u] : c;
+      return c;
+    }
+    return i < n ? cls(weight[i]) : -1;
+  };
   // totals per class
   int tot[WCLASSES];
 #pragma unroll
   for (int c = 0; c < WCLASSES; ++c) tot[c] = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int c = cls(weight[i]);
+  for (int st = 0; st < steps; ++st) {
+    const int c = class_of(st, st * 1024 + (int)threadIdx.x);
 #pragma unroll
     for (int k = 0; k < WCLASSES; ++k) tot[k] += c == k ? 1 : 0;
   }
@@ -1092,9 +1110,9 @@ __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict_
   int pos[WCLASSES];
 #pragma unroll
   for (int k = 0; k < WCLASSES; ++k) pos[k] = s_base[k];
-  for (int base = 0; base < n; base += 1024) {  // (order kept inside a class)
-    const int i = base + threadIdx.x;
-    const int c = i < n ? cls(weight[i]) : -1;
+  for (int st = 0; st < steps; ++st) {  // (order kept inside a class)
+    const int i = st * 1024 + (int)threadIdx.x;
+    const int c = class_of(st, i);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < WCLASSES; ++k) {
@@ -1124,6 +1142,7 @@ struct WitOp {
     if constexpr (DIM == 2 || DIM == 3) {
       const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
       if (rc != FLOODER_OK) return rc;
+      planes_done_for(verts, plane_tab, ns, st);   // (the cell sweep's entry, next on this stream, need not repeat it)
       hipLaunchKernelGGL(wit_list_kernel, dim3(1), dim3(1024), 0, st, out.weight, (int)ns, (float)g_wit_weight, item_list,
                          item_count);
       const int grid = (int)(ns < g_wit_grid ? ns : g_wit_grid);
