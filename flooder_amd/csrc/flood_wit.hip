@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
 // workgroup that pops a simplex only to find it too heavy pays an atomic round trip and two barriers for nothing -
 // 77 us per launch where every simplex is heavy.
 constexpr int WCLASSES = 4;
-constexpr int WLIST_PER = 8;  // simplices per thread held in registers (n <= 8192: one global round trip in all)
+constexpr int WLIST_PER = 32;  // simplices per thread whose class is held in registers, 4 bits each (n <= 32768: one global round trip in all)
 __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict__ weight, int n, float limit,
                                                         int32_t* __restrict__ list, int32_t* __restrict__ count) {
   __shared__ int s_cnt[WCLASSES][16];
@@ -1066,18 +1066,26 @@ __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict_
   };
   const int steps = (n + 1023) / 1024;
   const bool in_regs = steps <= WLIST_PER;
-  int c_reg[WLIST_PER];
+  uint32_t c_pack[WLIST_PER / 8];   // class + 1 of simplex step * 1024 + tid, 4 bits each
 #pragma unroll
-  for (int u = 0; u < WLIST_PER; ++u) {   // (all loads in flight together)
-    const int i = u * 1024 + (int)threadIdx.x;
-    c_reg[u] = (in_regs && i < n) ? cls(weight[i]) : -1;
+  for (int g = 0; g < WLIST_PER / 8; ++g) {
+    float w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // (eight loads in flight together)
+      const int i = (g * 8 + u) * 1024 + (int)threadIdx.x;
+      w8[u] = (in_regs && i < n) ? weight[i] : -1.f;
+    }
+    uint32_t pk = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pk |= (uint32_t)(cls(w8[u]) + 1) << (4 * u);
+    c_pack[g] = pk;
   }
   auto class_of = [&](int step, int i) -> int {
     if (in_regs) {
-      int c = -1;
+      uint32_t pk = 0u;
 #pragma unroll
-      for (int u = 0; u < WLIST_PER; ++u) c = step == u ? c_reg[u] : c;
-      return c;
+      for (int g = 0; g < WLIST_PER / 8; ++g) pk = (step >> 3) == g ? c_pack[g] : pk;
+      return (int)((pk >> (4 * (step & 7))) & 15u) - 1;
     }
     return i < n ? cls(weight[i]) : -1;
   };

@@ -58,7 +58,7 @@ SPANS = (("cell", "sweep", (("wit_sweep_kernel<3>", 1), ("wit_list_kernel", 1), 
          ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)),
          # tree sweep over sorted samples: keys, the radix sort's launches (rocprim kernels are not listed by name:
          # their share is in kernel_stats.csv), the sweep
-         ("bvh", "sweep_bvh", (("sweep_sorted_kernel<6, 1>", 1), ("sample_keys_kernel<6>", 1))),
+         ("bvh", "sweep_bvh", (("sweep_sorted_kernel<6, 1, false>", 1), ("sample_keys_kernel<6>", 1))),
          ("ball", "sweep_ball", (("sweep_kernel<3, true>", 1),)))
 for method, span, kerns, in SPANS:
     have = [(k, m) for k, m in kerns if k in out and "FETCH_SIZE_mean_per_launch" in out[k]]
