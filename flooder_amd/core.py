@@ -518,6 +518,10 @@ class PointIndex:
         pts32 = points.detach().to(torch.float32).contiguous()
         n, dim = pts32.shape
         self.n, self.dim = n, dim
+        # where the rows came from: flood_complex(index=...) refuses an index whose source tensor has been written to
+        # in place since (same storage, other version counter); a different tensor of the same shape cannot be told
+        # from a copy of the same cloud and is taken on the caller's word
+        self.source = (points.data_ptr(), points._version)
         self.dp = lib.flooder_padded_dim(dim)
         self.box = box if box is not None else cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
         codes = torch.empty(n, dtype=torch.int64, device=dev)
@@ -886,7 +890,9 @@ def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: t
 def bvh_sorts_samples(dim: int, S: int, R: int) -> bool:
     """Does the tree sweep of S simplices x R samples in ``dim`` dimensions run over spatially sorted samples?"""
     want = BVH_SORTED_SAMPLES if BVH_SORTED_SAMPLES is not None else dim > 3
-    return bool(want) and BVH_SORTED_MIN_SAMPLES <= S * R < (1 << 32) - 2
+    # (keys, sorted keys, order and the radix sort's scratch: ~20 B per sample on top of the (S, R) buffer - beyond
+    # the workspace bound the per-simplex sweep, which needs none of it, takes over)
+    return bool(want) and BVH_SORTED_MIN_SAMPLES <= S * R < (1 << 32) - 2 and S * R * 20 <= SORTED_WORKSPACE_BYTES
 
 
 def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.Tensor, faces: _FaceTable,
@@ -982,6 +988,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
 
 # tree sweep over spatially sorted samples (csrc/flood_sorted.hip): None = above 3 dimensions, True / False = always / never
 BVH_SORTED_SAMPLES: Optional[bool] = None
+SORTED_WORKSPACE_BYTES = 16 << 30   # scratch the sorted-sample sweep may take (288 GB of HBM per GPU)
 SORTED_FUSED_FACES = False  # the sorted sweep delivers the face maxima itself and drops what cannot raise one (measured SLOWER at cfg 4: 116 vs 87 ms - in 6-D the distances of a triangle's samples concentrate, 83 % of the leaves are still evaluated; kept as an option)
 BVH_SORTED_MIN_SAMPLES = 64 * 1024   # below this the sort costs more than it saves
 EMPTY_CACHE_ABOVE_BYTES = 1 << 30   # flood_complex releases the allocator's cache when more than this is cached unused
@@ -1235,6 +1242,10 @@ def flood_complex(
             raise ValueError("index= applies to ROCm tensors with method 'cell' or 'bvh'")
         if not isinstance(index, PointIndex) or (index.n, index.dim) != tuple(points.shape) or index.pts.device != points.device:
             raise ValueError("index= is not a PointIndex of these points (shape or device differ)")
+        src = getattr(index, "source", None)
+        if src is not None and src[0] == points.data_ptr() and src[1] != points._version:
+            raise ValueError("index= was built from an earlier state of `points` (the tensor has been modified in "
+                             "place since): rebuild the PointIndex")
         shared_index = index
     if isinstance(landmarks, Integral):
         if (shared_index is None and points.is_cuda and method != "ball" and points.shape[1] <= FPS_BUCKET_MAX_DIM and points.dtype in SUPPORTED_DTYPES

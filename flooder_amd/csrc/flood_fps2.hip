@@ -656,7 +656,7 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
   ProgressSlot* slot = progress_slot(device);
   if (slot) {
     std::lock_guard<std::mutex> guard(slot->busy);
-    const u64 tag = (u64)(++slot->calls & 0xffu);
+    const u64 tag = (u64)(++slot->calls % 255u) + 1ull;   // 1 .. 255: never the tag of the freshly zeroed word
     volatile u64* word = slot->host;
     *word = 0ull;   // (a stale store of an earlier call carries that call's tag)
     hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n, order,
@@ -682,13 +682,29 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
         for (int i = 0; i < room; ++i, ++enq)
           hipLaunchKernelGGL((fps2_batch_step_kernel<DIM, RPL>), dim3(grid), dim3(256), 0, st, pts_sorted, minsq, n,
                              order, n_buckets, box, keys, bcoord, enq, n_lms, ctr, rec, out_idx, flags, slot->dev, tag);
+        if (hipGetLastError() != hipSuccess)   // (a launch that failed would never report: the wait below must not start)
+          return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: a launch of the selection failed");
         spins = 0;
       } else if (++spins > (1L << 22)) {   // nothing reported for a long time: is the stream still alive?
         const hipError_t q = hipStreamQuery(st);
         if (q != hipSuccess && q != hipErrorNotReady)
           return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: the stream failed during the selection");
-        if (q == hipSuccess && (*word >> 56) == tag && (int)(uint32_t)*word < n_lms && (int)(uint32_t)*word == seen_it)
-          return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: no progress (internal error)");
+        if (q == hipSuccess) {
+          // every enqueued launch has run.  If the progress word is behind (a store of this call overwritten by a late
+          // store of an earlier call on another stream, or no store at all) the device counter is the truth: read it
+          // back, as the path without pinned memory does
+          const u64 v2 = *word;
+          if (!((v2 >> 56) == tag && (int)(uint32_t)v2 > seen_it)) {
+            int32_t now = 0;
+            if (hipMemcpyAsync(&now, ctr + enq, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+              return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: reading the landmark counter failed");
+            if (now <= seen_it && now < n_lms)
+              return fail(FLOODER_E_LAUNCH, "flooder_fps_batched_f32: no progress (internal error)");
+            seen_it = now;
+            seen_l = enq;
+          }
+        }
         spins = 0;
       }
     }

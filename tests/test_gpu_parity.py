@@ -768,3 +768,17 @@ def test_index_sort_is_a_stable_sort(dev):
                                              _native.ptr(tmp), nb, 0), "flooder_index_sort")
         torch.cuda.synchronize()
         assert np.array_equal(order.cpu().numpy().astype(np.int64), want), (n, bits)
+
+
+def test_index_of_a_modified_cloud_is_refused(dev):
+    """``flood_complex(index=...)``: an index built before the cloud tensor was written to in place is refused (same
+    storage, other version counter); an untouched tensor passes."""
+    g = torch.Generator().manual_seed(1)
+    pts = torch.randn(50_000, 3, generator=g).to(dev)
+    lms = fa.generate_landmarks(pts, 60, start_idx=0)
+    idx = core.PointIndex(pts)
+    a = fa.flood_complex(pts, lms, points_per_edge=6, index=idx)
+    assert a == fa.flood_complex(pts, lms, points_per_edge=6)
+    pts.mul_(1.5)
+    with pytest.raises(ValueError, match="modified in place"):
+        fa.flood_complex(pts, lms, points_per_edge=6, index=idx)
