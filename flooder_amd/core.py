@@ -1002,6 +1002,7 @@ SHARED_FACE_SLOTS = True   # one running maximum per distinct face of the comple
 FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does not fit is finished by one wave)
 CELL_DENSITY_GRID = True   # PointIndex carries a density grid; the cell sweep reads its first cell size from it
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
+WIT_MIN_SIMPLICES = 1536   # fewer simplices than this in a sweep: no witness sweep (1024 persistent workgroups, one simplex each)
 CELL_WITNESS = True  # sparse simplices go to the witness sweep first (whole simplex per wave, coarse samples + bounds)
 
 
@@ -1056,7 +1057,11 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # [48:] histogram of the flagged tiles' bounds and the cursors of the finish's counting sort
         # (one zero fill for everything that starts at zero: top | ctl | face_bits)
         # (the sharded work-queue heads of the sweep's launches sit in front: QUEUE_WORDS each)
-        use_wit = CELL_WITNESS and CELL_SUPER and CELL_PROBE and plan.wit is not None and index.dim in (2, 3)
+        # (a short queue - a rank's share of a multi-GPU run - leaves the witness sweep's workgroups one simplex each: the
+        # launch then lasts as long as its longest item, 250 - 300 us, where the cell sweep balances chunk by chunk;
+        # measured on an eighth of cfg 2: 0.65 ms per rank with it, 0.55 without)
+        use_wit = (CELL_WITNESS and CELL_SUPER and CELL_PROBE and plan.wit is not None and index.dim in (2, 3)
+                   and S >= WIT_MIN_SIMPLICES)
         zeroed = torch.zeros((1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots,
                              dtype=torch.int32, device=dev)
         if use_wit:
