@@ -537,7 +537,8 @@ def main():
                 "fallback_nodes_expanded": sh[11], "fallback_max_tests_one_tile": sh[12],
                 "finish_tiles_dropped_on_arrival": sh[13], "finish_samples_live_on_arrival": sh[14],
                 "finish_focus_rounds": sh[15],
-                "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks, "dense_tiles": core.LAST_STATS.dense_tiles,
+                "fused_faces": bool(core.FUSED_FACES), "deferred_chunks": core.LAST_STATS.deferred_chunks,
+                "light_heavy_simplices": list(getattr(core.LAST_STATS, "light_heavy", (None, None))), "dense_tiles": core.LAST_STATS.dense_tiles,
                 "finish_shared_rounds": list(core.LAST_STATS.hard_entries),
                 "shared_face_slots": slots is not None}
     else:

@@ -1120,6 +1120,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
                 FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
+            LAST_STATS.light_heavy = (int(ctl[14].item()), int(ctl[15].item()))
             LAST_STATS.dense_tiles = int(ctl[18].item())
             c_h = fctl[:24].tolist()
             LAST_STATS.hard_entries = (int(c_h[5]), int(c_h[7]))

@@ -288,6 +288,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
   // cloud too dense for runs of four, or a short queue, has every simplex on the heavy list)
   const bool use_lists = TILES || (!SUPER && dl.list && (!dl.split || dl.split[2] != 0));
   const int64_t n_heavy_items = (!TILES && use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
+  // (decided once per launch, wave-uniform: see the item decoding below)
+  const bool chunk_major = wave_uniform((!SUPER && !TILES && dl.chunk_major && use_lists && dl.heavy && chunks > 1 &&
+                                         3 * (n_heavy_items / chunks) < n_simplices) ? 1 : 0) != 0;
   // chunk launch: the chunks the runs deferred come FIRST - they are the long items of this launch (a neighbourhood
   // that overflowed the shared stage), and at the end of the queue they were its tail
   const bool lfirst = TILES || dl.listed_first != 0;
@@ -330,13 +333,26 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       if (dl.light) s = dl.light[s];
     } else if (use_lists && (lfirst ? g >= n_listed : g < n_heavy_items)) {
       const int64_t gh = lfirst ? g - n_listed : g;
-      if (dl.chunk_major) {
-        // chunk-major: chunk 0 of every heavy simplex, then chunk 1, ... - by the time the later chunks of a simplex
-        // are swept its first ones have raised the running maximum of the full simplex, against which interior
-        // samples are dropped in the cell query (below)
-        const int64_t nh = (int64_t)dl.split[1];
-        q = (int)(gh / nh);
-        s = dl.heavy[gh - (int64_t)q * nh];
+      // (only where the heavy list is the small dense rest of a cloud whose sparse simplices the witness sweep has
+      // taken - cfg 2: 1725 of 6052; with every simplex on the list the order cost a rank's share of cfg 3 half of its
+      // sweep time again, for reasons not understood: 2.11 / 1.10 ms against 1.43 / 0.75 at W = 2 / 4)
+      if (chunk_major) {
+        // pilots first: chunk 0 of every heavy simplex, then the other chunks simplex by simplex in list order - by the
+        // time the later chunks of a simplex are swept its first one has raised the running maximum of the full
+        // simplex, against which interior samples are dropped in the cell query (below), and the long items (the
+        // chunks of the densest simplices, first in the list) still start first.  (ALL chunks in chunk-major order
+        // put the last chunk of the densest simplex at the very end of the queue: a rank's share of cfg 3 took 2.11
+        // instead of 1.43 ms.)
+        const int64_t nh = n_heavy_items / chunks;
+        if (gh < nh) {
+          q = 0;
+          s = dl.heavy[gh];
+        } else {
+          const int64_t g2 = gh - nh;
+          const int64_t si = g2 / (chunks - 1);
+          q = 1 + (int)(g2 - si * (chunks - 1));
+          s = dl.heavy[si];
+        }
       } else {
         s = gh / chunks;
         q = (int)(gh - s * chunks);
@@ -1483,7 +1499,7 @@ struct CellOp {
       dl.listed_first = g_cell_listed_first;
       // (chunk-major order costs the L2 locality of a simplex's neighbouring chunks: measured a gain on queues up to
       // ~100 k chunks - cfg 2: 1.290 -> 1.246 ms per step, cfg 3: 4.72 -> 4.69 -, a small loss at cfg 5's 504 k)
-      dl.chunk_major = (g_cell_chunk_major && n_chunks <= (int64_t)g_cell_chunk_major_max) ? 1 : 0;
+      dl.chunk_major = (g_cell_chunk_major && n_chunks <= (int64_t)g_cell_chunk_major_max && n_chunks > ns) ? 1 : 0;
       dl.drop = g_cell_drop;
 #define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
   hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
