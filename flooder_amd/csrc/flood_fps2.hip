@@ -584,7 +584,10 @@ __global__ void fps2_last_kernel(const u64* best, int n_lms, int64_t* out_idx) {
 
 __global__ void fps2_set_ctr_kernel(int32_t* ctr, int value) { ctr[0] = value; }
 
-// one pinned progress word per device (allocated at first use, kept for the life of the process)
+// pinned progress words: eight per device, picked by the stream (allocated at first use, kept for the life of the
+// process).  A call returns with surplus launches of its own still in flight; their late stores carry the old tag and
+// land in the word of THEIR stream, so a call on another stream is not disturbed (two streams that share a word are
+// still safe: a lost store is noticed when the stream goes idle and the device counter is read back instead)
 struct ProgressSlot {
   std::mutex busy;
   u64* host = nullptr;
@@ -592,11 +595,11 @@ struct ProgressSlot {
   unsigned calls = 0;
   bool tried = false;
 };
-inline ProgressSlot* progress_slot(int device) {
-  static ProgressSlot slots[64];
+inline ProgressSlot* progress_slot(int device, hipStream_t stream) {
+  static ProgressSlot slots[64 * 8];
   static std::mutex init;
   if (device < 0 || device >= 64 || g_fps_rounds) return nullptr;
-  ProgressSlot& s = slots[device];
+  ProgressSlot& s = slots[device * 8 + (int)((reinterpret_cast<uintptr_t>(stream) >> 6) & 7u)];
   std::lock_guard<std::mutex> guard(init);
   if (!s.tried) {
     s.tried = true;
@@ -653,7 +656,7 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
   // stream is never drained; without pinned memory: rounds of launches with a counter read-back between them.
   int device = 0;
   hipGetDevice(&device);
-  ProgressSlot* slot = progress_slot(device);
+  ProgressSlot* slot = progress_slot(device, st);
   if (slot) {
     std::lock_guard<std::mutex> guard(slot->busy);
     const u64 tag = (u64)(++slot->calls % 255u) + 1ull;   // 1 .. 255: never the tag of the freshly zeroed word

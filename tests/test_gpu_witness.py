@@ -143,3 +143,27 @@ def test_witness_sweep_options_change_nothing(opts, dev):
     ref_t = run(tor, lms_t, False)
     set_options(**opts)
     assert_same(run(tor, lms_t, True), ref_t, f"torus {opts}")
+
+
+@pytest.mark.parametrize("case", ["triangles_in_3d", "plane_cloud", "large_lattice", "ragged_rows"])
+def test_witness_sweep_other_shapes(case, dev):
+    """Simplices of lower dimension than the cloud (no face planes: the region is a box), a 2-D cloud, the largest
+    lattice the kernel takes (R = 7770 of 8192), a row count that is no multiple of 64 or 256."""
+    g = torch.Generator().manual_seed(21)
+    if case == "triangles_in_3d":
+        pts, n_l, kw = torch.randn(120_000, 3, generator=g), 120, dict(max_dimension=2, points_per_edge=40)
+    elif case == "plane_cloud":
+        pts, n_l, kw = torch.randn(150_000, 2, generator=g), 2500, dict(points_per_edge=40)
+    elif case == "large_lattice":
+        pts, n_l, kw = torch.randn(60_000, 3, generator=g), 60, dict(points_per_edge=35)
+    else:
+        pts, n_l, kw = torch.randn(100_000, 3, generator=g), 250, dict(points_per_edge=17)   # R = 969
+    pts = pts.to(dev)
+    lms = fa.generate_landmarks(pts, n_l, start_idx=0)
+    d = kw.get("max_dimension", pts.shape[1])
+    w, _, fi = core.generate_grid(kw["points_per_edge"], d, dev, torch.float32)
+    assert core.SamplePlan(w, core._FaceTable(fi, w.shape[0], dev)).wit is not None, "no witness plan for this lattice"
+    on = run(pts, lms, True, **kw)
+    off = run(pts, lms, False, **kw)
+    assert_same(on, off, case)
+    assert_same(on, fa.flood_complex(pts, lms, method="bvh", **kw), case + " / tree sweep")
