@@ -9,7 +9,8 @@ import flooder_amd as fa
 from flooder_amd import core
 from helpers import assert_tree_matches_kdtree
 
-dev = torch.device('cuda:0')
+dev = torch.device("cuda:0")
+core.WIT_MIN_SIMPLICES = 0   # (the witness sweep on every queue, however short: this is a parity stress)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(2024)
 bad = 0
