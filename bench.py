@@ -124,6 +124,7 @@ def parse_args():
     ap.add_argument("--no-slots", action="store_true", help="one face-maximum word per (simplex, face) instead of per distinct face")
     ap.add_argument("--no-super", action="store_true", help="cell sweep chunk by chunk (no shared stage per run of four)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end flood_complex timing")
+    ap.add_argument("--no-kd-order", action="store_true", help="point index in curve order also above 3D (default there: k-d tree order)")
     ap.add_argument("--no-witness", action="store_true", help="no witness sweep: every simplex goes through the cell sweep")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="flooder_set_option switch (include/flooder_hip.h), e.g. --option cell_grid=512")
@@ -191,6 +192,8 @@ def main():
         core.CELL_SUPER = False
     if args.no_witness:
         core.CELL_WITNESS = False
+    if args.no_kd_order:
+        core.KD_ORDER_ABOVE_DIM = 8
     if args.units:
         core.SAMPLE_UNITS = tuple(int(v) for v in args.units.split("/"))
     w = WORKLOADS[args.workload]
@@ -513,6 +516,11 @@ def main():
                 "max_tests_one_tile": sh[3], "samples_per_tile": per_tile, "lanes_per_tile": 64,
                 "tiles": f"{per_tile} consecutive samples of a Z-order of all (simplex, sample) pairs" if sorted_tiles
                          else "samples of one simplex"}
+        if sorted_tiles and any(sh[4:11]):   # library built with -DFLOODER_SORTED_TIMERS (diagnostic)
+            tot = float(sum(sh[4:10])) or 1.0
+            st_h["phase_cycle_share"] = {k: round(v / tot, 4) for k, v in zip(
+                ("pop+store", "samples", "node", "refine", "leaf_test", "leaf_eval"), sh[4:10])}
+            st_h["refine_passes_per_tile"] = round(sh[10] / max(n_tiles, 1), 2)
     elif args.method == "cell":
         sh = stats.cpu().tolist()
         tiles_total = S * ((R + 63) // 64)

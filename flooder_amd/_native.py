@@ -41,6 +41,8 @@ SIGNATURES = {
     "flooder_curve_key_bits": (c_int, [c_int]),
     "flooder_index_sort_bytes": (c_int64, [c_int64]),
     "flooder_index_sort": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "flooder_kd_order_bytes": (c_int64, [c_int64]),
+    "flooder_kd_order_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_select_grid_bytes": (c_int64, [c_int]),
     "flooder_box_select_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),

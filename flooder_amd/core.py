@@ -502,6 +502,10 @@ def cloud_box(points: torch.Tensor) -> torch.Tensor:
     return box
 
 
+# point index above this dimension: rows in k-d tree order instead of curve order (8 = never)
+KD_ORDER_ABOVE_DIM = 3
+
+
 class PointIndex:
     """Copy of a point set sorted along a space-filling curve (Hilbert by default) plus its implicit box tree
     (HBM resident).
@@ -524,21 +528,34 @@ class PointIndex:
         self.source = (points.data_ptr(), points._version)
         self.dp = lib.flooder_padded_dim(dim)
         self.box = box if box is not None else cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
-        codes = torch.empty(n, dtype=torch.int64, device=dev)
-        with _span(timer, "morton"):
-            _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
-                                                 _native.ptr(codes), st), "flooder_morton_f32")
-        # sorted row -> original index (int32); radix sort over the bits the codes use
+        # sorted row -> original index (int32)
         self.order32 = torch.empty(n, dtype=torch.int32, device=dev)
-        codes_sorted = torch.empty(n, dtype=torch.int64, device=dev)
-        tmp_bytes = int(lib.flooder_index_sort_bytes(n))
-        if tmp_bytes < 0:
-            raise RuntimeError("flooder_index_sort_bytes failed")
-        tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
-        with _span(timer, "sort"):
-            _native.check(lib.flooder_index_sort(_native.ptr(codes), n, int(lib.flooder_curve_key_bits(dim)),
-                                                 _native.ptr(codes_sorted), _native.ptr(self.order32), _native.ptr(tmp),
-                                                 tmp_bytes, st), "flooder_index_sort")
+        self.kd = dim > KD_ORDER_ABOVE_DIM and n > BVH_LEAF
+        if self.kd:
+            # above 3D: the order of a balanced k-d tree aligned with the box tree's groups (flood_index.hip) - a curve
+            # cuts space on a fixed grid and the 1024-point nodes of a 6-D Hilbert order overlap each other
+            tmp_bytes = int(lib.flooder_kd_order_bytes(n))
+            if tmp_bytes < 0:
+                raise RuntimeError("flooder_kd_order_bytes failed")
+            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+            with _span(timer, "sort"):
+                _native.check(lib.flooder_kd_order_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),
+                                                       _native.ptr(tmp), tmp_bytes, st), "flooder_kd_order_f32")
+        else:
+            codes = torch.empty(n, dtype=torch.int64, device=dev)
+            with _span(timer, "morton"):
+                _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
+                                                     _native.ptr(codes), st), "flooder_morton_f32")
+            # radix sort over the bits the codes use
+            codes_sorted = torch.empty(n, dtype=torch.int64, device=dev)
+            tmp_bytes = int(lib.flooder_index_sort_bytes(n))
+            if tmp_bytes < 0:
+                raise RuntimeError("flooder_index_sort_bytes failed")
+            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+            with _span(timer, "sort"):
+                _native.check(lib.flooder_index_sort(_native.ptr(codes), n, int(lib.flooder_curve_key_bits(dim)),
+                                                     _native.ptr(codes_sorted), _native.ptr(self.order32), _native.ptr(tmp),
+                                                     tmp_bytes, st), "flooder_index_sort")
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
         self.pts = torch.empty((n_pad, self.dp), dtype=torch.float32, device=dev)
         n_nodes = int(lib.flooder_bvh_node_count(n))

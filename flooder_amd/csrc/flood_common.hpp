@@ -38,6 +38,8 @@ extern int g_cell_drop;           // cell query drops interior samples that cann
 extern int g_cell_one_pass;         // cell sweep: dense chunks are classified and evaluated in ONE pass over their candidates
 extern int g_cell_min_grid;          // ... and the smallest launch  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
 extern int g_sorted_ks;
+extern int g_sorted_blocks;
+extern int g_sorted_batch_pct;  // sorted sweep: a batch of leaf tests = the bounds within this % of the nearest one (100: one leaf)
 extern int g_sorted_refresh;  // fused sorted sweep: evaluated leaves between two readings of the face maxima
 extern int g_cell_tiles;   // 1: dense chunks hand their tiles to a third launch (one sample per lane) instead of the exhaustive loop (measured slower: off)
 extern int g_curve_bits;

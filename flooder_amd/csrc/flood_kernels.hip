@@ -356,6 +356,35 @@ __global__ __launch_bounds__(256) void face_max_kernel(const uint32_t* __restric
   }
 }
 
+// Coarse lattices (R <= 64 rows, <= 32 faces: the triangles and edges of a high-dimensional run - a million of them at
+// cfg 4): a block per simplex is a million 36-row blocks whose dispatch alone took 1.8 ms.  Here a WAVE takes a simplex
+// (lane = row, one coalesced load), the faces' row lists are turned into one membership word per row once per block,
+// and every face is one masked wave maximum.
+__global__ __launch_bounds__(256) void face_max_small_kernel(const uint32_t* __restrict__ d2, int64_t n_simplices, int R,
+                                                             const int32_t* __restrict__ face_ptr,
+                                                             const int32_t* __restrict__ face_rows, int n_faces,
+                                                             float* __restrict__ out_face, float* __restrict__ out_dist) {
+  __shared__ uint32_t s_memb[64];
+  if (threadIdx.x < 64) s_memb[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int f = 0; f < n_faces; ++f)
+    for (int q = face_ptr[f] + threadIdx.x; q < face_ptr[f + 1]; q += blockDim.x) atomicOr(&s_memb[face_rows[q]], 1u << f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t mine = lane < R ? s_memb[lane] : 0u;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_simplices; s += waves) {
+    const uint32_t v = lane < R ? d2[s * (int64_t)R + lane] : 0u;
+    if (out_dist && lane < R) out_dist[s * (int64_t)R + lane] = __builtin_sqrtf(__uint_as_float(v));
+    float mine_f = 0.f;
+    for (int f = 0; f < n_faces; ++f) {   // (d2 bits of non-negative floats order like the floats)
+      const uint32_t m = wave_max_u32(((mine >> f) & 1u) ? v : 0u);
+      if (lane == f) mine_f = __builtin_sqrtf(__uint_as_float(m));
+    }
+    if (lane < n_faces) out_face[s * (int64_t)n_faces + lane] = mine_f;
+  }
+}
+
 __global__ void fill_u32_kernel(uint32_t* __restrict__ buf, int64_t n, uint32_t value) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = value;
@@ -723,6 +752,14 @@ int flooder_set_option(const char* name, int value) {
     g_cell_drop = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "sorted_batch_pct") == 0 && value >= 100) {
+    g_sorted_batch_pct = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "sorted_blocks") == 0 && value >= 0) {
+    g_sorted_blocks = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "sorted_refresh") == 0 && value >= 1) {
     g_sorted_refresh = value;
     return FLOODER_OK;
@@ -863,6 +900,13 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
   if (!d2 || !face_ptr || !face_rows || !out_face || n_faces < 1 || R < 1)
     return fail(FLOODER_E_ARG, "flooder_face_max_f32: bad argument");
   if (n_simplices > 0x7fffffff) return fail(FLOODER_E_ARG, "flooder_face_max_f32: too many simplices");
+  if (R <= 64 && n_faces <= 32) {
+    int64_t blocks = (n_simplices + 3) / 4;
+    if (blocks > 8 * 256) blocks = 8 * 256;
+    hipLaunchKernelGGL(face_max_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d2, n_simplices, R,
+                       face_ptr, face_rows, n_faces, out_face, out_dist);
+    return check_launch("face_max");
+  }
   hipLaunchKernelGGL(face_max_kernel, dim3((unsigned)n_simplices), dim3(256), 0, (hipStream_t)stream,
                      d2, R, face_ptr, face_rows, n_faces, out_face, out_dist);
   return check_launch("face_max");

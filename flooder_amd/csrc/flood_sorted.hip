@@ -20,11 +20,47 @@
 
 using namespace flooder;
 
-namespace flooder { int g_sorted_ks = 1; int g_sorted_refresh = 4; }  // samples per lane of the sorted sweep (option "sorted_ks": 1 or 2)
+namespace flooder { int g_sorted_ks = 1; int g_sorted_refresh = 4; int g_sorted_blocks = 0; int g_sorted_batch_pct = 400; }  // samples per lane of the sorted sweep (option "sorted_ks": 1 or 2)
 
 namespace {
 
 constexpr float SAFE = 0.99999f;
+
+// SUB-TILES.  The tile's bounding box against a leaf box is a weak test in 6D (the gaps of six axes add up, and the box of
+// 64 samples is as wide as a leaf): three of four leaves that pass it fail the per-sample test that follows, and that
+// test - the leaf's box broadcast from its lane, every sample against it, a ballot - is a serial chain that took 45 % of
+// the kernel's cycles.  The tile is therefore cut into NSUB runs of 64 / NSUB consecutive lanes (consecutive samples of
+// the sorted order: each run is a tighter box), every leaf lane keeps its NSUB lower bounds, and a leaf stays a
+// candidate only while one of them is below the largest running minimum OF THAT RUN (four DPP steps after every
+// evaluated leaf).  Only bounds: what a tile evaluates shrinks, the minima do not change.
+#ifndef FLOODER_SORTED_NSUB
+#define FLOODER_SORTED_NSUB 4
+#endif
+constexpr int NSUB = FLOODER_SORTED_NSUB;   // 1 (off), 4, 8 or 16
+// the transposed refine (below) paid while every leaf test began with a wave-wide minimum; with batched tests it is a
+// loss at every threshold (cfg 4: 47.7 ms without, 49.7 / 51.5 / 59.6 ms at 200 / 100 / 50 %): compiled out
+#ifndef FLOODER_SORTED_REFINE
+#define FLOODER_SORTED_REFINE 0
+#endif
+constexpr bool SORTED_REFINE = FLOODER_SORTED_REFINE != 0;
+constexpr int SUBSZ = 64 / NSUB;
+static_assert(NSUB == 1 || NSUB == 4 || NSUB == 8 || NSUB == 16, "sub-tiles of 64, 16, 8 or 4 lanes");
+
+// all-reduce inside runs of SUBSZ lanes (aligned): every lane ends up with its run's value
+template <bool MAX>
+__device__ __forceinline__ float sub_reduce(float x) {
+  auto op = [](float a, float b) { return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
+  x = op(x, dpp_move<0xB1, 0xF>(x));                            // quad_perm [1,0,3,2]
+  x = op(x, dpp_move<0x4E, 0xF>(x));                            // quad_perm [2,3,0,1]
+  if constexpr (SUBSZ >= 8) x = op(x, dpp_move<0x141, 0xF>(x));  // row_half_mirror
+  if constexpr (SUBSZ >= 16) x = op(x, dpp_move<0x140, 0xF>(x)); // row_mirror
+  if constexpr (SUBSZ == 64) {
+    x = op(x, dpp_move<0x142, 0xA>(x));
+    x = op(x, dpp_move<0x143, 0xC>(x));
+    x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+  }
+  return x;
+}
 
 template <int DIM>
 __global__ __launch_bounds__(256) void sample_keys_kernel(const float* __restrict__ verts,
@@ -125,27 +161,43 @@ struct SortedFaces {
   }
 };
 
+// 7 waves per SIMD for the default instantiation: left alone the compiler takes all 106 scalar registers, which holds
+// the kernel at 6 (MI355X_MICROARCH.md: 800 per SIMD in blocks of 16); at 94 it spills 12 more of them and is 2 % faster
+// (cfg 4: 46.9 -> 46.0 ms; 8 waves = 78 registers, 64 spilled: 47.8 ms)
+#ifndef FLOODER_SORTED_MIN_WAVES
+#define FLOODER_SORTED_MIN_WAVES 7
+#endif
 template <int DIM, int KS, bool FUSED>
-__global__ __launch_bounds__(256) void sweep_sorted_kernel(
+__global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORTED_MIN_WAVES : 1) void sweep_sorted_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_samples, const uint32_t* __restrict__ order, int32_t* __restrict__ queue,
-    uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct, SortedFaces sf) {
+    uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct, float batch_scale,
+    SortedFaces sf) {
   // KS samples per lane: a tile is 64 * KS consecutive samples of the sorted order (lane l holds l, l + 64, ...)
   constexpr int DP = padded_dim(DIM);
   constexpr int TILE = 64 * KS;
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
+  __shared__ float s_sub[4][NSUB][2 * FLOODER_MAX_DIM];   // boxes of the tile's sub-tiles (lo[8], hi[8])
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int64_t n_tiles = (n_samples + TILE - 1) / TILE;
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
 
+#ifdef FLOODER_SORTED_TIMERS
+  // diagnostic build: cycles per phase (s_memtime), summed over the waves into stats[4..9], refine passes in stats[10]
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime(), n_refine = 0;
+#define SPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts[i] += t_ - ts_prev; ts_prev = t_; } while (0)
+#else
+#define SPHASE(i) do { } while (0)
+#endif
   int q_shard = (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;
   for (;;) {
     const int64_t g = queue_pop(queue, q_shard, q_tried, n_tiles, lane);  // sharded heads (flood_common.hpp)
     if (g < 0) break;
+    SPHASE(0);
     const unsigned long long tests_before = n_leaf_test + n_node_test;
     // ---- this lane's samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
     float p[KS][DIM], best[KS];
@@ -208,8 +260,30 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       }
       tlo[k] = wave_min_f32(mn);
       thi[k] = wave_max_f32(mx);
+      if constexpr (NSUB > 1) {
+        const float smn = sub_reduce<false>(mn), smx = sub_reduce<true>(mx);
+        if ((lane & (SUBSZ - 1)) == 0) {
+          s_sub[wv][lane / SUBSZ][k] = smn;
+          s_sub[wv][lane / SUBSZ][FLOODER_MAX_DIM + k] = smx;
+        }
+      }
     }
+    __builtin_amdgcn_wave_barrier();
     float M = __builtin_inff();  // largest running minimum of the tile (wave-uniform)
+    float Mq[NSUB], lbq[NSUB];   // ... of every sub-tile (wave-uniform); this lane's leaf against the sub-tiles' boxes
+#pragma unroll
+    for (int q = 0; q < NSUB; ++q) { Mq[q] = __builtin_inff(); lbq[q] = __builtin_inff(); }
+    // is this lane's leaf of the current group still worth a look?
+    auto leaf_cand = [&](float lb_tile) -> bool {
+      if constexpr (NSUB == 1) {
+        return lb_tile * SAFE < M;
+      } else {
+        bool c = false;
+#pragma unroll
+        for (int q = 0; q < NSUB; ++q) c = c || (lbq[q] * SAFE < Mq[q]);
+        return c;
+      }
+    };
 
     float c_lo[DIM], c_hi[DIM];
     auto child_bounds = [&](int lvl, int64_t grp) -> float {
@@ -234,8 +308,31 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       return lb;
     };
 
+    // this lane's leaf box (c_lo, c_hi) against every sub-tile's box; the smallest of them is the leaf's place in the
+    // nearest-first order (a lower bound for every sample, tighter than the tile's)
+    auto sub_bounds = [&]() -> float {
+      float nearest = __builtin_inff();
+#pragma unroll
+      for (int q = 0; q < NSUB; ++q) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float gap = __builtin_fmaxf(__builtin_fmaxf(c_lo[k] - s_sub[wv][q][FLOODER_MAX_DIM + k],
+                                                            s_sub[wv][q][k] - c_hi[k]), 0.f);
+          a = __builtin_fmaf(gap, gap, a);
+        }
+        lbq[q] = a;
+        nearest = __builtin_fminf(nearest, a);
+      }
+      return nearest;
+    };
+    SPHASE(1);
     int lvl = top;
+    unsigned long long batch = 0ull;   // leaves of the current group taken out of lb0 and waiting for their test
     float lb0 = child_bounds(top, 0);
+    if constexpr (NSUB > 1) {
+      if (top == 0) lb0 = sub_bounds();
+    }
     int64_t grp0 = 0;
     ++n_node_test;
     if (top > 0) {
@@ -264,13 +361,15 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
         } else {
           lb0 = lb;
           grp0 = c;
+          if constexpr (NSUB > 1) lb0 = sub_bounds();
           // ---- transposed refine: the 64 leaf boxes of the group (one per lane) against every sample of the tile
           // (one lane's samples broadcast at a time); a leaf no sample can improve on is dropped here, in 1/64 of a
           // per-leaf test, before the nearest-first loop pops it.  Worth it when the per-leaf tests it replaces
           // cost more than one pass over the tile's samples.
-          const bool cand = lb * SAFE < M;
+          SPHASE(2);
           constexpr int PER_LEAF = KS * 4 * DIM + 40, PER_GROUP = 64 * KS * (4 * DIM + 3);
-          if ((int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 > (int64_t)PER_GROUP * refine_pct) {
+          const bool cand = SORTED_REFINE ? leaf_cand(lb) : false;
+          if (SORTED_REFINE && (int64_t)__popcll(__ballot(cand)) * PER_LEAF * 100 > (int64_t)PER_GROUP * refine_pct) {
             bool need = false;
 #pragma unroll 2
             for (int src = 0; src < 64; ++src) {
@@ -288,18 +387,34 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
               }
             }
             if (!(cand && need)) lb0 = __builtin_inff();
+#ifdef FLOODER_SORTED_TIMERS
+            ++n_refine;
+#endif
+            SPHASE(3);
           }
         }
+        SPHASE(2);
         continue;
       }
-      // ---- leaf level: nearest unvisited leaf of the current group
-      const float mn = wave_min_f32(lb0);
-      if (!(mn * SAFE < M)) {
-        if (++lvl > top) break;
-        continue;
+      // ---- leaf level: the nearest unvisited leaves of the current group that are still candidates.  Finding THE
+      // nearest costs a wave-wide minimum (six dependent DPP steps) per leaf; one minimum opens a BATCH instead - every
+      // candidate whose bound is within batch_pct % of the nearest one - and the batch is worked off in lane order with
+      // scalar bit operations only.  After an evaluation the batch loses the leaves that have stopped being candidates.
+      if (batch == 0ull) {
+        if constexpr (NSUB > 1) {
+          if (!leaf_cand(lb0)) lb0 = __builtin_inff();   // (for good: the sub-tiles' maxima only fall)
+        }
+        const float mn = wave_min_f32(lb0);
+        if (!(mn * SAFE < M)) {
+          if (++lvl > top) break;
+          continue;
+        }
+        const bool in_batch = lb0 <= mn * batch_scale;
+        batch = __ballot(in_batch);
+        if (in_batch) lb0 = __builtin_inff();  // visited
       }
-      const int j = __builtin_ctzll(__ballot(lb0 == mn));
-      if (lane == j) lb0 = __builtin_inff();  // visited
+      const int j = __builtin_ctzll(batch);
+      batch &= batch - 1ull;
       const int64_t c = grp0 * FAN + j;
       ++n_leaf_test;
       // can any sample of any lane still improve against leaf c?  (its box comes from lane j)
@@ -320,6 +435,7 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
         }
         need = need || (alive[i] && lbp * SAFE < best[i]);
       }
+      SPHASE(4);
       if (__ballot(need) == 0ull) continue;
       ++n_leaf_eval;
       const float* cp = pts + c * (int64_t)LEAF * DP;
@@ -363,7 +479,19 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
       float bm = -1.f;
 #pragma unroll
       for (int i = 0; i < KS; ++i) bm = __builtin_fmaxf(bm, alive[i] ? best[i] : -1.f);
-      M = wave_max_f32(bm);   // (nobody left alive: M = -1, every remaining bound test fails, the walk unwinds)
+      if constexpr (NSUB > 1) {
+        const float sm = sub_reduce<true>(bm);
+        M = -1.f;
+#pragma unroll
+        for (int q = 0; q < NSUB; ++q) {
+          Mq[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), q * SUBSZ));
+          M = __builtin_fmaxf(M, Mq[q]);
+        }
+        if (batch != 0ull) batch &= __ballot(leaf_cand(0.f));
+      } else {
+        M = wave_max_f32(bm);   // (nobody left alive: M = -1, every remaining bound test fails, the walk unwinds)
+      }
+      SPHASE(5);
     }
     if constexpr (FUSED) {
       // the samples still alive are exact: deliver (only where the value can raise the maximum last seen or read now)
@@ -394,8 +522,13 @@ __global__ __launch_bounds__(256) void sweep_sorted_kernel(
     atomicAdd(&stats[0], n_leaf_eval);
     atomicAdd(&stats[1], n_leaf_test);
     atomicAdd(&stats[2], n_node_test);
+#ifdef FLOODER_SORTED_TIMERS
+    for (int i = 0; i < 6; ++i) atomicAdd(&stats[4 + i], ts[i]);
+    atomicAdd(&stats[10], n_refine);
+#endif
   }
 }
+#undef SPHASE
 
 template <int DIM>
 struct SampleKeysOp {
@@ -423,10 +556,12 @@ struct SweepSortedOp {
       blocks_per_cu = nb > 8 ? 8 : nb;
     }
     const int64_t n_tiles = (n_samples + 64 * KS - 1) / (64 * KS);
-    int64_t grid = (int64_t)blocks_per_cu * 256;
+    // (option "sorted_blocks": fewer resident blocks per CU than fit - a diagnostic for how much of the kernel is latency)
+    int64_t grid = (int64_t)(g_sorted_blocks > 0 && g_sorted_blocks < blocks_per_cu ? g_sorted_blocks : blocks_per_cu) * 256;
     if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
     hipLaunchKernelGGL((sweep_sorted_kernel<DIM, KS, FUSED>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts,
-                       weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct, sf);
+                       weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct,
+                       (float)(g_sorted_batch_pct < 100 ? 100 : g_sorted_batch_pct) * 0.01f, sf);
     return check_launch("sweep_sorted");
   }
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,

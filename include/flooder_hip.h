@@ -182,6 +182,17 @@ int64_t flooder_index_sort_bytes(int64_t n_pts);
 int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
                        void* tmp, int64_t tmp_bytes, void* stream);
 
+/* Order of a balanced k-d tree over the cloud (default of the point index above 3 dimensions; core.KD_ORDER_ABOVE_DIM):
+ * order[j] = index of the point at row j, such that every ALIGNED group of 16 * 2^i rows - the leaves and inner nodes
+ * of the implicit box tree - is a cell of the tree (each level splits every group along the widest axis of its box at
+ * the positional median).  One (segmented box, key, radix sort) round per level; no curve codes.  In 6D the boxes of
+ * the 1024-point nodes overlap 3x less than those of a Hilbert order and the sorted sweep tests and evaluates fewer
+ * leaves.  Any order is a valid index: results do not depend on it.  tmp: flooder_kd_order_bytes(n_pts) bytes of device
+ * scratch (-1: too many points, n_pts <= 2^31 - 1).  Replaces torch.argsort of core.py:143 like flooder_index_sort. */
+int64_t flooder_kd_order_bytes(int64_t n_pts);
+int flooder_kd_order_f32(const float* pts, int64_t n_pts, int dim, int ld, int32_t* order, void* tmp, int64_t tmp_bytes,
+                         void* stream);
+
 /* Sub-cloud of a block of simplices (block-sharded runs): the rows of pts (n_pts x dim floats, row stride ld) that lie
  * inside the box (box: 2 * dim device floats, lo then hi, bounds inclusive) AND - dim 2 / 3, with cell_flags
  * (flooder_select_grid_bytes(dim) zeroed bytes), cloud_box (the 16 floats of flooder_bbox_f32) and n_balls bounding

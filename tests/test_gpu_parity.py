@@ -137,6 +137,61 @@ def test_sorted_sample_sweep_is_bit_identical(name, dev, monkeypatch):
     assert_close_filtration(dict_values(res[True], keys), z["filtration_f32"], z["points"], name)
 
 
+@pytest.mark.parametrize("n,dim", [(17, 6), (1000, 8), (1025, 4), (5000, 4), (70_001, 5), (300_000, 6)])
+def test_kd_order_is_a_permutation_whose_aligned_groups_are_tree_cells(n, dim, dev, monkeypatch):
+    """Point index above 3D (csrc/flood_index.hip, kd_order): the rows are a permutation of the cloud, and every
+    aligned group of 16 * 2^j rows splits into its two halves along ONE axis - exactly where kd_local_kernel sorts
+    exact coordinates (groups of up to 1024 rows), within 2^-8 of the group's extent where a radix sort of quantised
+    coordinates does (above)."""
+    g = torch.Generator().manual_seed(n + dim)
+    pts = torch.randn(n, dim, generator=g).to(dev)
+    monkeypatch.setattr(core, "KD_ORDER_ABOVE_DIM", 3)
+    idx = core.PointIndex(pts)
+    assert idx.kd
+    o = idx.order32.long().cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(n))
+    rows = idx.pts[:n, :dim].cpu().numpy()
+    assert np.array_equal(rows, pts.cpu().numpy()[o])
+    assert bool(torch.isinf(idx.pts[n:]).all())
+    size = 32
+    while size // 2 < n:
+        slack = 0.0 if size <= 1024 else 2.0 ** -8
+        for a in range(0, n, size):
+            left, right = rows[a:a + size // 2], rows[a + size // 2:a + size]
+            if len(right) == 0:
+                continue
+            grp = rows[a:a + size]
+            ext = grp.max(0) - grp.min(0)
+            gap = right.min(0) - left.max(0) + slack * ext * 1.01   # >= 0 along the split axis
+            assert (gap >= 0).any(), (size, a, gap)
+        size *= 2
+        if size > 8192 and n > 100_000:   # (the upper levels of the large cloud: a few groups each)
+            size *= 4
+
+
+@pytest.mark.parametrize("dim,kw", [(6, dict(max_dimension=2, points_per_edge=6)), (4, dict(max_dimension=3, points_per_edge=4)),
+                                    (5, dict(max_dimension=2, num_rand=40))])
+def test_kd_order_and_curve_order_give_the_same_filtration(dim, kw, dev, monkeypatch):
+    """Any order of the rows is a valid index (the boxes are taken from the rows): k-d order and Hilbert order, sorted
+    sweep and per-simplex tree sweep, bit for bit - and the landmark selection picks the same indices on either."""
+    rng = np.random.default_rng(dim)
+    P = rng.normal(size=(60_000, dim)).astype(np.float32)
+    tp = torch.as_tensor(P, device=dev)
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    out, lms = {}, {}
+    for above in (3, 8):
+        monkeypatch.setattr(core, "KD_ORDER_ABOVE_DIM", above)
+        lm = fa.generate_landmarks(tp, 28, start_idx=0)
+        lms[above] = lm.cpu().numpy()
+        for srt in (True, False):
+            monkeypatch.setattr(core, "BVH_SORTED_SAMPLES", srt)
+            torch.manual_seed(3)
+            out[above, srt] = fa.flood_complex(tp, lm, method="bvh", **kw)
+    assert np.array_equal(lms[3], lms[8])
+    assert np.array_equal(lms[3], P[fo.exact_fps(P, 28, 0)])
+    assert out[3, True] == out[8, True] == out[3, False] == out[8, False]
+
+
 @pytest.mark.parametrize("refresh", [1, 4, 1000])
 def test_fused_sorted_sweep_equals_unfused(refresh, dev, monkeypatch):
     """The sorted sweep that delivers the face maxima itself and drops every sample that cannot raise one (default
