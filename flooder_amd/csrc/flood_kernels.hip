@@ -357,31 +357,42 @@ __global__ __launch_bounds__(256) void face_max_kernel(const uint32_t* __restric
 }
 
 // Coarse lattices (R <= 64 rows, <= 32 faces: the triangles and edges of a high-dimensional run - a million of them at
-// cfg 4): a block per simplex is a million 36-row blocks whose dispatch alone took 1.8 ms.  Here a WAVE takes a simplex
-// (lane = row, one coalesced load), the faces' row lists are turned into one membership word per row once per block,
-// and every face is one masked wave maximum.
+// cfg 4): a block per simplex is a million 36-row blocks whose dispatch alone took 1.8 ms, and a wave reduction per face
+// is 250 instructions per simplex (0.46 ms).  Here a wave takes U = 64 / F simplices per step (F = the number of faces
+// rounded up to a power of two): their rows go through LDS (one coalesced load each), and lane (u, f) runs through the
+// row list of face f of simplex u.
 __global__ __launch_bounds__(256) void face_max_small_kernel(const uint32_t* __restrict__ d2, int64_t n_simplices, int R,
                                                              const int32_t* __restrict__ face_ptr,
-                                                             const int32_t* __restrict__ face_rows, int n_faces,
+                                                             const int32_t* __restrict__ face_rows, int n_faces, int lgF,
                                                              float* __restrict__ out_face, float* __restrict__ out_dist) {
-  __shared__ uint32_t s_memb[64];
-  if (threadIdx.x < 64) s_memb[threadIdx.x] = 0u;
+  __shared__ uint32_t s_v[4][32][64];       // [wave][simplex of the step][row]
+  __shared__ uint8_t s_rows[32 * 64];       // the faces' row lists (every face lists at most R <= 64 rows)
+  __shared__ int s_ptr[33];
+  for (int f = threadIdx.x; f <= n_faces; f += blockDim.x) s_ptr[f] = face_ptr[f];
   __syncthreads();
-  for (int f = 0; f < n_faces; ++f)
-    for (int q = face_ptr[f] + threadIdx.x; q < face_ptr[f + 1]; q += blockDim.x) atomicOr(&s_memb[face_rows[q]], 1u << f);
+  const int n_rows = s_ptr[n_faces] < 32 * 64 ? s_ptr[n_faces] : 32 * 64;
+  for (int q = threadIdx.x; q < n_rows; q += blockDim.x) s_rows[q] = (uint8_t)face_rows[q];
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const uint32_t mine = lane < R ? s_memb[lane] : 0u;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int U = 64 >> lgF, f = lane & ((1 << lgF) - 1), u_mine = lane >> lgF;
+  const int qb = f < n_faces ? s_ptr[f] : 0, qe = f < n_faces ? s_ptr[f + 1] : 0;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_simplices; s += waves) {
-    const uint32_t v = lane < R ? d2[s * (int64_t)R + lane] : 0u;
-    if (out_dist && lane < R) out_dist[s * (int64_t)R + lane] = __builtin_sqrtf(__uint_as_float(v));
-    float mine_f = 0.f;
-    for (int f = 0; f < n_faces; ++f) {   // (d2 bits of non-negative floats order like the floats)
-      const uint32_t m = wave_max_u32(((mine >> f) & 1u) ? v : 0u);
-      if (lane == f) mine_f = __builtin_sqrtf(__uint_as_float(m));
+  for (int64_t s0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * U; s0 < n_simplices; s0 += waves * U) {
+    for (int u = 0; u < U; ++u) {   // (wave-uniform trip count)
+      const int64_t s = s0 + u;
+      const uint32_t v = (lane < R && s < n_simplices) ? d2[s * (int64_t)R + lane] : 0u;
+      s_v[wv][u][lane] = v;
+      if (out_dist && lane < R && s < n_simplices) out_dist[s * (int64_t)R + lane] = __builtin_sqrtf(__uint_as_float(v));
     }
-    if (lane < n_faces) out_face[s * (int64_t)n_faces + lane] = mine_f;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t m = 0u;   // (d2 bits of non-negative floats order like the floats)
+    for (int q = qb; q < qe; ++q) {
+      const uint32_t t = s_v[wv][u_mine][s_rows[q]];
+      m = t > m ? t : m;
+    }
+    const int64_t s = s0 + u_mine;
+    if (f < n_faces && s < n_simplices) out_face[s * (int64_t)n_faces + f] = __builtin_sqrtf(__uint_as_float(m));
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -901,10 +912,13 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
     return fail(FLOODER_E_ARG, "flooder_face_max_f32: bad argument");
   if (n_simplices > 0x7fffffff) return fail(FLOODER_E_ARG, "flooder_face_max_f32: too many simplices");
   if (R <= 64 && n_faces <= 32) {
-    int64_t blocks = (n_simplices + 3) / 4;
-    if (blocks > 8 * 256) blocks = 8 * 256;
+    int lgF = 1;   // (at most 32 simplices per step: the LDS rows of a wave)
+    while ((1 << lgF) < n_faces) ++lgF;
+    const int per_block = 4 * (64 >> lgF);
+    int64_t blocks = (n_simplices + per_block - 1) / per_block;
+    if (blocks > 6 * 256) blocks = 6 * 256;
     hipLaunchKernelGGL(face_max_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d2, n_simplices, R,
-                       face_ptr, face_rows, n_faces, out_face, out_dist);
+                       face_ptr, face_rows, n_faces, lgF, out_face, out_dist);
     return check_launch("face_max");
   }
   hipLaunchKernelGGL(face_max_kernel, dim3((unsigned)n_simplices), dim3(256), 0, (hipStream_t)stream,

@@ -39,6 +39,11 @@ constexpr float SAFE = 0.99999f;
 constexpr int NSUB = FLOODER_SORTED_NSUB;   // 1 (off), 4, 8 or 16
 // the transposed refine (below) paid while every leaf test began with a wave-wide minimum; with batched tests it is a
 // loss at every threshold (cfg 4: 47.7 ms without, 49.7 / 51.5 / 59.6 ms at 200 / 100 / 50 %): compiled out
+// the box of the leaf under test: 1 = read from LDS (written once per group), 0 = twelve v_readlane from its lane
+#ifndef FLOODER_SORTED_LDSBOX
+#define FLOODER_SORTED_LDSBOX 1
+#endif
+static_assert(!FLOODER_SORTED_LDSBOX || FLOODER_SORTED_NSUB > 1, "the leaf boxes are published by sub_bounds()");
 #ifndef FLOODER_SORTED_REFINE
 #define FLOODER_SORTED_REFINE 0
 #endif
@@ -180,6 +185,9 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
   __shared__ float s_lb[4][MAXL][FAN];
   __shared__ int64_t s_grp[4][MAXL];
   __shared__ float s_sub[4][NSUB][2 * FLOODER_MAX_DIM];   // boxes of the tile's sub-tiles (lo[8], hi[8])
+#if FLOODER_SORTED_LDSBOX
+  __shared__ float s_box[4][FAN][2 * DIM];                // boxes of the current group's leaves (a test reads one)
+#endif
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int64_t n_tiles = (n_samples + TILE - 1) / TILE;
@@ -311,6 +319,13 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
     // this lane's leaf box (c_lo, c_hi) against every sub-tile's box; the smallest of them is the leaf's place in the
     // nearest-first order (a lower bound for every sample, tighter than the tile's)
     auto sub_bounds = [&]() -> float {
+#if FLOODER_SORTED_LDSBOX
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {   // the group's leaf boxes, for the per-leaf tests
+        s_box[wv][lane][k] = c_lo[k];
+        s_box[wv][lane][DIM + k] = c_hi[k];
+      }
+#endif
       float nearest = __builtin_inff();
 #pragma unroll
       for (int q = 0; q < NSUB; ++q) {
@@ -419,11 +434,19 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
       ++n_leaf_test;
       // can any sample of any lane still improve against leaf c?  (its box comes from lane j)
       float blo[DIM], bhi[DIM];
+#if FLOODER_SORTED_LDSBOX
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {   // (wave-uniform address: broadcast reads)
+        blo[k] = s_box[wv][j][k];
+        bhi[k] = s_box[wv][j][DIM + k];
+      }
+#else
 #pragma unroll
       for (int k = 0; k < DIM; ++k) {
         blo[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_lo[k]), j));
         bhi[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_hi[k]), j));
       }
+#endif
       bool need = false;
 #pragma unroll
       for (int i = 0; i < KS; ++i) {
