@@ -638,15 +638,21 @@ def main():
             "flop_per_pair": flop_per_pair, "pairs": dom_rec["pairs_evaluated"],
             "avg_launch_ms": dom_rec["ms_per_step"], "avg_launch_ms_rocprof": None if prof_us is None else round(prof_us / 1e3, 4),
             "issue_util": issue_util,
-            "limiter": "fp32 VALU issue + dependent-latency chains (LDS round trips, tree-node loads) at 3 waves per "
-                       "SIMD (cell sweep) / 4 (witness sweep); HBM traffic is a few percent of peak",
+            "limiter": ("fp32 VALU issue (62 % busy by SQ_INSTS_VALU x 2 cycles at the 2.14 GHz the counters imply) + the "
+                        "walk: 350 leaf tests and 60 node expansions per 90 evaluated leaves of a 64-sample tile in 6D, "
+                        "7 waves per SIMD; the leaf rows come from the Infinity Cache (the cloud fits)"
+                        if args.method == "bvh" else
+                        "fp32 VALU issue + dependent-latency chains (LDS round trips, tree-node loads) at 3 waves per "
+                        "SIMD (cell sweep) / 4 (witness sweep); HBM traffic is a few percent of peak"),
             "samples_resolved": int(S) * int(R),
             "samples_per_ns": round(int(S) * int(R) / (dom_rec["ms_per_step"] * 1e6), 3),
-            "note": "achieved counts EVALUATED pairs only.  Since round 4 most samples of a sparse simplex are never "
-                    "evaluated against the cloud: four witness distances bound them and the bound cannot raise a face "
-                    "maximum (witness sweep).  Fewer pairs in less time: the fraction of the vector peak says how busy "
-                    "the ALUs are, samples_per_ns (all S x R samples of the step / the kernel's time) how fast the "
-                    "answer is produced",
+            "note": ("achieved counts EVALUATED pairs only (exact nearest-neighbour culling by the box tree)"
+                     if args.method == "bvh" else
+                     "achieved counts EVALUATED pairs only.  Since round 4 most samples of a sparse simplex are never "
+                     "evaluated against the cloud: four witness distances bound them and the bound cannot raise a face "
+                     "maximum (witness sweep).  Fewer pairs in less time: the fraction of the vector peak says how busy "
+                     "the ALUs are, samples_per_ns (all S x R samples of the step / the kernel's time) how fast the "
+                     "answer is produced"),
             "hbm": {"bound": "hbm", "achieved": dom_rec["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom_rec["hbm_frac"], "algorithmic_bytes": dom_bytes,
                     "traffic_frac_of_algorithmic": None if not traffic else round(traffic / max(dom_bytes, 1), 4),
