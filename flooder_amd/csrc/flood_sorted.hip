@@ -44,6 +44,11 @@ constexpr int NSUB = FLOODER_SORTED_NSUB;   // 1 (off), 4, 8 or 16
 #define FLOODER_SORTED_LDSBOX 1
 #endif
 static_assert(!FLOODER_SORTED_LDSBOX || FLOODER_SORTED_NSUB > 1, "the leaf boxes are published by sub_bounds()");
+// sub-tile bounds also for the parents of the leaf groups (1) or for leaves only (0)
+#ifndef FLOODER_SORTED_NODE_SUB
+#define FLOODER_SORTED_NODE_SUB 1
+#endif
+constexpr bool SORTED_NODE_SUB = FLOODER_SORTED_NODE_SUB != 0;
 #ifndef FLOODER_SORTED_REFINE
 #define FLOODER_SORTED_REFINE 0
 #endif
@@ -197,6 +202,8 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 #ifdef FLOODER_SORTED_TIMERS
   // diagnostic build: cycles per phase (s_memtime), summed over the waves into stats[4..9], refine passes in stats[10]
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime(), n_refine = 0;
+  unsigned long long n_groups = 0, n_groups_empty = 0, n_groups_idle = 0;
+  int evals_in_group = 0;
 #define SPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts[i] += t_ - ts_prev; ts_prev = t_; } while (0)
 #else
 #define SPHASE(i) do { } while (0)
@@ -318,14 +325,7 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 
     // this lane's leaf box (c_lo, c_hi) against every sub-tile's box; the smallest of them is the leaf's place in the
     // nearest-first order (a lower bound for every sample, tighter than the tile's)
-    auto sub_bounds = [&]() -> float {
-#if FLOODER_SORTED_LDSBOX
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) {   // the group's leaf boxes, for the per-leaf tests
-        s_box[wv][lane][k] = c_lo[k];
-        s_box[wv][lane][DIM + k] = c_hi[k];
-      }
-#endif
+    auto sub_bounds_of = [&](float (&dst)[NSUB]) -> float {
       float nearest = __builtin_inff();
 #pragma unroll
       for (int q = 0; q < NSUB; ++q) {
@@ -336,10 +336,43 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
                                                             s_sub[wv][q][k] - c_hi[k]), 0.f);
           a = __builtin_fmaf(gap, gap, a);
         }
-        lbq[q] = a;
+        dst[q] = a;
         nearest = __builtin_fminf(nearest, a);
       }
       return nearest;
+    };
+    auto sub_bounds = [&]() -> float {
+#if FLOODER_SORTED_LDSBOX
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) {   // the group's leaf boxes, for the per-leaf tests
+        s_box[wv][lane][k] = c_lo[k];
+        s_box[wv][lane][DIM + k] = c_hi[k];
+      }
+#endif
+      return sub_bounds_of(lbq);
+    };
+    // the same bounds for the nodes ONE level above the leaves (each the parent of a leaf group; one group of them is
+    // open at a time, so a register set does): 35 of the 56 leaf groups a cfg 4 tile used to open were left without
+    // a single evaluation - the tile's box reaches them, no run of 16 samples does
+    // (kept as halves rounded toward zero - still lower bounds - two to a register: four more live floats spill)
+    typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+    half2_t lbq1[(NSUB + 1) / 2];
+#pragma unroll
+    for (int q = 0; q < (NSUB + 1) / 2; ++q) lbq1[q] = half2_t{(__fp16)0.f, (__fp16)0.f};
+    auto node_bounds = [&]() -> float {
+      float tmp[NSUB];
+      const float nearest = sub_bounds_of(tmp);
+#pragma unroll
+      for (int q = 0; q + 1 < NSUB; q += 2) lbq1[q / 2] = __builtin_amdgcn_cvt_pkrtz(tmp[q], tmp[q + 1]);
+      return nearest;
+    };
+    auto node_cand = [&]() -> bool {
+      bool c = false;
+#pragma unroll
+      for (int q = 0; q + 1 < NSUB; q += 2) {
+        c = c || ((float)lbq1[q / 2][0] * SAFE < Mq[q]) || ((float)lbq1[q / 2][1] * SAFE < Mq[q + 1]);
+      }
+      return c;
     };
     SPHASE(1);
     int lvl = top;
@@ -351,12 +384,18 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
     int64_t grp0 = 0;
     ++n_node_test;
     if (top > 0) {
+      if constexpr (NSUB > 1 && SORTED_NODE_SUB) {
+        if (top == 1) lb0 = node_bounds();
+      }
       s_lb[wv][top][lane] = lb0;
       if (lane == 0) s_grp[wv][top] = 0;
     }
     for (;;) {
       if (lvl > 0) {
-        const float lbv = s_lb[wv][lvl][lane];
+        float lbv = s_lb[wv][lvl][lane];
+        if constexpr (NSUB > 1 && SORTED_NODE_SUB) {
+          if (lvl == 1 && !node_cand()) lbv = __builtin_inff();   // (for good: the sub-tiles' maxima only fall)
+        }
         const float mn = wave_min_f32(lbv);
         if (!(mn * SAFE < M)) {  // nothing left at this level can improve any sample of the tile
           if (++lvl > top) break;
@@ -371,12 +410,22 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
         const float lb = child_bounds(lvl, c);
         ++n_node_test;
         if (lvl > 0) {
-          s_lb[wv][lvl][lane] = lb;
+          float lbn = lb;
+          if constexpr (NSUB > 1 && SORTED_NODE_SUB) {
+            if (lvl == 1) lbn = node_bounds();
+          }
+          s_lb[wv][lvl][lane] = lbn;
           if (lane == 0) s_grp[wv][lvl] = c;
         } else {
           lb0 = lb;
           grp0 = c;
           if constexpr (NSUB > 1) lb0 = sub_bounds();
+#ifdef FLOODER_SORTED_TIMERS
+          ++n_groups;
+          if (__ballot(leaf_cand(lb0)) == 0ull) ++n_groups_empty;   // (no leaf of the group is a candidate on arrival)
+          if (evals_in_group == 0 && n_groups > 1) ++n_groups_idle;  // (the PREVIOUS group was left without an evaluation)
+          evals_in_group = 0;
+#endif
           // ---- transposed refine: the 64 leaf boxes of the group (one per lane) against every sample of the tile
           // (one lane's samples broadcast at a time); a leaf no sample can improve on is dropped here, in 1/64 of a
           // per-leaf test, before the nearest-first loop pops it.  Worth it when the per-leaf tests it replaces
@@ -461,6 +510,9 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
       SPHASE(4);
       if (__ballot(need) == 0ull) continue;
       ++n_leaf_eval;
+#ifdef FLOODER_SORTED_TIMERS
+      ++evals_in_group;
+#endif
       const float* cp = pts + c * (int64_t)LEAF * DP;
       // rows stream through SGPRs (scalar loads), UB at a time: 8 rows of 8 floats would need 64 SGPRs on top of the
       // traversal's own; 4 rows keep the spills away
@@ -548,6 +600,9 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 #ifdef FLOODER_SORTED_TIMERS
     for (int i = 0; i < 6; ++i) atomicAdd(&stats[4 + i], ts[i]);
     atomicAdd(&stats[10], n_refine);
+    atomicAdd(&stats[11], n_groups);
+    atomicAdd(&stats[12], n_groups_empty);
+    atomicAdd(&stats[13], n_groups_idle);
 #endif
   }
 }
