@@ -516,13 +516,14 @@ def main():
                 "max_tests_one_tile": sh[3], "samples_per_tile": per_tile, "lanes_per_tile": 64,
                 "tiles": f"{per_tile} consecutive samples of a Z-order of all (simplex, sample) pairs" if sorted_tiles
                          else "samples of one simplex"}
-        if sorted_tiles and any(sh[4:14]):   # library built with -DFLOODER_SORTED_TIMERS (diagnostic)
+        if sorted_tiles and any(sh[4:15]):   # library built with -DFLOODER_SORTED_TIMERS (diagnostic)
             tot = float(sum(sh[4:10])) or 1.0
             st_h["phase_cycle_share"] = {k: round(v / tot, 4) for k, v in zip(
                 ("pop+store", "samples", "node", "refine", "leaf_test", "leaf_eval"), sh[4:10])}
             st_h["refine_passes_per_tile"] = round(sh[10] / max(n_tiles, 1), 2)
             st_h["leaf_groups_per_tile"] = {"visited": round(sh[11] / max(n_tiles, 1), 2), "no candidate on arrival": round(sh[12] / max(n_tiles, 1), 2),
-                                            "left without an evaluation": round(sh[13] / max(n_tiles, 1), 2)}
+                                            "left without an evaluation": round(sh[13] / max(n_tiles, 1), 2),
+                                            "spared by the exact test of the parent's box": round(sh[14] / max(n_tiles, 1), 2)}
     elif args.method == "cell":
         sh = stats.cpu().tolist()
         tiles_total = S * ((R + 63) // 64)

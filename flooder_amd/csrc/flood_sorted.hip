@@ -44,11 +44,17 @@ constexpr int NSUB = FLOODER_SORTED_NSUB;   // 1 (off), 4, 8 or 16
 #define FLOODER_SORTED_LDSBOX 1
 #endif
 static_assert(!FLOODER_SORTED_LDSBOX || FLOODER_SORTED_NSUB > 1, "the leaf boxes are published by sub_bounds()");
-// sub-tile bounds also for the parents of the leaf groups (1) or for leaves only (0)
+// sub-tile bounds also for the parents of the leaf groups (1) or for leaves only (0): 41.3 -> 40.7 ms at cfg 4 on their
+// own, nothing beside the exact test of the parent's box (34.4 with, 34.3 without): off
 #ifndef FLOODER_SORTED_NODE_SUB
-#define FLOODER_SORTED_NODE_SUB 1
+#define FLOODER_SORTED_NODE_SUB 0
 #endif
 constexpr bool SORTED_NODE_SUB = FLOODER_SORTED_NODE_SUB != 0;
+// exact per-sample test of a leaf group's parent box before the group is opened (1) or not (0)
+#ifndef FLOODER_SORTED_NODE_EXACT
+#define FLOODER_SORTED_NODE_EXACT 1
+#endif
+constexpr bool SORTED_NODE_EXACT = FLOODER_SORTED_NODE_EXACT != 0;
 #ifndef FLOODER_SORTED_REFINE
 #define FLOODER_SORTED_REFINE 0
 #endif
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
   const int wv = threadIdx.x >> 6;
   const int64_t n_tiles = (n_samples + TILE - 1) / TILE;
   const int top = lv.n_levels - 1;
-  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0;
+  unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0, n_node_spared = 0;
 
 #ifdef FLOODER_SORTED_TIMERS
   // diagnostic build: cycles per phase (s_memtime), summed over the waves into stats[4..9], refine passes in stats[10]
@@ -407,6 +413,31 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
         // leaf address below is wave-uniform and loads the 16 rows of a leaf into VGPRs instead of SGPRs)
         const int64_t c = wave_uniform64(s_grp[wv][lvl]) * FAN + j;
         --lvl;
+        if constexpr (SORTED_NODE_EXACT) {
+          // the parent of a leaf group, before the group is opened: its box (two scalar loads) against every sample.
+          // 28 of the 49 groups a cfg 4 tile opened were left without an evaluation; this test spares 21 of them the
+          // 64 box loads, the sub-tile bounds and the leaf tests that all fail
+          if (lvl == 0) {
+            const float* nb = nodes + (lv.off[1] + c) * 2 * DP;
+            const typename RowVec<DP>::type nlo = load_uniform_row<DP>(nb), nhi = load_uniform_row<DP>(nb + DP);
+            bool nd = false;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+              float lbp = 0.f;
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) {
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(nlo[k] - p[i][k], p[i][k] - nhi[k]), 0.f);
+                lbp = __builtin_fmaf(gap, gap, lbp);
+              }
+              nd = nd || (alive[i] && lbp * SAFE < best[i]);
+            }
+            if (__ballot(nd) == 0ull) {
+              lvl = 1;
+              ++n_node_spared;
+              continue;
+            }
+          }
+        }
         const float lb = child_bounds(lvl, c);
         ++n_node_test;
         if (lvl > 0) {
@@ -603,6 +634,7 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
     atomicAdd(&stats[11], n_groups);
     atomicAdd(&stats[12], n_groups_empty);
     atomicAdd(&stats[13], n_groups_idle);
+    atomicAdd(&stats[14], n_node_spared);
 #endif
   }
 }
