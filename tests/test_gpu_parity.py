@@ -169,6 +169,43 @@ def test_kd_order_is_a_permutation_whose_aligned_groups_are_tree_cells(n, dim, d
             size *= 4
 
 
+@pytest.mark.parametrize("case", ["duplicates", "line", "one_point", "two_clusters"])
+def test_kd_order_on_degenerate_clouds(case, dev, monkeypatch):
+    """k-d order where a split has nothing to split: every point repeated, a cloud on a line in 5D, ONE point repeated,
+    two far clusters of different size.  Still a permutation, and the sweep over it equals the sweep over the curve order."""
+    rng = np.random.default_rng(11)
+    dim = 5
+    if case == "duplicates":
+        base = rng.normal(size=(3000, dim)).astype(np.float32)
+        P = np.concatenate([base, base, base[:1500]])
+    elif case == "line":
+        t = rng.uniform(-1, 1, size=(9000, 1)).astype(np.float32)
+        P = (t * np.array([[1.0, -2.0, 0.5, 0.0, 3.0]], dtype=np.float32)).astype(np.float32)
+    elif case == "one_point":
+        P = np.tile(np.array([[0.25, -1.0, 2.0, 0.0, 7.0]], dtype=np.float32), (2100, 1))
+    else:
+        P = np.concatenate([rng.normal(size=(7000, dim)), 50.0 + 0.01 * rng.normal(size=(333, dim))]).astype(np.float32)
+    tp = torch.as_tensor(P, device=dev)
+    monkeypatch.setattr(core, "KD_ORDER_ABOVE_DIM", 3)
+    idx = core.PointIndex(tp)
+    assert idx.kd
+    o = idx.order32.long().cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(len(P)))
+    assert np.array_equal(idx.pts[:len(P), :dim].cpu().numpy(), P[o])
+    if case == "one_point":
+        return
+    L = tp[torch.as_tensor(fo.exact_fps(P, 12, 0), device=dev)]
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    out = {}
+    for above in (3, 8):
+        monkeypatch.setattr(core, "KD_ORDER_ABOVE_DIM", above)
+        try:
+            out[above] = fa.flood_complex(tp, L, max_dimension=2, points_per_edge=5, method="bvh")
+        except Exception as e:   # (a degenerate landmark set: Qhull refuses it on either order alike)
+            out[above] = repr(type(e))
+    assert out[3] == out[8]
+
+
 @pytest.mark.parametrize("dim,kw", [(6, dict(max_dimension=2, points_per_edge=6)), (4, dict(max_dimension=3, points_per_edge=4)),
                                     (5, dict(max_dimension=2, num_rand=40))])
 def test_kd_order_and_curve_order_give_the_same_filtration(dim, kw, dev, monkeypatch):
