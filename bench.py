@@ -329,6 +329,15 @@ def main():
         mine = (torch.arange(S_all * er // ew, S_all * (er + 1) // ew, device=dev) if args.shard == "blocks"
                 else torch.arange(er, S_all, ew, device=dev))
         face_hook = lambda t: t  # noqa: E731  (the 360 KB all_reduce is not emulated)
+    # a simplex-sharded run through the sorted-sample sweep (above 3D) shards the TILES of the sorted order instead
+    # (core.shards_sorted_tiles): every rank keeps all simplices and combines its partial face maxima with MAX
+    tile_shard = None
+    if (mine is not None and args.shard == "simplices" and args.method == "bvh"
+            and core.shards_sorted_tiles(w["dim"], S_all, weights.shape[0], "bvh")):
+        tile_shard = (er, ew) if (args.emulate_shard and world == 1) else (rank, world)
+        mine = None
+        if world > 1:
+            face_hook = min_reduce_hook()
     if mine is not None:
         verts, centers, radii = verts[mine].contiguous(), centers[mine].contiguous(), radii[mine].contiguous()
         cnt0 = cnt0[mine]
@@ -381,7 +390,12 @@ def main():
             if st is not None:
                 stats.zero_()
             out, _ = core._sweep_dimension_bvh(index, verts, weights, faces, hook, timer=timer,
-                                               stats=None if st is None else st[:4], plan=plan)
+                                               stats=None if st is None else st[:4], plan=plan, tile_shard=tile_shard)
+            if tile_shard is not None and world > 1:   # MAX over the ranks (MIN of the negated non-negative values)
+                neg = -out
+                with core._span(timer, "reduce"):
+                    face_hook(neg)
+                out = -neg
         else:
             out, _ = core._sweep_dimension_hip(index[0], index[1], axis, w["dim"], verts, centers, radii, weights,
                                                faces, hook, timer=timer)

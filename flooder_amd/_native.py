@@ -63,6 +63,9 @@ SIGNATURES = {
                                                    c_void_p, c_void_p]),
     "flooder_sweep_bvh_sorted_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_sweep_bvh_sorted_shard_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                   c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),

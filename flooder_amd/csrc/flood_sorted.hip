@@ -183,13 +183,21 @@ struct SortedFaces {
 #ifndef FLOODER_SORTED_MIN_WAVES
 #define FLOODER_SORTED_MIN_WAVES 7
 #endif
+// A rank of a multi-GPU run takes a CONTIGUOUS world-th of the tiles of the sorted order: its tiles are tiles of the
+// unsharded sweep, and they lie in one region of space - an eighth of cfg 4's tiles touches an eighth of the cloud
+// (6.9 ms of sweep; every 8th chunk of 256 tiles, which evens out the 12 % a tile at the sparse end of the curve costs
+// more, works on the whole cloud from a cold cache: 8.7 - 9.7 ms).  world <= 1: all tiles.
+struct TileShard {
+  int rank, world;
+};
+
 template <int DIM, int KS, bool FUSED>
 __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORTED_MIN_WAVES : 1) void sweep_sorted_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_samples, const uint32_t* __restrict__ order, int32_t* __restrict__ queue,
     uint32_t* __restrict__ out_d2, unsigned long long* __restrict__ stats, int refine_pct, float batch_scale,
-    SortedFaces sf) {
+    SortedFaces sf, TileShard ts) {
   // KS samples per lane: a tile is 64 * KS consecutive samples of the sorted order (lane l holds l, l + 64, ...)
   constexpr int DP = padded_dim(DIM);
   constexpr int TILE = 64 * KS;
@@ -201,7 +209,13 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 #endif
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int64_t n_tiles = (n_samples + TILE - 1) / TILE;
+  const int64_t n_tiles_all = (n_samples + TILE - 1) / TILE;
+  int64_t n_tiles = n_tiles_all;
+  int64_t tile_first = 0;
+  if (ts.world > 1) {
+    tile_first = n_tiles_all * ts.rank / ts.world;
+    n_tiles = n_tiles_all * (ts.rank + 1) / ts.world - tile_first;
+  }
   const int top = lv.n_levels - 1;
   unsigned long long n_leaf_eval = 0, n_leaf_test = 0, n_node_test = 0, max_item_tests = 0, n_node_spared = 0;
 
@@ -216,8 +230,9 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 #endif
   int q_shard = (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;
   for (;;) {
-    const int64_t g = queue_pop(queue, q_shard, q_tried, n_tiles, lane);  // sharded heads (flood_common.hpp)
+    int64_t g = queue_pop(queue, q_shard, q_tried, n_tiles, lane);  // sharded heads (flood_common.hpp)
     if (g < 0) break;
+    g += tile_first;
     SPHASE(0);
     const unsigned long long tests_before = n_leaf_test + n_node_test;
     // ---- this lane's samples: p = sum_j w[r,j] * v[s,j,:]   (core.py:188; same fma order as every other sweep)
@@ -657,7 +672,7 @@ struct SweepSortedOp {
   template <int KS, bool FUSED>
   static int launch(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                     int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
-                    unsigned long long* stats, SortedFaces sf, hipStream_t st) {
+                    unsigned long long* stats, SortedFaces sf, TileShard ts, hipStream_t st) {
     // persistent blocks of 4 independent waves, as many as the registers let a CU hold (asked once per instantiation)
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
@@ -665,22 +680,26 @@ struct SweepSortedOp {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sweep_sorted_kernel<DIM, KS, FUSED>, 256, 0) != hipSuccess || nb < 1) nb = 4;
       blocks_per_cu = nb > 8 ? 8 : nb;
     }
-    const int64_t n_tiles = (n_samples + 64 * KS - 1) / (64 * KS);
+    int64_t n_tiles = (n_samples + 64 * KS - 1) / (64 * KS);
+    if (ts.world > 1) {
+      n_tiles = n_tiles * (ts.rank + 1) / ts.world - n_tiles * ts.rank / ts.world;
+      if (n_tiles == 0) return FLOODER_OK;
+    }
     // (option "sorted_blocks": fewer resident blocks per CU than fit - a diagnostic for how much of the kernel is latency)
     int64_t grid = (int64_t)(g_sorted_blocks > 0 && g_sorted_blocks < blocks_per_cu ? g_sorted_blocks : blocks_per_cu) * 256;
     if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
     hipLaunchKernelGGL((sweep_sorted_kernel<DIM, KS, FUSED>), dim3((unsigned)grid), dim3(256), 0, st, pts, nodes, lv, verts,
                        weights, k1, R, n_samples, order, queue, out, stats, g_bvh_refine_pct,
-                       (float)(g_sorted_batch_pct < 100 ? 100 : g_sorted_batch_pct) * 0.01f, sf);
+                       (float)(g_sorted_batch_pct < 100 ? 100 : g_sorted_batch_pct) * 0.01f, sf, ts);
     return check_launch("sweep_sorted");
   }
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, const float* weights,
                  int k1, int R, int64_t n_samples, const uint32_t* order, int32_t* queue, uint32_t* out,
-                 unsigned long long* stats, SortedFaces sf, hipStream_t st) {
+                 unsigned long long* stats, SortedFaces sf, TileShard ts, hipStream_t st) {
     if (sf.face_bits != nullptr)
-      return launch<1, true>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
-    if (g_sorted_ks == 2) return launch<2, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
-    return launch<1, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, st);
+      return launch<1, true>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, ts, st);
+    if (g_sorted_ks == 2) return launch<2, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, ts, st);
+    return launch<1, false>(pts, nodes, lv, verts, weights, k1, R, n_samples, order, queue, out, stats, sf, ts, st);
   }
 };
 
@@ -728,7 +747,23 @@ int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim
   return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
                                      reinterpret_cast<const uint32_t*>(sample_order), queue, out_d2,
                                      reinterpret_cast<unsigned long long*>(stats), SortedFaces{nullptr, nullptr, nullptr, 0, 0},
-                                     (hipStream_t)stream);
+                                     TileShard{0, 1}, (hipStream_t)stream);
+}
+
+int flooder_sweep_bvh_sorted_shard_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                       const int32_t* sample_order, int shard_rank, int shard_world, int32_t* queue,
+                                       uint32_t* out_d2, uint64_t* stats, void* stream) {
+  if (n_simplices == 0 || R == 0) return FLOODER_OK;
+  if (!pts_sorted || !nodes || !verts || !weights || !sample_order || !queue || !out_d2 || n_pts < 1 || k1 < 1 ||
+      k1 > FLOODER_MAX_VERTS || R < 0 || n_simplices * (int64_t)R > 0xfffffffeLL || shard_world < 1 || shard_rank < 0 ||
+      shard_rank >= shard_world)
+    return fail(FLOODER_E_ARG, "flooder_sweep_bvh_sorted_shard_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
+                                     reinterpret_cast<const uint32_t*>(sample_order), queue, out_d2,
+                                     reinterpret_cast<unsigned long long*>(stats), SortedFaces{nullptr, nullptr, nullptr, 0, 0},
+                                     TileShard{shard_rank, shard_world}, (hipStream_t)stream);
 }
 
 int flooder_sweep_bvh_sorted_faces_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
@@ -743,7 +778,7 @@ int flooder_sweep_bvh_sorted_faces_f32(const float* pts_sorted, int64_t n_pts, i
   return dispatch_dim<SweepSortedOp>(dim, pts_sorted, nodes, lv, verts, weights, k1, R, n_simplices * (int64_t)R,
                                      reinterpret_cast<const uint32_t*>(sample_order), queue, (uint32_t*)nullptr,
                                      reinterpret_cast<unsigned long long*>(stats),
-                                     SortedFaces{memb, face_bits, face_slot, n_faces, g_sorted_refresh}, (hipStream_t)stream);
+                                     SortedFaces{memb, face_bits, face_slot, n_faces, g_sorted_refresh}, TileShard{0, 1}, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -8,6 +8,13 @@ against 288 GB) and sweeps every W-th simplex of the sorted simplex list; the pe
 culled sweeps do work proportional to the number of SAMPLES, not points, so this is the decomposition that
 scales; the exchanged buffer is a few hundred KB.
 
+Above 3 dimensions, where a dimension pass runs through the sorted-sample sweep (tiles of 64 spatially consecutive
+samples of ALL simplices, ``csrc/flood_sorted.hip``), ``mode="simplices"`` shards the TILES of the sorted order
+instead of the simplices: every rank sorts all samples (the same order everywhere), sweeps a contiguous W-th of the
+tiles - exactly tiles of the unsharded sweep, in one region of space; every W-th simplex would thin the samples W times and widen the tiles
+by W^(1/dim) - and holds, per face, the maximum over ITS samples; the ranks' (S, F) matrices combine with MAX (the
+hook's MIN applied to the negated non-negative values).
+
 ``mode="points"``: the path also shards over the point cloud because
 ``min_x |p - x|`` is associative: every rank holds all simplices (tiny) and ANY subset of the
 points, computes the per-sample minimum squared distance against its subset, and one

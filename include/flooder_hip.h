@@ -252,6 +252,14 @@ int flooder_sweep_bvh_sorted_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
                                  const int32_t* sample_order, int32_t* queue, uint32_t* out_d2, uint64_t* stats,
                                  void* stream);
+/* The same sweep over ONE RANK'S tiles of a multi-GPU run: the contiguous run [T r / W, T (r + 1) / W) of the T tiles
+ * of the sorted order - tiles of the unsharded sweep (above 3D a rank that took every W-th SIMPLEX would sweep a W times
+ * thinner sample set in W^(1/dim) times wider tiles) in one region of space.  out_d2 is written for the rank's samples
+ * only: zero it first, take the face maxima over all of it and combine the ranks' (S, F) values with MAX. */
+int flooder_sweep_bvh_sorted_shard_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
+                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
+                                       const int32_t* sample_order, int shard_rank, int shard_world, int32_t* queue,
+                                       uint32_t* out_d2, uint64_t* stats, void* stream);
 
 /* The sorted sweep fused with the per-face maxima (core.py:251-276 folded in; the default above 3 dimensions when only
  * the face values are wanted): no (S, R) buffer.  A sample whose running minimum - the distance to a real point - does

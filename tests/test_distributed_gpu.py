@@ -40,6 +40,9 @@ def _worker(rank, world, port, name, out_dir, mode):
         from helpers import load_e2e
 
         _native.load()  # no fallback: the HIP library must be there
+        if name.startswith("gauss6d"):   # (small: let the sorted-sample sweep and its tile sharding run all the same)
+            from flooder_amd import core
+            core.BVH_SORTED_MIN_SAMPLES = 0
         dev = torch.device("cuda:0")
         z, kw, keys = load_e2e(name)
         pts = torch.as_tensor(z["points"], device=dev)
@@ -123,3 +126,70 @@ def test_block_shards_one_after_the_other_equal_unsharded(cloud, world):
     else:   # a few ranks of many: what they produced is final, the rest still +inf
         done = np.isfinite(got)
         assert done.any() and np.array_equal(got[done].view(np.uint32), want[done].view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,world,kw", [(6, 2, dict(max_dimension=2, points_per_edge=6)), (5, 3, dict(max_dimension=2, num_rand=40)),
+                                          (4, 8, dict(max_dimension=3, points_per_edge=4)), (6, 5000, dict(max_dimension=1, points_per_edge=5))])
+def test_tile_shards_of_the_sorted_sweep_one_after_the_other_equal_unsharded(dim, world, kw, monkeypatch):
+    """Above 3D a simplex-sharded run shards the TILES of the sorted sample order (core.shards_sorted_tiles): all
+    ranks of a ``world``-rank run one after the other on this GPU, each holding the face maxima over its own samples,
+    combined by what the all-reduce does (MIN of the negated matrices).  Bit for bit the unsharded values - also with
+    more ranks than tiles, and whether tiles or simplices are sharded."""
+    import flooder_amd as fa
+    from flooder_amd import core
+    from oracle import flood_oracle as fo
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(dim + world)
+    P = rng.normal(size=(50_000, dim)).astype(np.float32)
+    tp = torch.as_tensor(P, device=dev)
+    lms = tp[torch.as_tensor(fo.exact_fps(P, 26, 0), device=dev)]
+    monkeypatch.setattr(core, "BVH_SORTED_MIN_SAMPLES", 0)
+    torch.manual_seed(7)
+    want = fa.flood_complex(tp, lms, method="bvh", **kw)
+    keys = sorted(want)
+    ranks = list(range(world)) if world <= 8 else [0, 1, world // 2, world - 1]
+
+    def run(tiles):
+        monkeypatch.setattr(core, "SHARD_SORTED_TILES", tiles)
+        used = []
+        orig = core._sweep_dimension_bvh
+
+        def spy(*a, **k):
+            used.append(k.get("tile_shard"))
+            return orig(*a, **k)
+
+        monkeypatch.setattr(core, "_sweep_dimension_bvh", spy)
+        parts = {}   # per dimension pass (in call order): the matrices as they enter the all-reduce
+
+        def collect_for(r):
+            calls = [0]
+
+            def hook(full):
+                parts.setdefault(calls[0], []).append(full.clone())
+                calls[0] += 1
+            return hook
+
+        def reduce_hook():
+            calls = [0]
+
+            def hook(full):
+                full.copy_(torch.stack(parts.get(calls[0], []) + [full]).amin(dim=0))
+                calls[0] += 1
+            return hook
+
+        for r in ranks[1:]:
+            torch.manual_seed(7)
+            fa.flood_complex(tp, lms, method="bvh", simplex_shard=(r, world), face_reduce_hook=collect_for(r), **kw)
+        torch.manual_seed(7)
+        got = fa.flood_complex(tp, lms, method="bvh", simplex_shard=(ranks[0], world), face_reduce_hook=reduce_hook(), **kw)
+        monkeypatch.setattr(core, "_sweep_dimension_bvh", orig)
+        return got, used
+
+    got, used = run(True)
+    assert any(u is not None for u in used), "no dimension pass was tile-sharded"
+    if world <= 8:
+        assert sorted(got) == keys and [got[k] for k in keys] == [want[k] for k in keys]
+        got2, used2 = run(False)
+        assert all(u is None for u in used2)
+        assert [got2[k] for k in keys] == [want[k] for k in keys]
