@@ -55,6 +55,11 @@ constexpr bool SORTED_NODE_SUB = FLOODER_SORTED_NODE_SUB != 0;
 #define FLOODER_SORTED_NODE_EXACT 1
 #endif
 constexpr bool SORTED_NODE_EXACT = FLOODER_SORTED_NODE_EXACT != 0;
+// rows of a leaf per batch of scalar loads for 8-float rows: 8 (1) or 4 (0).  8 spills 37 more scalar registers at 7 waves
+// per SIMD and is still 1.0 ms faster at cfg 4 (32.85 against 33.85 ms, twice on the same box)
+#ifndef FLOODER_SORTED_UB8
+#define FLOODER_SORTED_UB8 1
+#endif
 #ifndef FLOODER_SORTED_REFINE
 #define FLOODER_SORTED_REFINE 0
 #endif
@@ -560,9 +565,8 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
       ++evals_in_group;
 #endif
       const float* cp = pts + c * (int64_t)LEAF * DP;
-      // rows stream through SGPRs (scalar loads), UB at a time: 8 rows of 8 floats would need 64 SGPRs on top of the
-      // traversal's own; 4 rows keep the spills away
-      constexpr int UB = DP == 8 ? 4 : 8;
+      // rows stream through SGPRs (scalar loads), UB at a time (FLOODER_SORTED_UB8 above)
+      constexpr int UB = FLOODER_SORTED_UB8 ? 8 : (DP == 8 ? 4 : 8);
 #pragma unroll
       for (int h = 0; h < LEAF; h += UB) {
         typename RowVec<DP>::type cc[UB];
