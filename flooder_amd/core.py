@@ -1371,6 +1371,7 @@ def flood_complex(
     lm_np = landmarks.detach().to(torch.float64 if use_f64 else (torch.float32 if on_gpu else dtype)).cpu().numpy()
 
     results: List[tuple] = []  # (simplices (n,k), values (n,)) or indexed cell-face assignments, in update order
+    peak_ws = 0
     for d in range(max_dimension + 1):
         if num_rand is None and d < max_dimension:
             continue
@@ -1410,6 +1411,9 @@ def flood_complex(
             faces = _FaceTable(None, weights.shape[0], device)
         LAST_STATS.top_simplices = num_simplices
         LAST_STATS.samples_per_simplex = weights.shape[0]
+        # (rough device workspace of this pass: 4 B per sample, 24 with the sorted-sample sweep's keys and orders)
+        peak_ws = max(peak_ws, num_simplices * weights.shape[0] *
+                      (24 if (method == "bvh" and bvh_sorts_samples(dim, num_simplices, weights.shape[0])) else 8))
 
         tile_shard = None
         if simplex_shard is not None:
@@ -1509,7 +1513,9 @@ def flood_complex(
             for s, v in zip(simp.tolist(), vals.tolist()):
                 stree.assign_filtration(s, v)
     stree.make_filtration_non_decreasing()
-    if on_gpu and torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device) > EMPTY_CACHE_ABOVE_BYTES:
+    # (asking the allocator costs 0.2 ms of a 10 ms call: only after a call that can have left that much behind)
+    if (on_gpu and peak_ws > EMPTY_CACHE_ABOVE_BYTES // 4
+            and torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device) > EMPTY_CACHE_ABOVE_BYTES):
         # (core.py:281 of the reference empties the allocator's cache after every call - it has just dropped several GB
         # of masks and index pairs; here a call leaves tens of MB behind and the release costs a millisecond of an 11 ms
         # call, so it is done only when there is something worth releasing)
