@@ -1264,7 +1264,11 @@ def flood_complex(
     them): every ``world``-th simplex of the queue, or - ``shard_blocks=True``, float32 ROCm tensors, methods
     ``"cell"``/``"bvh"``, landmarks that are POINTS OF THE CLOUD (the caller vouches; true for every
     ``generate_landmarks`` result) - a contiguous block of the queue, swept against an index of the sub-cloud inside
-    the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too.
+    the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too.  A dimension
+    pass that runs the sorted-sample sweep (above 3D; ``shards_sorted_tiles``) shards the TILES of the sorted sample
+    order instead: this rank's (S, F) values are the maxima over ITS samples (0 where it has none), and
+    ``face_reduce_hook`` - an in-place elementwise MIN over the ranks, whatever it is given - receives the NEGATED
+    matrix, so that its MIN is the MAX of the values.
     """
     if use_triton is None:
         use_triton = HAS_HIP_KERNELS
