@@ -506,6 +506,15 @@ def cloud_box(points: torch.Tensor) -> torch.Tensor:
 KD_ORDER_ABOVE_DIM = 3
 
 
+def _tensor_version(t: torch.Tensor):
+    """In-place modification counter of a tensor, or None where torch keeps none (tensors created under
+    ``torch.inference_mode()`` raise on ``_version``): the staleness check of ``index=`` is skipped for those."""
+    try:
+        return None if t.is_inference() else t._version
+    except RuntimeError:
+        return None
+
+
 class PointIndex:
     """Copy of a point set sorted along a space-filling curve (Hilbert by default) plus its implicit box tree
     (HBM resident).
@@ -525,7 +534,7 @@ class PointIndex:
         # where the rows came from: flood_complex(index=...) refuses an index whose source tensor has been written to
         # in place since (same storage, other version counter); a different tensor of the same shape cannot be told
         # from a copy of the same cloud and is taken on the caller's word
-        self.source = (points.data_ptr(), points._version)
+        self.source = (points.data_ptr(), _tensor_version(points))
         self.dp = lib.flooder_padded_dim(dim)
         self.box = box if box is not None else cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
         # sorted row -> original index (int32)
@@ -628,6 +637,23 @@ def h2d_ms_of(index: "PointIndex") -> Optional[float]:
         return None
     torch.cuda.synchronize()
     return float(ev[0].elapsed_time(ev[1]))
+
+
+def _row_hash(x: torch.Tensor) -> torch.Tensor:
+    """64-bit mix of the float32 bit patterns of every row (-0.0 folded onto 0.0): equal rows, equal hashes."""
+    b = (x.to(torch.float32) + 0.0).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    h = torch.full((x.shape[0],), 0x2545F4914F6CDD1D, dtype=torch.int64, device=x.device)
+    for k in range(x.shape[1]):
+        h = (h ^ (b[:, k] + 0x632BE59BD9B4E019 + (h << 6) + (h >> 2))) * 0x100000001B3
+    return h
+
+
+def _rows_are_subset(rows: torch.Tensor, points32: torch.Tensor) -> bool:
+    """Is every row of ``rows`` bit-equal to some row of ``points32``?  (Row hashes through ``torch.isin``; a false
+    'yes' needs a 64-bit collision.)  One host synchronisation."""
+    if rows.shape[0] == 0:
+        return True
+    return bool(torch.isin(_row_hash(rows), _row_hash(points32)).all().item())
 
 
 def block_subcloud(points32: torch.Tensor, verts: torch.Tensor, d: int, box: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -848,23 +874,43 @@ class SamplePlan:
             for f in range(n_faces):
                 memb_all[inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]] |= np.uint32(1 << f)
             self.memb_all = torch.as_tensor(memb_all.view(np.int32), device=dev)
-        # fused sorted sweep (above 3D): every row but one PILOT per face - the row nearest to the centre of the
-        # face's rows - sorts behind the pilots, whose values bring the face maxima close to final first
-        self.late_rows = None
-        if n_faces <= 32:
-            late = np.ones(R, dtype=np.uint8)
-            wn = weights.detach().cpu().numpy().astype(np.float64)[perm]
-            for f in range(n_faces):
-                rows_f = inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]
-                if rows_f.size > 2:
-                    c = wn[rows_f].mean(axis=0)
-                    late[rows_f[np.argmin(((wn[rows_f] - c) ** 2).sum(axis=1))]] = 0
-            self.late_rows = torch.as_tensor(late, device=dev)
-        # coarse level of the witness sweep (None: not applicable to this table)
-        self.wit = None
-        wp = witness_plan(weights, perm) if self.memb_all is not None else None
-        if wp is not None:
-            self.wit = (torch.as_tensor(wp[0], device=dev), torch.as_tensor(wp[1].view(np.int32), device=dev), wp[2])
+        self._perm, self._weights, self._face_rows = perm, weights, (f_ptr, f_rows, inv)
+        self._late_rows = self._wit = None
+        self._late_built = self._wit_built = False
+
+    # The two tables below cost host work (a device sync for the weights, a cKDTree / farthest-point pass, one loop
+    # per face) and only one sweep each reads them: they are built when that sweep first asks - a ``num_rand`` call,
+    # whose weight table is new every time, never pays for a witness plan it cannot use.
+    @property
+    def late_rows(self):
+        """fused sorted sweep (above 3D, ``SORTED_FUSED_FACES``): every row but one PILOT per face - the row nearest
+        to the centre of the face's rows - sorts behind the pilots, whose values bring the face maxima close to final
+        first.  None: more than 32 faces."""
+        if not self._late_built:
+            self._late_built = True
+            if self.memb_all is not None:
+                f_ptr, f_rows, inv = self._face_rows
+                late = np.ones(self.R, dtype=np.uint8)
+                wn = self._weights.detach().cpu().numpy().astype(np.float64)[self._perm]
+                for f in range(self.faces.n_faces):
+                    rows_f = inv[f_rows[f_ptr[f]:f_ptr[f + 1]]]
+                    if rows_f.size > 2:
+                        c = wn[rows_f].mean(axis=0)
+                        late[rows_f[np.argmin(((wn[rows_f] - c) ** 2).sum(axis=1))]] = 0
+                self._late_rows = torch.as_tensor(late, device=self._weights.device)
+        return self._late_rows
+
+    @property
+    def wit(self):
+        """coarse level of the witness sweep (``witness_plan``): (coarse rows, parents, number of coarse samples) on
+        the device, or None where the table is not one the kernel takes."""
+        if not self._wit_built:
+            self._wit_built = True
+            wp = witness_plan(self._weights, self._perm) if self.memb_all is not None else None
+            if wp is not None:
+                dev = self._weights.device
+                self._wit = (torch.as_tensor(wp[0], device=dev), torch.as_tensor(wp[1].view(np.int32), device=dev), wp[2])
+        return self._wit
 
 
 def _sweep_dimension_f64(index: PointIndex, pts64_sorted: torch.Tensor, verts: torch.Tensor, weights: torch.Tensor,
@@ -1103,8 +1149,8 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # (a short queue - a rank's share of a multi-GPU run - leaves the witness sweep's workgroups one simplex each: the
         # launch then lasts as long as its longest item, 250 - 300 us, where the cell sweep balances chunk by chunk;
         # measured on an eighth of cfg 2: 0.65 ms per rank with it, 0.55 without)
-        use_wit = (CELL_WITNESS and CELL_SUPER and CELL_PROBE and plan.wit is not None and index.dim in (2, 3)
-                   and S >= WIT_MIN_SIMPLICES)
+        use_wit = (CELL_WITNESS and CELL_SUPER and CELL_PROBE and index.dim in (2, 3) and S >= WIT_MIN_SIMPLICES
+                   and plan.wit is not None)
         zeroed = torch.zeros((1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots,
                              dtype=torch.int32, device=dev)
         if use_wit:
@@ -1296,7 +1342,8 @@ def flood_complex(
         if not isinstance(index, PointIndex) or (index.n, index.dim) != tuple(points.shape) or index.pts.device != points.device:
             raise ValueError("index= is not a PointIndex of these points (shape or device differ)")
         src = getattr(index, "source", None)
-        if src is not None and src[0] == points.data_ptr() and src[1] != points._version:
+        ver = _tensor_version(points)
+        if src is not None and src[0] == points.data_ptr() and src[1] is not None and ver is not None and src[1] != ver:
             raise ValueError("index= was built from an earlier state of `points` (the tensor has been modified in "
                              "place since): rebuild the PointIndex")
         shared_index = index
@@ -1342,6 +1389,11 @@ def flood_complex(
     if blocks:
         pts32 = points.to(torch.float32).contiguous()
         block_box = shared_index.box if shared_index is not None else cloud_box(pts32)
+        if not _rows_are_subset(landmarks.to(torch.float32), pts32):
+            raise ValueError("shard_blocks / mode='blocks' needs landmarks that are rows of `points` (every "
+                             "generate_landmarks result is): a block's sub-cloud holds only the rows inside its "
+                             "simplices' bounding balls, which bound the nearest neighbours of the samples only then "
+                             "- use mode='simplices'")
     elif on_gpu and method != "ball":
         # the curve sort + box tree run on the GPU while the host triangulates the landmarks
         pts32 = points.to(torch.float32)

@@ -133,6 +133,47 @@ struct DeferList {
   int drop = 0;          // cell query: interior samples whose running minimum cannot raise the simplex's maximum stop early
 };
 
+// The arguments of cell_sweep_kernel: ONE struct in the kernarg segment.  As separate kernel parameters they were
+// ~116 SGPRs (Levels 26, DeferList 25, FaceAcc 19, ...) that the compiler loaded at the top of the kernel and kept
+// alive across the persistent loop - with 102 SGPRs available, 215 of them were parked in VGPR lanes (v_writelane /
+// v_readlane: 4 VGPRs of a kernel that sits at its 168-VGPR limit).  Now a field is read where it is used, through a
+// pointer to the kernarg segment that an empty asm statement hides from the optimiser (ARG below): a scalar load
+// from the scalar cache per use site and nothing to keep alive.
+struct CellParams {
+  const float* pts;
+  const float* nodes;
+  Levels lv;
+  const float* verts;
+  const float* plane_tab;
+  const float* weights;
+  int k1, R;
+  int64_t n_simplices;
+  float alpha;
+  int exh_dense, exh_sparse, brute_max, max_tries, exh_tries, retry_pct, retry_keep;
+  int32_t* queue;
+  uint32_t* out_d2;
+  int32_t* flag_list;
+  int32_t* flag_count;
+  unsigned long long* stats;
+  FaceAcc acc;
+  DeferList dl;
+  DensGrid dg;
+  int qblk;  // work queue: items are dealt to the shards in blocks of 2^qblk (flood_common.hpp: queue_pop_local); < 0: the interleaved queue
+};
+#define FLOODER_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ const FLOODER_AS4 CellParams* cell_args() {
+  const FLOODER_AS4 CellParams* p = (const FLOODER_AS4 CellParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));  // (a fresh pointer every time: loads through it are neither merged nor hoisted)
+  return p;
+}
+template <typename T>
+__device__ __forceinline__ T arg_copy(const FLOODER_AS4 T* p) {
+  T t;
+  __builtin_memcpy(&t, p, sizeof(T));
+  return t;
+}
+#define ARG(field) arg_copy(&cell_args()->field)
+
 // Outward unit normals of the faces of a full-dimensional simplex (face f is opposite vertex f), as planes
 // pn . (x - org) <= po relative to the LOCAL origin org = vertex 0 (no cancellation for clouds far from the
 // coordinate origin).  A point within c of a sample lies within c of every such half-space; the test in the sweep
@@ -240,13 +281,10 @@ __global__ __launch_bounds__(256) void simplex_planes_kernel(const float* __rest
 // whose neighbourhood does not fit the stage, and chunks that keep open samples (they would need a larger cell
 // size, i.e. a new stage), are appended to a deferred list that a SUPER = false launch works off chunk by chunk.
 template <int DIM, bool SUPER, int SPLV>
-__global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
-   
-    const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
-    const float* __restrict__ verts, const float* __restrict__ plane_tab, const float* __restrict__ weights, int k1, int R,
-    int64_t n_simplices, float alpha, int exh_dense, int exh_sparse, int brute_max, int max_tries, int exh_tries, int retry_pct, int retry_keep, int32_t* __restrict__ queue, uint32_t* __restrict__ out_d2,
-    int32_t* __restrict__ flag_list, int32_t* __restrict__ flag_count,
-    unsigned long long* __restrict__ stats, FaceAcc acc, DeferList dl, DensGrid dg) {
+__global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_the_kernarg_segment) {  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
+  // Launch-invariant arguments that the whole item loop needs (the rest: ARG(field) where it is used)
+  const int R = ARG(R), k1 = ARG(k1);
+  const bool has_stats = ARG(stats) != nullptr, fused = ARG(acc.face_bits) != nullptr;
   constexpr int DP = padded_dim(DIM);
   constexpr int SPL = SPLV;          // samples per lane
   constexpr int CHUNK = 64 * SPL;    // samples per wave item (SPLV = 1: the tile launch)
@@ -279,38 +317,46 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     const int sh = (i & 1) * 16;
     return (int)((atomicAdd(&s_cell32[i >> 1], 1u << sh) >> sh) & 0xffffu);
   };
-  const int top = lv.n_levels - 1;
+  const int top = ARG(lv.n_levels) - 1;
   const int n_slots = R;  // sample slots per simplex
   const int chunks = (n_slots + CHUNK - 1) / CHUNK;
   const int tiles64 = (n_slots + 63) >> 6;
   const int supers = (chunks + GS - 1) / GS;
   // (split[2] == 0: lists not filled - not produced any more, kept for callers that zero the counts themselves; a
   // cloud too dense for runs of four, or a short queue, has every simplex on the heavy list)
-  const bool use_lists = TILES || (!SUPER && dl.list && (!dl.split || dl.split[2] != 0));
-  const int64_t n_heavy_items = (!TILES && use_lists && dl.heavy) ? (int64_t)dl.split[1] * chunks : 0;
-  // (decided once per launch, wave-uniform: see the item decoding below)
-  const bool chunk_major = wave_uniform((!SUPER && !TILES && dl.chunk_major && use_lists && dl.heavy && chunks > 1 &&
-                                         3 * (n_heavy_items / chunks) < n_simplices) ? 1 : 0) != 0;
-  // chunk launch: the chunks the runs deferred come FIRST - they are the long items of this launch (a neighbourhood
-  // that overflowed the shared stage), and at the end of the queue they were its tail
-  const bool lfirst = TILES || dl.listed_first != 0;
-  const int64_t n_listed = TILES ? (int64_t)dl.tile_count[0] : (use_lists ? (int64_t)dl.count[0] : 0);
-  const int32_t* item_list = TILES ? dl.tile_list : dl.list;
-  const float* item_c = TILES ? dl.tile_c : dl.c;
-  const int64_t n_items = TILES ? (int64_t)dl.tile_count[0]
-                          : SUPER ? (dl.light ? (int64_t)dl.split[0] : n_simplices) * supers
-                                  : (use_lists ? n_heavy_items + n_listed : n_simplices * chunks);
+  // (item counts of a launch fit 32 bits: the entry point checks S x tiles against 2^31)
+  bool use_lists, chunk_major, lfirst;
+  int n_heavy_items, n_listed, n_items;
+  {
+    const DeferList dl = ARG(dl);
+    const int64_t n_simplices = ARG(n_simplices);
+    use_lists = TILES || (!SUPER && dl.list && (!dl.split || dl.split[2] != 0));
+    n_heavy_items = (!TILES && use_lists && dl.heavy) ? dl.split[1] * chunks : 0;
+    // (decided once per launch, wave-uniform: see the item decoding below)
+    chunk_major = wave_uniform((!SUPER && !TILES && dl.chunk_major && use_lists && dl.heavy && chunks > 1 &&
+                                3 * (int64_t)(n_heavy_items / chunks) < n_simplices) ? 1 : 0) != 0;
+    // chunk launch: the chunks the runs deferred come FIRST - they are the long items of this launch (a neighbourhood
+    // that overflowed the shared stage), and at the end of the queue they were its tail
+    lfirst = TILES || dl.listed_first != 0;
+    n_listed = TILES ? dl.tile_count[0] : (use_lists ? dl.count[0] : 0);
+    n_items = TILES ? dl.tile_count[0]
+              : SUPER ? (int)((dl.light ? (int64_t)dl.split[0] : n_simplices) * supers)
+                      : (use_lists ? n_heavy_items + n_listed : (int)(n_simplices * chunks));
+  }
   if (n_items == 0) return;  // (nothing for this launch: no need for 3072 waves to pop an empty queue)
-  unsigned long long n_pairs = 0, n_staged = 0, n_flagged = 0, n_retries = 0;
+  unsigned long long n_pairs = 0;
+  unsigned n_staged = 0, n_flagged = 0, n_retries = 0;  // (per-wave diagnostic counts: 32 bits hold them)
 #ifdef FLOODER_PHASE_TIMERS
   unsigned long long t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  unsigned long long g_gather0 = 0, g_gather = 0, g_cap = 0, g_tries = 0, g_brute = 0;
+  unsigned g_gather0 = 0, g_gather = 0, g_cap = 0, g_tries = 0, g_brute = 0;
 #ifdef FLOODER_WAVE_END
   const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  int q_shard = (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;  // sharded work queue (flood_common.hpp)
+  // sharded work queue (flood_common.hpp): XCD-local blocks of items, or (qblk < 0) interleaved items
+  const int qblk = ARG(qblk);
+  int q_shard = qblk >= 0 ? queue_home_local(wv) : (int)((blockIdx.x * 4 + wv) % QSHARDS), q_tried = 0;
   for (;;) {
     PHASE_T0();
 #ifdef FLOODER_PHASE_TIMERS
@@ -319,9 +365,14 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     unsigned long long t_phase0[12];
     for (int i = 0; i < 12; ++i) t_phase0[i] = t_phase[i];
 #endif
-    const int64_t g = queue_pop(queue, q_shard, q_tried, n_items, lane);
+    const int g = (int)(qblk >= 0 ? queue_pop_local(ARG(queue), q_shard, q_tried, n_items, lane, qblk)
+                                  : queue_pop(ARG(queue), q_shard, q_tried, n_items, lane));
     if (g < 0) break;
-    int64_t s;
+    // hot arguments of this item (the cold ones are read where they are used: ARG)
+    const float* __restrict__ const pts = ARG(pts);
+    const float* __restrict__ const nodes = ARG(nodes);
+    const float* __restrict__ const weights = ARG(weights);
+    int s;
     int q;            // current chunk of the simplex
     int n_sub = 1;    // chunks of this work item
     bool seeded = false;
@@ -330,9 +381,11 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       s = g / supers;
       q = (int)(g - s * supers) * GS;
       n_sub = chunks - q < GS ? chunks - q : GS;
-      if (dl.light) s = dl.light[s];
+      const int32_t* light = ARG(dl.light);
+      if (light) s = light[s];
     } else if (use_lists && (lfirst ? g >= n_listed : g < n_heavy_items)) {
-      const int64_t gh = lfirst ? g - n_listed : g;
+      const int gh = lfirst ? g - n_listed : g;
+      const int32_t* heavy = ARG(dl.heavy);
       // (only where the heavy list is the small dense rest of a cloud whose sparse simplices the witness sweep has
       // taken - cfg 2: 1725 of 6052; with every simplex on the list the order cost a rank's share of cfg 3 half of its
       // sweep time again, for reasons not understood: 2.11 / 1.10 ms against 1.43 / 0.75 at W = 2 / 4)
@@ -343,41 +396,42 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         // chunks of the densest simplices, first in the list) still start first.  (ALL chunks in chunk-major order
         // put the last chunk of the densest simplex at the very end of the queue: a rank's share of cfg 3 took 2.11
         // instead of 1.43 ms.)
-        const int64_t nh = n_heavy_items / chunks;
+        const int nh = n_heavy_items / chunks;
         if (gh < nh) {
           q = 0;
-          s = dl.heavy[gh];
+          s = heavy[gh];
         } else {
-          const int64_t g2 = gh - nh;
-          const int64_t si = g2 / (chunks - 1);
-          q = 1 + (int)(g2 - si * (chunks - 1));
-          s = dl.heavy[si];
+          const int g2 = gh - nh;
+          const int si = g2 / (chunks - 1);
+          q = 1 + (g2 - si * (chunks - 1));
+          s = heavy[si];
         }
       } else {
         s = gh / chunks;
-        q = (int)(gh - s * chunks);
-        s = dl.heavy[s];
+        q = gh - s * chunks;
+        s = heavy[s];
       }
     } else if (use_lists) {
-      const int64_t gl = lfirst ? g : g - n_heavy_items;
-      const int e = item_list[gl];
+      const int gl = lfirst ? g : g - n_heavy_items;
+      const int e = (TILES ? ARG(dl.tile_list) : ARG(dl.list))[gl];
       seeded = (e & 1) != 0;
-      c_seed = item_c[gl];
-      s = (int64_t)(e >> 1) / chunks;
-      q = (int)((e >> 1) - s * chunks);
+      c_seed = (TILES ? ARG(dl.tile_c) : ARG(dl.c))[gl];
+      s = (e >> 1) / chunks;
+      q = (e >> 1) - s * chunks;
     } else {
       s = g / chunks;
-      q = (int)(g - s * chunks);
+      q = g - s * chunks;
     }
+    s = wave_uniform(s);
     const int q_first = q;
-    const float* vs = verts + s * (int64_t)k1 * DIM;
+    const float* vs = ARG(verts) + (int64_t)s * k1 * DIM;
     const int n_live = R;  // live slots of this simplex
     if (q * CHUNK >= n_live) continue;
     auto defer = [&](int qq, int seeded_flag, float c_next) {
       if (lane == 0) {
-        const int pos = atomicAdd(dl.count, 1);
-        dl.list[pos] = (int)(((s * chunks + qq) << 1) | seeded_flag);
-        dl.c[pos] = c_next;
+        const int pos = atomicAdd(ARG(dl.count), 1);
+        ARG(dl.list)[pos] = (int)(((s * chunks + qq) << 1) | seeded_flag);
+        ARG(dl.c)[pos] = c_next;
       }
     };
     PHASE(0);
@@ -420,7 +474,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     float pn[DIM + 1][DIM], po[DIM + 1], pslack[DIM + 1], org[DIM];
     float sext;
     {
-      const float* pt = plane_tab + s * PLANE_ROW;
+      const float* pt = ARG(plane_tab) + (int64_t)s * PLANE_ROW;
       typename RowVec<4>::type t[PLANE_ROW / 4];
 #pragma unroll
       for (int i = 0; i < PLANE_ROW / 4; ++i) t[i] = load_uniform_row<4>(pt + 4 * i);
@@ -492,7 +546,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       const float c_ok_prev = (0.999f * c_prev) * (0.999f * c_prev);
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
-        const uint32_t w = out_d2[s * (int64_t)R + row[i]];
+        const uint32_t w = ARG(out_d2)[s * (int64_t)R + row[i]];
         best[i] = __uint_as_float(w & ~SETTLED_BIT);
         open[i] = open[i] && !(best[i] <= c_ok_prev);
       }
@@ -509,7 +563,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       bool over = false;
       // children of up to GB nodes `grp[u]` (valid for u < ng) at level lvl -> append hits to out_list
       auto test_children = [&](int lvl, const int (&grp)[GB], int ng, int* out_list, int& out_n, int cap) {
-        const int lvl_count = (int)lv.count[lvl], lvl_off = (int)lv.off[lvl];  // (node indices fit 32 bits here)
+        const int lvl_count = (int)ARG(lv.count[lvl]), lvl_off = (int)ARG(lv.off[lvl]);  // (node indices fit 32 bits here)
 #ifdef FLOODER_PHASE_TIMERS
         ++d_steps;
 #endif
@@ -572,6 +626,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     bool use_grid = false;
     float c = seeded ? c_seed : ext;
     int n0 = 0;  // points of the cloud inside the box
+    const DensGrid dg = ARG(dg);
     if (dg.grid != nullptr && !seeded) {
       typedef DensCfg<DIM> DC;
       const typename RowVec<4>::type b0 = load_uniform_row<4>(dg.box), b1 = load_uniform_row<4>(dg.box + 8);
@@ -606,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       if (mn >= dg.min_count) {  // every probed cell is well filled
         const float dens = (float)sum / ((float)NP * cell_vol);
         const float h = DIM == 3 ? cbrtf(1.f / dens) : __builtin_sqrtf(1.f / dens);
-        c = alpha * h;
+        c = ARG(alpha) * h;
         const float est = dens * vol;
         n0 = est < 1.f ? 1 : (est > 1.0e9f ? 1000000000 : (int)est);
         use_grid = true;
@@ -638,7 +693,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       }
       if (n0 > 0 && vol > 0.f) {
         const float h = DIM == 3 ? cbrtf(vol / (float)n0) : __builtin_sqrtf(vol / (float)n0);
-        c = alpha * h;
+        c = ARG(alpha) * h;
       }
     }
     if (!(c > 0.f) || !(c < 3.0e38f)) c = 1.f;
@@ -653,7 +708,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     // seed_mode (SUPER launch, chunk with open samples): the minima are parked in the (S, R) buffer for the deferred
     // per-chunk pass instead (every tile is written, nothing is flagged).
     auto finalize = [&](bool seed_mode) {
-    if (acc.face_bits) {
+    uint32_t* const out_d2 = ARG(out_d2);
+    if (fused) {
+      const FaceAcc acc = ARG(acc);
       // fused face maxima: every settled sample raises the running maximum of each face it lies on (one integer
       // atomic per face present in the chunk: interior chunks touch one face); the (S, R) buffer is only
       // written for the tiles the finish has to look at (bit 31 = already settled)
@@ -701,9 +758,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             int grp = 0;
             for (int lvl = top; lvl >= 0; --lvl) {
               const int idx = grp * FAN + lane;
-              const bool ok = idx < (int)lv.count[lvl];
+              const bool ok = idx < (int)ARG(lv.count[lvl]);
               float lo[DP], hi[DP];
-              const uint32_t nb_ = (uint32_t)((int)lv.off[lvl] + (ok ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
+              const uint32_t nb_ = (uint32_t)((int)ARG(lv.off[lvl]) + (ok ? idx : 0)) * (uint32_t)(2 * DP * sizeof(float));
               load_row_at<DP>(nodes, nb_, lo);
               load_row_at<DP>(nodes, nb_ + (uint32_t)(DP * sizeof(float)), hi);
               float lb = 0.f;
@@ -760,8 +817,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       for (int i = 0; i < SPL; ++i) nf += fl_on[i] ? 1 : 0;
       if (nf > 0) {  // (wave-uniform)
         int base = 0;
-        if (lane == 0) base = atomicAdd(flag_count, nf);
+        if (lane == 0) base = atomicAdd(ARG(flag_count), nf);
         base = wave_uniform(base);
+        int32_t* const flag_list = ARG(flag_list);
         int k = 0;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
@@ -792,8 +850,8 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         if (q * CHUNK + i * 64 + lane < n_live) out_d2[s * (int64_t)R + row[i]] = __float_as_uint(best[i]);
         if (!seed_mode && __ballot(open[i]) != 0ull) {
           if (lane == 0) {
-            const int pos = atomicAdd(flag_count, 1);
-            flag_list[pos] = (int)(s * tiles64 + q * SPL + i);
+            const int pos = atomicAdd(ARG(flag_count), 1);
+            ARG(flag_list)[pos] = (int)(s * tiles64 + q * SPL + i);
           }
           ++n_flagged;
         }
@@ -810,7 +868,8 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     // first kind (0: whatever they are).
     int kept_last = 0;  // points the last attempt kept per chunk (the next one keeps several times as many)
     auto retry_pays = [&](float c_now) -> bool {
-      if (kept_last > retry_keep) return false;
+      if (kept_last > ARG(retry_keep)) return false;
+      const int retry_pct = ARG(retry_pct);
       if (retry_pct <= 0) return true;
       const float lim = (1.998f * c_now) * (1.998f * c_now);
       int n_open = 0, n_near = 0;
@@ -843,9 +902,10 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       }
       // (an empty box gives no density: the cell size would fall back to the extent of the whole run, far more than
       // its chunks would try on their own - leave those to the per-chunk pass)
-      if (give_up || n0 == 0 || (float)n0 * grow > (float)dl.n0_limit) { defer_all_fresh(); continue; }
+      if (give_up || n0 == 0 || (float)n0 * grow > (float)ARG(dl.n0_limit)) { defer_all_fresh(); continue; }
     }
-    for (int attempt = seeded ? 1 : 0; attempt < (SUPER ? 1 : max_tries) && !give_up; ++attempt) {
+    const int max_tries = SUPER ? 1 : ARG(max_tries);
+    for (int attempt = seeded ? 1 : 0; attempt < max_tries && !give_up; ++attempt) {
       c = __builtin_fmaxf(c, ext / (float)(G - 3));
       const float inv_c = 1.f / c;
       int nc[DIM];
@@ -939,7 +999,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             best[i] = bb;
           }
         }
-        if (stats) n_pairs += (unsigned long long)n_st * SPL;
+        if (has_stats) n_pairs += (unsigned long long)n_st * SPL;
         n_st = 0;
         wave_lds_sync();
       };
@@ -993,13 +1053,13 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             decided = true;
             if constexpr (SUPER) {
               break;  // (a run that does not fit the stage is deferred: no need to count on)
-            } else if (dg.one_pass && !dl.tile_list && attempt < exh_tries) {
+            } else if (ARG(dg.one_pass) && !ARG(dl.tile_list) && attempt < ARG(exh_tries)) {
               // will the kept set be given up anyway (the cap below)?  Extrapolate from the share of the candidates
               // seen so far; a chunk that is likely to be dropped only counts on, as before
               const int seen = ib + 64 * UNR < n_cand ? ib + 64 * UNR : n_cand;
               const float est = (float)n_keep * (float)n_cand / (float)seen;
-              const float cap = (float)n0 * 8.f >= est ? (float)exh_dense : (float)exh_sparse;
-              if (est * 100.f <= (float)dg.one_pass * cap) {
+              const float cap = (float)n0 * 8.f >= est ? (float)ARG(exh_dense) : (float)ARG(exh_sparse);
+              if (est * 100.f <= (float)ARG(dg.one_pass) * cap) {
                 // switch: the first CAPW kept points are on record (last quarter of the stage), some of them from
                 // this batch; the batch is streamed again below - a point evaluated twice does no harm to a minimum
                 one_pass = true;
@@ -1028,7 +1088,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
             if (n_st + 64 * UNR > CAPE) flush_stage();
 #pragma unroll
             for (int u = 0; u < UNR; ++u) n_keep += stage_row(x[u], keep[u] && keep_point(x[u]));
-            if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) break;  // (hopeless after all: decided below)
+            if (n_keep > (n0 * 8 >= n_keep ? ARG(exh_dense) : ARG(exh_sparse))) break;  // (hopeless after all: decided below)
           }
         }
       }
@@ -1046,7 +1106,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         if (n_keep > CAPW) break;  // the neighbourhood of the whole run does not fit the stage: chunk by chunk
       }
       if constexpr (!SUPER && !TILES) {
-        if (n_keep > CAPW && dl.tile_list && g >= n_items - dl.tail_items) {
+        if (n_keep > CAPW && ARG(dl.tile_list) && (int64_t)g >= (int64_t)n_items - ARG(dl.tail_items)) {
           // dense chunk: its open tiles of 64 samples go to the tile launch (a quarter of the region each: most fit the
           // stage there) instead of an exhaustive evaluation of every kept point against all 256 samples.  A chunk
           // that already holds minima (seeded, or a second attempt) parks them first, as a run of four does.
@@ -1056,9 +1116,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           for (int i = 0; i < SPL; ++i) {
             if (q * CHUNK + i * 64 < n_live && __ballot(open[i]) != 0ull) {  // (wave-uniform)
               if (lane == 0) {
-                const int pos = atomicAdd(dl.tile_count, 1);
-                dl.tile_list[pos] = (int)(((s * tiles64 + q * SPL + i) << 1) | (fresh ? 0 : 1));
-                dl.tile_c[pos] = fresh ? 0.f : c;
+                const int pos = atomicAdd(ARG(dl.tile_count), 1);
+                ARG(dl.tile_list)[pos] = (int)(((s * tiles64 + q * SPL + i) << 1) | (fresh ? 0 : 1));
+                ARG(dl.tile_c)[pos] = fresh ? 0.f : c;
               }
             }
           }
@@ -1067,8 +1127,8 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
           break;
         }
       }
-      if (n_keep > (n0 * 8 >= n_keep ? exh_dense : exh_sparse)) { give_up = true; ++g_cap; break; }
-      if (n_keep <= brute_max) {
+      if (n_keep > (n0 * 8 >= n_keep ? ARG(exh_dense) : ARG(exh_sparse))) { give_up = true; ++g_cap; break; }
+      if (n_keep <= ARG(brute_max)) {
         // ---- few kept points: every sample against every one of them, straight from the compacted list the
         // classification pass left in the stage (broadcast LDS reads, no cell table, no second pass over the
         // candidates).  Cheaper than the cell query's dependent LDS chains while the list is short.
@@ -1097,7 +1157,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
               best[i] = bb;
             }
           }
-          if (stats) n_pairs += (unsigned long long)n_keep * SPL;
+          if (has_stats) n_pairs += (unsigned long long)n_keep * SPL;
         };
         if constexpr (SUPER) {
           for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
@@ -1136,7 +1196,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
         c *= 2.f;
         continue;
       }
-      if (n_keep > CAPW && attempt >= exh_tries) { give_up = true; ++g_cap; break; }  // leave it to the finish
+      if (n_keep > CAPW && attempt >= ARG(exh_tries)) { give_up = true; ++g_cap; break; }  // leave it to the finish
       if (n_keep > CAPW) {
         // ---- too many points for the LDS cell stage: evaluate them exhaustively instead.  The candidates
         // are streamed once more, the kept ones are compacted into LDS (<= CAPW at a time) and every lane
@@ -1191,7 +1251,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
               best[i] = bb;
             }
           }
-          if (stats) n_pairs += (unsigned long long)n_st * SPL;
+          if (has_stats) n_pairs += (unsigned long long)n_st * SPL;
           n_st = 0;
           wave_lds_sync();
 #ifdef FLOODER_PHASE_TIMERS
@@ -1308,14 +1368,17 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
       // than 0), counts as verified, and delivers nothing.  In a dense region the first row of cells (own cell and its
       // two x-neighbours, ~7 points) usually suffices where the exact query looks at all 27 cells (~66 points).
       uint32_t thr_top = 0u;
-      if (dl.drop && acc.face_bits)
+      if (fused && ARG(dl.drop)) {
+        const FaceAcc acc = ARG(acc);
         thr_top = __hip_atomic_load(acc.face_bits + acc.slot_of(s, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const uint32_t* const memb = thr_top != 0u ? ARG(acc.memb) : nullptr;
       auto query_cells = [&]() -> bool {
         bool any_open = false;
   #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           if (open[i]) {
-            const uint32_t thr_i = (thr_top != 0u && acc.memb[row[i]] == 1u) ? thr_top : 0u;
+            const uint32_t thr_i = (thr_top != 0u && memb[row[i]] == 1u) ? thr_top : 0u;
             int ck[DIM];
             float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
   #pragma unroll
@@ -1359,7 +1422,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
               const int last = (lb + gap2[0][2] < b) ? 3 : 2;
               const int bg = s_cell[base + first];
               const int en = s_cell[base + last];
-              if (stats) n_pairs += (unsigned long long)(en - bg);
+              if (has_stats) n_pairs += (unsigned long long)(en - bg);
               // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
               // the list - a minimum over more real points is still a valid upper bound, and exact once verified
               for (int j = bg; j < en; j += 4) {
@@ -1419,6 +1482,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     finalize(false);
     PHASE(10);
 #ifdef FLOODER_PHASE_TIMERS
+    unsigned long long* const stats = ARG(stats);
     if (stats && lane == 0) {  // diagnostic build only: sixteen values per chunk
       stats[64 + 16 * g] = t_chunk0;
       stats[64 + 16 * g + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1429,6 +1493,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(  // (3 waves per SI
     }
 #endif
   }
+  unsigned long long* const stats = ARG(stats);
 #ifdef FLOODER_WAVE_END
   // diagnostic build: when did every wave start and finish?  (plain per-wave stores instead of the shared counters,
   // whose same-address atomics would themselves stretch the end of the kernel)
@@ -1501,10 +1566,18 @@ struct CellOp {
       // ~100 k chunks - cfg 2: 1.290 -> 1.246 ms per step, cfg 3: 4.72 -> 4.69 -, a small loss at cfg 5's 504 k)
       dl.chunk_major = (g_cell_chunk_major && n_chunks <= (int64_t)g_cell_chunk_major_max && n_chunks > ns) ? 1 : 0;
       dl.drop = g_cell_drop;
-#define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                       \
-  hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts, plane_tab, weights, \
-                     k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse, brute_max, g_cell_tries, g_cell_exh_tries, \
-                     g_cell_retry_pct, g_cell_retry_keep, QUEUE_, out, flag_list, flag_count, stats, acc, dl, dg)
+      CellParams cp{pts, nodes, lv, verts, plane_tab, weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse,
+                    brute_max, g_cell_tries, g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list,
+                    flag_count, stats, acc, dl, dg, 0};
+      // blocks of consecutive items per XCD-local queue shard (flood_common.hpp): about a simplex and a half of chunks,
+      // two simplices of runs of four
+      const int qb = g_cell_queue_block;
+#define FLOODER_CELL_LAUNCH(SUPER_, SPL_, QUEUE_)                                                                    \
+  do {                                                                                                               \
+    cp.queue = QUEUE_;                                                                                               \
+    cp.qblk = qb < 0 ? -1 : (SUPER_ ? (qb > 2 ? qb - 2 : 0) : qb);                                                   \
+    hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, cp);                    \
+  } while (0)
       if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         // (split: every simplex is on the heavy list of a short queue - the split kernel was told - and the chunk

@@ -36,6 +36,7 @@ extern int g_cell_chunk_major;    // cell sweep, chunk launch: heavy simplices c
 extern int g_cell_chunk_major_max;  // ... for queues of at most this many chunks
 extern int g_cell_drop;           // cell query drops interior samples that cannot raise the simplex's maximum
 extern int g_cell_one_pass;         // cell sweep: dense chunks are classified and evaluated in ONE pass over their candidates
+extern int g_cell_queue_block;     // cell sweep: log2 of the item blocks of the XCD-local work queue (-1: interleaved items, any XCD)
 extern int g_cell_min_grid;          // ... and the smallest launch  // > 0: the cell sweep reads the local density from the index's density grid where every probed cell holds at least this many points (no first tree walk there); 0: never
 extern int g_sorted_ks;
 extern int g_sorted_blocks;
@@ -139,6 +140,32 @@ __device__ __forceinline__ int64_t queue_pop(int32_t* __restrict__ heads, int& s
     const int64_t item = (int64_t)j * QSHARDS + shard;
     if (item < n_items) return item;
     shard = shard + 1 == QSHARDS ? 0 : shard + 1;
+    ++tried;
+  }
+  return -1;
+}
+
+// ---- the same queue, XCD-local.  The eight XCDs have an L2 each (4 MB, not coherent with the others); items that
+// follow each other in a queue are neighbours in space - the ~20 chunks of a simplex share most of their leaves, the
+// next simplex of the axis-ordered queue many - and the interleaved queue above deals them to all eight L2s (cfg 5:
+// 17 GB of L2 misses per launch for a 256 MB cloud).  Here item blocks of 2^blk CONSECUTIVE items go to the shards in
+// turn, shards 2x and 2x+1 are the home of the waves of XCD x (HW_REG_XCC_ID), and a wave leaves its XCD's shards
+// only when both are dry: j-th pop of shard h -> item ((j >> blk) * QSHARDS + h) << blk | (j & (2^blk - 1)), which
+// grows with j, so a shard is exhausted at the first item past the end.  Shards are visited in the order
+// home ^ 0, 1, 2 ...: the partner shard of the own XCD first, then another XCD's pair, a different one for every XCD.
+__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }  // hwreg(HW_REG_XCC_ID, 0, 4)
+static_assert(FLOODER_QUEUE_SHARDS == 16, "two shards per XCD");
+__device__ __forceinline__ int queue_home_local(int wave_in_block) { return xcc_id() * 2 + (wave_in_block & 1); }
+__device__ __forceinline__ int64_t queue_pop_local(int32_t* __restrict__ heads, int home, int& tried, int64_t n_items, int lane, int blk) {
+  home = __builtin_amdgcn_readfirstlane(home);
+  tried = __builtin_amdgcn_readfirstlane(tried);
+  while (tried < QSHARDS) {
+    const int shard = home ^ tried;
+    int j = 0;
+    if (lane == 0) j = atomicAdd(&heads[shard * QSTRIDE], 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    const int64_t item = ((((int64_t)(j >> blk) * QSHARDS + shard) << blk) | (int64_t)(j & ((1 << blk) - 1)));
+    if (item < n_items) return item;
     ++tried;
   }
   return -1;

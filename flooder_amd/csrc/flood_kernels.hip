@@ -807,6 +807,10 @@ int flooder_set_option(const char* name, int value) {
     g_cell_one_pass = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_queue_block") == 0 && value >= -1 && value <= 12) {
+    g_cell_queue_block = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_min_grid") == 0 && value >= 1) {
     g_cell_min_grid = value;
     return FLOODER_OK;

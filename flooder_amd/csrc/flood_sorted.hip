@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
 
 #ifdef FLOODER_SORTED_TIMERS
   // diagnostic build: cycles per phase (s_memtime), summed over the waves into stats[4..9], refine passes in stats[10]
-  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime(), n_refine = 0;
+  unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, ts_prev = __builtin_amdgcn_s_memtime(), n_refine = 0;
   unsigned long long n_groups = 0, n_groups_empty = 0, n_groups_idle = 0;
   int evals_in_group = 0;
-#define SPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts[i] += t_ - ts_prev; ts_prev = t_; } while (0)
+#define SPHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_ph[i] += t_ - ts_prev; ts_prev = t_; } while (0)
 #else
 #define SPHASE(i) do { } while (0)
 #endif
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, (KS == 1 && !FUSED && DIM <= 6) ? FLOODER_SORT
     atomicAdd(&stats[1], n_leaf_test);
     atomicAdd(&stats[2], n_node_test);
 #ifdef FLOODER_SORTED_TIMERS
-    for (int i = 0; i < 6; ++i) atomicAdd(&stats[4 + i], ts[i]);
+    for (int i = 0; i < 6; ++i) atomicAdd(&stats[4 + i], t_ph[i]);
     atomicAdd(&stats[10], n_refine);
     atomicAdd(&stats[11], n_groups);
     atomicAdd(&stats[12], n_groups_empty);

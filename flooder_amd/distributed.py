@@ -53,8 +53,11 @@ def shard_points(points: torch.Tensor, rank: int, world_size: int) -> torch.Tens
     return points[rank::world_size].contiguous()
 
 
-def min_reduce_hook(group: Optional[dist.ProcessGroup] = None):
+def min_reduce_hook(group: Optional[dist.ProcessGroup] = None, always: bool = False):
     """``reduce_hook`` for ``flood_complex``: in-place ``all_reduce(MIN)`` over the process group.
+
+    ``always``: issue the collective also on a group of ONE rank (where it changes nothing) - the way the RCCL
+    path is exercised on a single GPU: ``tests/test_distributed_gpu.py::test_rccl_world_size_one``.
 
     On ROCm tensors the buffer holds bit patterns of non-negative squared distances, for which integer order ==
     numeric order: int32 words of float32 values (+inf = 0x7f800000) for float32 inputs, int64 words of float64
@@ -64,25 +67,25 @@ def min_reduce_hook(group: Optional[dist.ProcessGroup] = None):
     """
 
     def hook(buf: torch.Tensor) -> None:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
             dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=group)
 
     return hook
 
 
-def global_widest_axis(points_shard: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> int:
+def global_widest_axis(points_shard: torch.Tensor, group: Optional[dist.ProcessGroup] = None, always: bool = False) -> int:
     """Axis of largest extent of the WHOLE cloud (what ``core.py:140-142`` computes on one device),
     from per-shard extrema combined with two tiny all-reduces, so that every rank sorts its simplices
     the same way."""
     lo = points_shard.min(dim=0).values.to(torch.float32)
     hi = points_shard.max(dim=0).values.to(torch.float32)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     return int(torch.argmax(hi - lo).item())
 
 
-def sync_cpu_rng(device: torch.device, group: Optional[dist.ProcessGroup] = None, src: int = 0) -> None:
+def sync_cpu_rng(device: torch.device, group: Optional[dist.ProcessGroup] = None, src: int = 0, always: bool = False) -> None:
     """Give every rank rank ``src``'s global CPU generator state.
 
     ``generate_uniform_weights`` (``core.py:405-427`` of the reference) draws the random barycentric
@@ -91,7 +94,7 @@ def sync_cpu_rng(device: torch.device, group: Optional[dist.ProcessGroup] = None
     sampled with the weights an unsharded run would use, so the generator state is broadcast (about 5 KB)
     before the weights are drawn: the result equals the unsharded result under rank ``src``'s seed,
     whatever the other ranks' generators held."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1)):
         return
     state = torch.get_rng_state()
     buf = state.to(device) if device.type == "cuda" else state.clone()
@@ -100,7 +103,7 @@ def sync_cpu_rng(device: torch.device, group: Optional[dist.ProcessGroup] = None
 
 
 def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, mode: str = "simplices",
-                          group: Optional[dist.ProcessGroup] = None, **kwargs):
+                          group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False, **kwargs):
     """``flood_complex`` over all ranks of ``group``; every rank returns the full result.
 
     ``mode="simplices"``: ``points`` is the FULL cloud on every rank, simplices are interleaved over the
@@ -110,17 +113,17 @@ def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, 
 
     With ``num_rand`` the sample weights come from the global CPU generator; rank 0's generator state is
     broadcast first (``sync_cpu_rng``), so seeding rank 0 is enough and the result equals the unsharded
-    one under that seed."""
+    one under that seed.  ``always_reduce``: run the collectives on a one-rank group too (``min_reduce_hook``)."""
     if not isinstance(landmarks, torch.Tensor):
         raise TypeError("flood_complex_sharded needs explicit landmark coordinates (identical on every "
                         "rank); run generate_landmarks on the full cloud first")
     num_rand = kwargs.get("num_rand", args[2] if len(args) > 2 else None)
     if num_rand is not None:
-        sync_cpu_rng(points.device, group)
+        sync_cpu_rng(points.device, group, always=always_reduce)
     if mode == "points":
-        axis = global_widest_axis(points, group)
-        return flood_complex(points, landmarks, *args, reduce_hook=min_reduce_hook(group), sort_axis=axis,
-                             **kwargs)
+        axis = global_widest_axis(points, group, always_reduce)
+        return flood_complex(points, landmarks, *args, reduce_hook=min_reduce_hook(group, always_reduce),
+                             sort_axis=axis, **kwargs)
     if mode not in ("simplices", "blocks"):
         raise ValueError("mode must be 'simplices', 'blocks' or 'points'")
     if dist.is_available() and dist.is_initialized():
@@ -128,4 +131,4 @@ def flood_complex_sharded(points: torch.Tensor, landmarks: torch.Tensor, *args, 
     else:
         rank, world = 0, 1
     return flood_complex(points, landmarks, *args, simplex_shard=(rank, world), shard_blocks=(mode == "blocks"),
-                         face_reduce_hook=min_reduce_hook(group), **kwargs)
+                         face_reduce_hook=min_reduce_hook(group, always_reduce), **kwargs)

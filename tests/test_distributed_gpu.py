@@ -193,3 +193,100 @@ def test_tile_shards_of_the_sorted_sweep_one_after_the_other_equal_unsharded(dim
         got2, used2 = run(False)
         assert all(u is None for u in used2)
         assert [got2[k] for k in keys] == [want[k] for k in keys]
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """One rank, backend "nccl" (= RCCL on ROCm), the device bound at init as bench.py does."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from flooder_amd import _native, core
+        from flooder_amd.distributed import flood_complex_sharded, shard_points
+        from helpers import load_e2e
+
+        _native.load()
+        assert dist.get_backend() == "nccl"
+        # the collectives of the three modes, on the dtypes they are issued with, through RCCL itself
+        for t, op in ((torch.tensor([3, 0x7f800000, 5], dtype=torch.int32, device=dev), dist.ReduceOp.MIN),
+                      (torch.tensor([3, 0x7ff0000000000000], dtype=torch.int64, device=dev), dist.ReduceOp.MIN),
+                      (torch.tensor([-1.5, -0.0, float("-inf")], dtype=torch.float32, device=dev), dist.ReduceOp.MIN),
+                      (torch.tensor([1.5, float("inf")], dtype=torch.float32, device=dev), dist.ReduceOp.MAX)):
+            want = t.clone()
+            dist.all_reduce(t, op=op)
+            assert torch.equal(t.view(torch.int64 if t.dtype == torch.int64 else torch.int32),
+                               want.view(torch.int64 if t.dtype == torch.int64 else torch.int32)), (t, want)
+        res = {}
+        for name in ("torus3d_grid30", "eight2d_rand", "gauss6d_maxdim2"):
+            if name.startswith("gauss6d"):   # (small: let the sorted-sample sweep and its tile sharding run all the same)
+                core.BVH_SORTED_MIN_SAMPLES = 0
+            z, kw, keys = load_e2e(name)
+            pts = torch.as_tensor(z["points"], device=dev)
+            lms = torch.as_tensor(z["landmarks"], device=dev)
+            for mode in ("simplices", "points", "blocks"):
+                torch.manual_seed(int(z["weight_seed"]))
+                p = shard_points(pts, rank, world) if mode == "points" else pts
+                fc = flood_complex_sharded(p, lms, mode=mode, always_reduce=True, **kw)
+                res[f"{name}/{mode}"] = np.array([fc[k] for k in keys])
+        # float64 inputs: the (S, R) int64 bit patterns through MIN
+        z, kw, keys = load_e2e("torus3d_grid30")
+        fc = flood_complex_sharded(torch.as_tensor(z["points"], device=dev).double(), torch.as_tensor(z["landmarks"], device=dev).double(),
+                                   mode="points", always_reduce=True, **kw)
+        res["torus3d_grid30/points_f64"] = np.array([fc[k] for k in keys])
+        np.savez(os.path.join(out_dir, "rccl.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one(tmp_path):
+    """RCCL itself, on the one GPU there is: a world of ONE rank with backend "nccl" and ``device_id`` at init (what
+    ``bench.py`` does on an 8-GPU node), every collective of the sharded path forced to run (``always_reduce``) -
+    ``all_reduce(MIN)`` on int32 / int64 bit patterns (``mode="points"``, float32 and float64 inputs), on the float32
+    (S, F) matrix (``"simplices"``, ``"blocks"``) and on the negated matrix of the tile shards above 3D, MIN / MAX of
+    the cloud's extent, the generator-state broadcast.  Results must be the unsharded ones bit for bit."""
+    import warnings
+
+    import flooder_amd as fa
+    from flooder_amd import core
+
+    assert torch.cuda.is_available()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "rccl.npz")
+    dev = torch.device("cuda:0")
+    keep = core.BVH_SORTED_MIN_SAMPLES
+    try:
+        for name in ("torus3d_grid30", "eight2d_rand", "gauss6d_maxdim2"):
+            if name.startswith("gauss6d"):
+                core.BVH_SORTED_MIN_SAMPLES = 0
+            z, kw, keys = load_e2e(name)
+            torch.manual_seed(int(z["weight_seed"]))
+            full = fa.flood_complex(torch.as_tensor(z["points"], device=dev), torch.as_tensor(z["landmarks"], device=dev), **kw)
+            want = np.array([full[k] for k in keys])
+            for mode in ("simplices", "points", "blocks"):
+                assert np.array_equal(got[f"{name}/{mode}"], want), (name, mode)
+        z, kw, keys = load_e2e("torus3d_grid30")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            full = fa.flood_complex(torch.as_tensor(z["points"], device=dev).double(), torch.as_tensor(z["landmarks"], device=dev).double(), **kw)
+        assert np.array_equal(got["torus3d_grid30/points_f64"], np.array([full[k] for k in keys]))
+    finally:
+        core.BVH_SORTED_MIN_SAMPLES = keep
+
+
+def test_block_shards_refuse_landmarks_off_the_cloud():
+    """``shard_blocks`` is exact only for landmarks that are rows of the cloud (a block's sub-cloud holds the rows inside
+    its bounding balls): anything else is refused instead of answered with values that are too large."""
+    import flooder_amd as fa
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    pts = torch.randn(20_000, 3, generator=g).to(dev)
+    lms = fa.generate_landmarks(pts, 40, start_idx=0)
+    fa.flood_complex(pts, lms, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True)
+    with pytest.raises(ValueError, match="rows of `points`"):
+        fa.flood_complex(pts, lms + 1e-3, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True)

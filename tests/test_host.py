@@ -338,3 +338,48 @@ def test_gudhi_branches_with_a_stub_module(monkeypatch):
     torch.manual_seed(1)
     want_r = fa.flood_complex(pts, lms, num_rand=50)
     assert set(got_r) == set(want_r) and all(abs(got_r[k] - want_r[k]) <= 1e-12 for k in want_r)
+
+
+def test_index_source_version_of_inference_tensors():
+    """Tensors created under ``torch.inference_mode()`` keep no version counter (``_version`` raises): the staleness
+    check of ``index=`` is skipped for them instead of crashing every GPU call."""
+    from flooder_amd import core
+
+    with torch.inference_mode():
+        t = torch.randn(8, 3)
+    assert core._tensor_version(t) is None
+    u = torch.randn(8, 3)
+    v0 = core._tensor_version(u)
+    u.add_(1.0)
+    assert core._tensor_version(u) == v0 + 1
+
+
+def test_rows_are_subset_is_bit_exact():
+    from flooder_amd import core
+
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(5000, 3, generator=g)
+    assert core._rows_are_subset(p[::97], p)
+    assert core._rows_are_subset(p[:0], p)
+    q = p[::97].clone()
+    q[3, 1] = torch.nextafter(q[3, 1], torch.tensor(10.0))
+    assert not core._rows_are_subset(q, p)
+    z = torch.zeros(1, 3)
+    assert core._rows_are_subset(-z, torch.cat([p, z]))   # (-0.0 is the row 0.0)
+
+
+def test_sample_plan_builds_its_host_side_tables_on_demand(monkeypatch):
+    """The witness plan and the pilot rows cost host work (cKDTree, a device sync) and one sweep each reads them:
+    nothing is built until asked for (a ``num_rand`` call never asks)."""
+    from flooder_amd import core
+
+    calls = []
+    orig = core.witness_plan
+    monkeypatch.setattr(core, "witness_plan", lambda w, perm: calls.append(1) or orig(w, perm))
+    w, _, fi = core.generate_grid(14, 3, torch.device("cpu"), torch.float32)
+    plan = core.SamplePlan(w, core._FaceTable(fi, w.shape[0], torch.device("cpu")))
+    assert calls == [] and plan._late_rows is None
+    assert plan.wit is not None and calls == [1]
+    assert plan.wit is not None and calls == [1]          # (cached)
+    late = plan.late_rows
+    assert late is not None and int((late == 0).sum()) <= plan.faces.n_faces

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / LDS / spill figures of the kernels of one source: tools/kernel_resources.sh flood_wit.hip [name filter] [extra hipcc flags]
-SRC=flooder_amd/csrc/$1; FLT=${2:-}; shift 2
+SRC=flooder_amd/csrc/$1; FLT=${2:-}; shift; [ $# -gt 0 ] && shift
 T=$(mktemp -d)
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DFLOODER_BUILD "$@" --cuda-device-only -c $SRC -o $T/dev.bundle 2>/dev/null || { echo "compile failed"; exit 1; }
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/dev.bundle --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/dev.co
