@@ -29,13 +29,23 @@ using namespace flooder;
 namespace {
 
 constexpr int SPL_CHUNK = 4;      // samples per lane of a chunk item (256 samples per wave)
-constexpr int CAPW = 480;         // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
-constexpr int MAXLEAF = 896;      // leaves gathered per wave item (14 K points before filtering)
+#ifndef FLOODER_CELL_CAPW
+#define FLOODER_CELL_CAPW 480
+#endif
+#ifndef FLOODER_CELL_MAXLEAF
+#define FLOODER_CELL_MAXLEAF 584
+#endif
+#ifndef FLOODER_CELL_WAVES
+#define FLOODER_CELL_WAVES 4
+#endif
+constexpr int CAPW = FLOODER_CELL_CAPW;  // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
+constexpr int MAXLEAF = FLOODER_CELL_MAXLEAF;  // leaves gathered per wave item (896: 14 K points before filtering)
 constexpr int MAXFRONT = 192;     // inner nodes per level of the gather
 constexpr int MAX_TRIES = 3;      // cell sizes tried per chunk at most (option cell_tries)
 constexpr int EXH_MAX = 4 * CAPW;         // kept points evaluated exhaustively at most (sparse chunk box)
 constexpr int UNR = 4;            // candidate rows in flight per lane in the staging loops
-constexpr int BRUTE_CAP = CAPW - CAPW / 4 - 4;  // compacted points the classification pass may leave in the stage
+constexpr int KEEP0 = CAPW - CAPW / 3;      // first stage slot under the kept-candidate list (its CAPW ints = a third of the stage)
+constexpr int BRUTE_CAP = KEEP0 - 4;  // compacted points the classification pass may leave in the stage
 
 // Density grid of the cloud (flooder_density_grid_f32: G^DIM point counts over the cloud's box).  Where its cells are
 // well filled a chunk reads the local density from the cells under its box - nine loads - instead of walking the
@@ -83,18 +93,34 @@ __device__ __forceinline__ void load_row_at(const float* __restrict__ base, uint
   load_row<DP>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)byte_off), out);
 }
 
-// One staged point (x, y, z, -) from LDS.  The fourth word is not needed and the compiler reads 12 bytes
-// (ds_read_b96).  Forcing the 16-byte read (-DFLOODER_LDS_B128: .w kept "used" by an empty asm statement) halves the
-// LDS cycles per instruction on paper and measured SLOWER: sweep 1.46 vs 1.38 ms (cfg 2), 2.54 vs 2.48 (cfg 3), 8.93
-// vs 8.61 (cfg 5) - the LDS array is busy 14 % of the kernel (SQ_LDS_IDX_ACTIVE), the query waits on latency, not on
-// LDS bandwidth, and the extra live register per point in flight costs more than the cycles save.
-__device__ __forceinline__ float4 lds_point(const float4* p) {
-  const float4 v = *p;
-#ifdef FLOODER_LDS_B128
-  asm volatile("" ::"v"(v.w));
-#endif
-  return v;
-}
+// The point stage in LDS: blocks of FOUR points, 48 bytes each - x[4], y[4], z[4] - 12 bytes per point instead of a
+// padded 16-byte row.  Four consecutive points are three 16-byte reads (they were four 12-byte ones), and the stage of
+// a wave shrinks by a quarter: with it the kernel's LDS fits FOUR workgroups per CU (40 KB each) where 13 KB per wave
+// allowed three - the sweep is bound by issue + dependent latency and a fourth wave per SIMD is worth 14 - 20 % of it.
+// Readers take whole blocks: a list that starts inside a block is read from the block's start (the extra entries are
+// real points of an earlier cell or list: a minimum over more real points is still a valid upper bound, and exact once
+// verified), and up to three entries past a list's end are real points or the +inf pads behind it.
+struct Stage {
+  float* b;
+  __device__ __forceinline__ void put(int slot, float x, float y, float z) const {
+    float* q = b + (slot >> 2) * 12 + (slot & 3);
+    q[0] = x;
+    q[4] = y;
+    q[8] = z;
+  }
+  __device__ __forceinline__ void pad(int n, int lane) const {  // four +inf entries behind a list of n
+    if (lane < 4) put(n + lane, __builtin_inff(), __builtin_inff(), __builtin_inff());
+  }
+  // points j .. j+3, j a multiple of four (.w unused)
+  __device__ __forceinline__ void get4(int j, float4 (&x)[4]) const {
+    const float4* q = reinterpret_cast<const float4*>(b + (j >> 2) * 12);
+    const float4 X = q[0], Y = q[1], Z = q[2];
+    x[0] = make_float4(X.x, Y.x, Z.x, 0.f);
+    x[1] = make_float4(X.y, Y.y, Z.y, 0.f);
+    x[2] = make_float4(X.z, Y.z, Z.z, 0.f);
+    x[3] = make_float4(X.w, Y.w, Z.w, 0.f);
+  }
+};
 
 __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -281,7 +307,7 @@ __global__ __launch_bounds__(256) void simplex_planes_kernel(const float* __rest
 // whose neighbourhood does not fit the stage, and chunks that keep open samples (they would need a larger cell
 // size, i.e. a new stage), are appended to a deferred list that a SUPER = false launch works off chunk by chunk.
 template <int DIM, bool SUPER, int SPLV>
-__global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_the_kernarg_segment) {  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
+__global__ __launch_bounds__(256, FLOODER_CELL_WAVES) void cell_sweep_kernel(CellParams args_in_the_kernarg_segment) {  // (3 waves per SIMD: what the 13 KB of LDS per wave allow)
   // Launch-invariant arguments that the whole item loop needs (the rest: ARG(field) where it is used)
   const int R = ARG(R), k1 = ARG(k1);
   const bool has_stats = ARG(stats) != nullptr, fused = ARG(acc.face_bits) != nullptr;
@@ -298,20 +324,20 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
   // it holds and this kernel is short of them.  Two lists live inside the point stage while it holds no points:
   // the gather's frontier (first 1.5 KB, gather phase only) and the kept-candidate list of the classification
   // pass (last quarter; read completely into registers before the first point is scattered).
-  __shared__ float4 s_pts_all[4][CAPW + 4];  // (+4: the unrolled readers run up to three entries past a list's end)
+  __shared__ __attribute__((aligned(16))) float s_pts_all[4][(CAPW + 4) * 3];  // (+4: the readers run up to three entries past a list's end)
   __shared__ uint32_t s_cell_all[4][(NC + 8) / 2];
   __shared__ int s_leaf_all[4][MAXLEAF];
-  static_assert(2 * MAXFRONT * sizeof(int) + CAPW * sizeof(int) <= CAPW * sizeof(float4), "aliases fit the stage");
-  static_assert(CAPW % 4 == 0 && CAPW <= 512, "kept-list alias and the 10-bit cell field");
+  static_assert(2 * MAXFRONT * sizeof(int) <= KEEP0 * 12, "the frontier alias ends below the kept list");
+  static_assert(CAPW % 12 == 0 && KEEP0 % 4 == 0 && CAPW <= 512, "kept-list alias on a block boundary and the 10-bit cell field");
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  float4* s_pts = s_pts_all[wv];
+  const Stage s_pts{s_pts_all[wv]};
   uint32_t* s_cell32 = s_cell_all[wv];
   const uint16_t* s_cell = reinterpret_cast<const uint16_t*>(s_cell32);  // [i+1]: count -> start -> end of cell i
   uint16_t* s_cell_w = reinterpret_cast<uint16_t*>(s_cell32);
   int* s_leaf = s_leaf_all[wv];
-  int* s_keep = reinterpret_cast<int*>(s_pts + (CAPW - CAPW / 4));  // (candidate slot << 10) | cell
-  int* s_front = reinterpret_cast<int*>(s_pts);
+  int* s_keep = reinterpret_cast<int*>(s_pts.b + KEEP0 * 3);  // (candidate slot << 10) | cell
+  int* s_front = reinterpret_cast<int*>(s_pts.b);
   // entry i of the 16-bit cell table: word i >> 1, half i & 1 (counts stay below 2^16: no carry into the neighbour)
   auto cell_add = [&](int i) -> int {
     const int sh = (i & 1) * 16;
@@ -972,15 +998,14 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
       bool one_pass = false;
       int n_st = 0, n_rec = 0, ib_resume = 0;
       bool decided = false;
-      constexpr int CAPE = CAPW - CAPW / 4 - 4;  // stage entries below the kept-list alias (and four of padding)
-      static_assert(CAPE >= 64 * UNR + 64, "a batch of candidate rows fits the part of the stage below the kept list");
+      constexpr int CAPE = KEEP0 - 4;  // stage entries below the kept-list alias (and four of padding)
+      static_assert(CAPE >= 64 * UNR + 32, "a batch of candidate rows fits the part of the stage below the kept list");
       auto flush_stage = [&]() {
-        if (lane < 4) s_pts[n_st + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+        s_pts.pad(n_st, lane);
         wave_lds_sync();
         for (int j = 0; j < n_st; j += 4) {
           float4 x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
+s_pts.get4(j, x);
 #pragma unroll
           for (int i = 0; i < SPL; ++i) {
             float bb = best[i];
@@ -1006,12 +1031,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
       auto stage_row = [&](const float (&x)[DP], bool k) {
         const unsigned long long m = __ballot(k);
         if (k) {
-          float4 v;
-          v.x = x[0];
-          v.y = x[1];
-          v.z = DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f;
-          v.w = 0.f;
-          s_pts[n_st + lane_rank(m)] = v;
+          s_pts.put(n_st + lane_rank(m), x[0], x[1], DIM > 2 ? x[DIM > 2 ? 2 : 0] : 0.f);
         }
         n_st += __popcll(m);
         return __popcll(m);
@@ -1038,12 +1058,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
             const int slot = n_keep + lane_rank(m);
             if (slot < CAPW) s_keep[slot] = (idx << 10) | cid;
             if (slot < BRUTE_CAP) {  // (below the kept-list alias) small sets are evaluated straight from here
-              float4 v;
-              v.x = x[u][0];
-              v.y = x[u][1];
-              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-              v.w = 0.f;
-              s_pts[slot] = v;
+              s_pts.put(slot, x[u][0], x[u][1], DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f);
             }
           }
           n_keep += __popcll(m);
@@ -1132,13 +1147,12 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
         // ---- few kept points: every sample against every one of them, straight from the compacted list the
         // classification pass left in the stage (broadcast LDS reads, no cell table, no second pass over the
         // candidates).  Cheaper than the cell query's dependent LDS chains while the list is short.
-        if (lane < 4) s_pts[n_keep + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+        s_pts.pad(n_keep, lane);
         wave_lds_sync();
         auto brute_eval = [&]() {
           for (int j = 0; j < n_keep; j += 4) {
             float4 x[4];
-  #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
+  s_pts.get4(j, x);
   #pragma unroll
             for (int i = 0; i < SPL; ++i) {
               float bb = best[i];
@@ -1227,12 +1241,11 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
 #ifdef FLOODER_PHASE_TIMERS
           const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
 #endif
-          if (lane < 4) s_pts[n_st + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+          s_pts.pad(n_st, lane);
           wave_lds_sync();
           for (int j = 0; j < n_st; j += 4) {
             float4 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
+s_pts.get4(j, x);
 #pragma unroll
             for (int i = 0; i < SPL; ++i) {
               float bb = best[i];
@@ -1282,12 +1295,7 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
             keep[u] = keep[u] && keep_point(x[u]);
             const unsigned long long m = __ballot(keep[u]);
             if (keep[u]) {
-              float4 v;
-              v.x = x[u][0];
-              v.y = x[u][1];
-              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-              v.w = 0.f;
-              s_pts[n_st + lane_rank(m)] = v;
+              s_pts.put(n_st + lane_rank(m), x[u][0], x[u][1], DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f);
             }
             n_st += __popcll(m);
           }
@@ -1345,17 +1353,12 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
           for (int u = 0; u < UNR; ++u) {
             if (ent[h + u] >= 0) {
               const int pos = cell_add((ent[h + u] & 1023) + 1);
-              float4 v;
-              v.x = x[u][0];
-              v.y = x[u][1];
-              v.z = DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f;
-              v.w = 0.f;
-              s_pts[pos] = v;
+              s_pts.put(pos, x[u][0], x[u][1], DIM > 2 ? x[u][DIM > 2 ? 2 : 0] : 0.f);
             }
           }
         }
       }
-      if (lane < 4) s_pts[total + lane] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+      s_pts.pad(total, lane);
       wave_lds_sync();
       n_staged += (unsigned long long)total;
       if (attempt > 0) ++n_retries;
@@ -1425,10 +1428,9 @@ __global__ __launch_bounds__(256, 3) void cell_sweep_kernel(CellParams args_in_t
               if (has_stats) n_pairs += (unsigned long long)(en - bg);
               // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
               // the list - a minimum over more real points is still a valid upper bound, and exact once verified
-              for (int j = bg; j < en; j += 4) {
+              for (int j = bg & ~3; j < en; j += 4) {
                 float4 x[4];
-  #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = lds_point(s_pts + j + u);
+  s_pts.get4(j, x);
   #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   float t0 = p[i][0] - x[u].x;
