@@ -262,6 +262,7 @@ def main():
     # loads, allocator, first PointIndex); warm = the same call again (it builds its own PointIndex where the
     # bucketed path runs); ready = with a PointIndex of the cloud passed in, as flood_complex(points, int) does
     def timed_fps(**kw):
+        core.forget_index()      # (every call sees a fresh cloud: no PointIndex remembered from the call before)
         torch.cuda.synchronize()
         t0_ = time.perf_counter()
         out_ = fa.generate_landmarks(pts_full, w["n_lms"], start_idx=0, **kw)
@@ -504,6 +505,7 @@ def main():
         def wall(fn, reps=3):
             ts = []
             for _ in range(reps):
+                core.forget_index()   # (a fresh cloud every call: the index build is part of what is timed)
                 torch.cuda.synchronize()
                 t0_ = time.perf_counter()
                 r_ = fn()

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
+PY_LIB = os.path.join(PKG_DIR, "libflooder_py.so")   # CPython-API helpers (loaded with ctypes.PyDLL)
 
 HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
 HOST_SOURCES = ["persistence.cpp"]
@@ -98,7 +99,28 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return HOST_LIB
 
 
+def build_py(force: bool = False, verbose: bool = False) -> str:
+    """The dict hand-off (csrc/pyhandoff.c): plain C against this interpreter's headers; no libpython link - the
+    symbols resolve in the running interpreter."""
+    import sysconfig
+
+    src = os.path.join(CSRC, "pyhandoff.c")
+    if not force and _newer(PY_LIB, [src]):
+        return PY_LIB
+    cc = shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths()["include"]
+    if cc is None or not os.path.exists(os.path.join(inc, "Python.h")):
+        return ""   # (no compiler or no headers: simplex_tree.to_dict falls back to the Python loop)
+    cmd = [cc, "-O2", "-shared", "-fPIC", f"-I{inc}", "-o", PY_LIB + ".tmp", src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(PY_LIB + ".tmp", PY_LIB)
+    return PY_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False):
+    build_py(force, verbose)
     return build_hip(force, verbose), build_host(force, verbose)
 
 

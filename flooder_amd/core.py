@@ -30,6 +30,7 @@ The (S, R, dim) tensor of sample points the reference materialises (``core.py:18
 from __future__ import annotations
 
 import itertools
+import weakref
 import warnings
 from numbers import Integral
 from typing import Callable, Dict, List, Optional, Tuple, Union
@@ -168,11 +169,15 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
         if method == "bucket" and (FPS_BATCHED or dim > 3) and n > int(lib.flooder_fps_batched_max_points()):
             method = "bucket" if dim <= 3 else "brute"     # (one landmark per launch / brute force beyond 16 M points)
             if dim <= 3:
-                return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx)
+                return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, points)
         if method == "bucket" and (FPS_BATCHED or dim > 3):
             global LAST_FPS_LAUNCHES
             import ctypes
-            index = index if index is not None else PointIndex(pts)
+            if index is None:
+                index = _recall_index(points)
+                if index is None:
+                    index = PointIndex(pts)
+                    _remember_index(points, index)
             nb = int(lib.flooder_fps_bucket_count(n))
             dp = index.dp
             minsq = torch.empty(n, dtype=torch.float32, device=pts.device)
@@ -197,7 +202,7 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
                                      words=12 + max(dp, 4))
             return out_idx
         if method == "bucket":
-            return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx)
+            return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, points)
         work_min = torch.empty(4 * n, dtype=torch.float32, device=pts.device)
         work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
         with torch.cuda.device(pts.device):
@@ -218,9 +223,14 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
     return torch.as_tensor(idx, device=points.device)
 
 
-def _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx):
+def _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, source=None):
     """``flooder_fps_indexed_f32``: bucketed exact FPS, one launch per landmark (dim <= 3)."""
-    index = index if index is not None else PointIndex(pts)
+    if index is None:
+        index = _recall_index(source) if source is not None else None
+        if index is None:
+            index = PointIndex(pts)
+            if source is not None:
+                _remember_index(source, index)
     nb = int(lib.flooder_fps_bucket_count(n))
     rows = torch.empty(4 * index.pts.shape[0], dtype=torch.float32, device=pts.device)
     box = torch.empty(8 * nb, dtype=torch.float32, device=pts.device)
@@ -513,6 +523,38 @@ def _tensor_version(t: torch.Tensor):
         return None if t.is_inference() else t._version
     except RuntimeError:
         return None
+
+
+# The last PointIndex built from a caller's tensor (generate_landmarks / flood_complex), remembered by the IDENTITY of
+# that tensor (a weak reference: a freed tensor's address can be handed to another one) and its version counter:
+#     lms = generate_landmarks(points, 1000); flood_complex(points, lms)        # the second call reuses the index
+# - and so does every rank of flood_complex_sharded, where the replicated index build is the part that does not divide
+# (16 M points: 0.97 ms of a 3 ms rank step).  One entry; INDEX_CACHE = False switches it off.
+INDEX_CACHE = True
+_LAST_INDEX: List = [None, None, None]   # weakref to the source tensor, its version, the PointIndex
+
+
+def _remember_index(points: torch.Tensor, index: "PointIndex") -> None:
+    ver = _tensor_version(points)
+    if INDEX_CACHE and ver is not None:
+        try:
+            _LAST_INDEX[:] = [weakref.ref(points), ver, index]
+        except TypeError:
+            _LAST_INDEX[:] = [None, None, None]
+
+
+def _recall_index(points: torch.Tensor) -> Optional["PointIndex"]:
+    ref, ver, index = _LAST_INDEX
+    if (INDEX_CACHE and ref is not None and ref() is points and ver == _tensor_version(points)
+            and (index.n, index.dim) == tuple(points.shape) and index.pts.device == points.device
+            and index.kd == (index.dim > KD_ORDER_ABOVE_DIM and index.n > BVH_LEAF)):   # (the row order asked for now)
+        return index
+    return None
+
+
+def forget_index() -> None:
+    """Drop the remembered PointIndex (it keeps a padded, sorted copy of the last cloud alive: 16 B per 3-D point)."""
+    _LAST_INDEX[:] = [None, None, None]
 
 
 class PointIndex:
@@ -1350,7 +1392,10 @@ def flood_complex(
     if isinstance(landmarks, Integral):
         if (shared_index is None and points.is_cuda and method != "ball" and points.shape[1] <= FPS_BUCKET_MAX_DIM and points.dtype in SUPPORTED_DTYPES
                 and _has_hip_kernels() and points.shape[0] >= FPS_BUCKET_MIN_POINTS and landmarks > 64):
-            shared_index = PointIndex(points.to(torch.float32))
+            shared_index = _recall_index(points)
+            if shared_index is None:
+                shared_index = PointIndex(points.to(torch.float32))
+                _remember_index(points, shared_index)
         landmarks = generate_landmarks(points, min(landmarks, points.shape[0]), fps_h, start_idx=start_idx,
                                        index=shared_index)
     if landmarks.device != points.device:
@@ -1397,7 +1442,13 @@ def flood_complex(
     elif on_gpu and method != "ball":
         # the curve sort + box tree run on the GPU while the host triangulates the landmarks
         pts32 = points.to(torch.float32)
-        index = shared_index if shared_index is not None else PointIndex(pts32)
+        if shared_index is None:
+            shared_index = _recall_index(points)     # (the index generate_landmarks built from this very tensor)
+        if shared_index is not None:
+            index = shared_index
+        else:
+            index = PointIndex(pts32)
+            _remember_index(points, index)
         if use_f64:  # the float64 rows in the order of the (float32) index
             lib_ = _native.load()
             pts64_sorted = torch.empty((index.pts.shape[0], index.dp), dtype=torch.float64, device=device)

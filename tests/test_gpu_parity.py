@@ -874,3 +874,49 @@ def test_index_of_a_modified_cloud_is_refused(dev):
     pts.mul_(1.5)
     with pytest.raises(ValueError, match="modified in place"):
         fa.flood_complex(pts, lms, points_per_edge=6, index=idx)
+
+
+def test_the_index_of_generate_landmarks_is_reused_by_flood_complex(dev, monkeypatch):
+    """``lms = generate_landmarks(points, n); flood_complex(points, lms)``: the second call takes the PointIndex the
+    first one built from the SAME tensor object (identity + version counter; one entry) - on every rank of a sharded
+    run the replicated index build is the part that does not divide.  Another tensor, an in-place write, an inference
+    tensor or ``forget_index`` rebuild it; the values are the same either way."""
+    g = torch.Generator().manual_seed(21)
+    pts = torch.randn(200_000, 3, generator=g).to(dev)
+    built = []
+    orig = core.PointIndex.__init__
+
+    def spy(self, *a, **k):
+        built.append(1)
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(core.PointIndex, "__init__", spy)
+    core.forget_index()
+    lms = fa.generate_landmarks(pts, 150, start_idx=0)
+    assert len(built) == 1
+    a = fa.flood_complex(pts, lms, points_per_edge=8)
+    assert len(built) == 1, "flood_complex rebuilt the index generate_landmarks had just built"
+    b = fa.flood_complex(pts.clone(), lms, points_per_edge=8)          # another tensor: its own index
+    assert len(built) == 2 and a == b
+    c = fa.flood_complex(pts, lms, points_per_edge=8)                  # (one entry: the clone's index replaced it)
+    assert len(built) == 3 and a == c
+    pts.add_(0.0)                                                      # in-place write: version counter moves
+    fa.flood_complex(pts, lms, points_per_edge=8)
+    assert len(built) == 4
+    fa.flood_complex(pts, lms, points_per_edge=8)
+    assert len(built) == 4
+    core.forget_index()
+    fa.flood_complex(pts, lms, points_per_edge=8)
+    assert len(built) == 5
+    with torch.inference_mode():                                       # no version counter: never remembered, never crashes
+        pin = torch.randn(100_000, 3, generator=g).to(dev)
+        lin = fa.generate_landmarks(pin, 80, start_idx=0)
+        n0 = len(built)
+        fa.flood_complex(pin, lin, points_per_edge=6)
+        assert len(built) == n0 + 1
+    monkeypatch.setattr(core, "INDEX_CACHE", False)
+    core.forget_index()
+    fa.flood_complex(pts, lms, points_per_edge=8)
+    n1 = len(built)
+    fa.flood_complex(pts, lms, points_per_edge=8)
+    assert len(built) == n1 + 1

@@ -383,3 +383,27 @@ def test_sample_plan_builds_its_host_side_tables_on_demand(monkeypatch):
     assert plan.wit is not None and calls == [1]          # (cached)
     late = plan.late_rows
     assert late is not None and int((late == 0).sum()) <= plan.faces.n_faces
+
+
+def test_to_dict_in_c_equals_the_python_loop():
+    """``SimplexTree.to_dict`` builds the tuples in one C pass (csrc/pyhandoff.c through ctypes.PyDLL): same keys, same
+    Python types, same values as the .tolist() + zip loop it replaces."""
+    from flooder_amd import simplex_tree as stm
+
+    rng = np.random.default_rng(5)
+    st = stm.SimplexTree.from_cells(stm.delaunay_cells(rng.normal(size=(300, 3))), 300)
+    st._materialise_all()
+    for d in st._rows:
+        st._vals[d][:] = rng.random(st._rows[d].shape[0])
+    if stm._py_lib() is None:
+        pytest.skip("no C compiler / Python headers here: the Python loop is the only path")
+    a = st.to_dict()
+    keep = stm._PY_LIB
+    stm._PY_LIB = None
+    try:
+        b = st.to_dict()
+    finally:
+        stm._PY_LIB = keep
+    assert a == b and list(a) == list(b)
+    k = next(iter(a))
+    assert type(k) is tuple and type(k[0]) is int and type(a[k]) is float

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; TAG=$1; shift; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 i=0
 for spec in "$@"; do
   i=$((i+1)); set -- $spec; wl=$1; shift
-  timeout 900 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 --no-cold "$@" > $OUT/ab_$i.json 2> $OUT/ab_$i.err
+  timeout 300 python bench.py --workload $wl --no-cpu-baseline --steps 20 --warmup 3 --no-cold "$@" > $OUT/ab_$i.json 2> $OUT/ab_$i.err
   python - $OUT/ab_$i.json "$spec" <<'PY'
 import json, sys
 try:

@@ -158,7 +158,6 @@ for (k, c) in sorted(acc):
 PY
             grep -A17 "cell_sweep\|finish_faces\|sweep_bvh" $OUT/icache_summary_$wl.txt
             rm -rf $OUT/pmc_icache_$wl $OUT/pmc_inst_$wl ;;
-    tindex) timeout 300 python tools/time_index.py > $OUT/time_index.txt 2>&1; cat $OUT/time_index.txt ;;
     *) echo "unknown step $s" ;;
   esac
 done
