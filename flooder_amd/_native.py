@@ -79,12 +79,6 @@ SIGNATURES = {
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
-    "flooder_sweep_cell_heavy_first_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                                   c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                   c_void_p, c_float, c_void_p]),
-    "flooder_sweep_join": (c_int, [c_void_p]),
     "flooder_wit_max_rows": (c_int, []),
     "flooder_wit_max_coarse": (c_int, []),
     "flooder_sweep_witness_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

@@ -1134,7 +1134,6 @@ FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does
 CELL_DENSITY_GRID = True   # PointIndex carries a density grid; the cell sweep reads its first cell size from it
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 WIT_MIN_SIMPLICES = 1536   # fewer simplices than this in a sweep: no witness sweep (1024 persistent workgroups, one simplex each)
-CELL_HEAVY_FIRST = True   # with the witness sweep: the simplices it never tries start on a side stream beside it
 CELL_WITNESS = True  # sparse simplices go to the witness sweep first (whole simplex per wave, coarse samples + bounds)
 
 
@@ -1220,41 +1219,27 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
                                                          k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
         with _span(timer, "sweep"):
-            try:
-                if use_wit and CELL_HEAVY_FIRST:
-                    # the simplices the witness sweep never tries (heavier than its limit) start at once on the library's
-                    # side stream; flooder_sweep_cell_faces_f32 below joins it
-                    _native.check(lib.flooder_sweep_cell_heavy_first_f32(
-                        _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                        _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),
-                        _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
-                        ctl[1:].data_ptr(), _native.ptr(flags[1]), ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list),
-                        fctl[3:].data_ptr(), _native.ptr(defer_list), _native.ptr(defer_c), ctl[12:].data_ptr(), _native.ptr(wgt),
-                        _native.ptr(planes), _native.ptr(index.dens), _native.ptr(index.box), _native.ptr(sub(0, 9)),
-                        -1.0, st), "flooder_sweep_cell_heavy_first_f32")
-                if use_wit:
-                    wst = stats[16:40] if stats is not None and stats.numel() >= 40 else None
-                    _native.check(lib.flooder_sweep_witness_f32(
-                        _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                        _native.ptr(w_perm), k1, R, S, _native.ptr(plan.wit[0]), plan.wit[2], _native.ptr(plan.wit[1]),
-                        qwit.data_ptr(), _native.ptr(d2), _native.ptr(plan.memb_all), F, _native.ptr(face_bits),
-                        _native.ptr(slot_t), _native.ptr(flags[0]), ctl[1:].data_ptr(), _native.ptr(flags[1]),
-                        ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list), fctl[3:].data_ptr(),
-                        _native.ptr(wgt), _native.ptr(split[0]), _native.ptr(planes), _native.ptr(wst), st),
-                        "flooder_sweep_witness_f32")   # (split[0]: scratch until the cell sweep's entry fills it)
-                _native.check(lib.flooder_sweep_cell_faces_f32(
+            if use_wit:
+                wst = stats[16:40] if stats is not None and stats.numel() >= 40 else None
+                _native.check(lib.flooder_sweep_witness_f32(
                     _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                    _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),
-                    _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
-                    ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
-                    ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
-                    fctl[3:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
-                    ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
-                    _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(index.dens),
-                    _native.ptr(index.box), _native.ptr(sub(0, 9)), st),
-                    "flooder_sweep_cell_faces_f32")
-            finally:   # (whatever happened: nothing may still run on the side stream when the buffers go)
-                lib.flooder_sweep_join(st)
+                    _native.ptr(w_perm), k1, R, S, _native.ptr(plan.wit[0]), plan.wit[2], _native.ptr(plan.wit[1]),
+                    qwit.data_ptr(), _native.ptr(d2), _native.ptr(plan.memb_all), F, _native.ptr(face_bits),
+                    _native.ptr(slot_t), _native.ptr(flags[0]), ctl[1:].data_ptr(), _native.ptr(flags[1]),
+                    ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list), fctl[3:].data_ptr(),
+                    _native.ptr(wgt), _native.ptr(split[0]), _native.ptr(planes), _native.ptr(wst), st),
+                    "flooder_sweep_witness_f32")   # (split[0]: scratch until the cell sweep's entry fills it)
+            _native.check(lib.flooder_sweep_cell_faces_f32(
+                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
+                _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),
+                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
+                ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
+                ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
+                fctl[3:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
+                ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
+                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(index.dens),
+                _native.ptr(index.box), _native.ptr(sub(0, 9)), st),
+                "flooder_sweep_cell_faces_f32")
         with _span(timer, "fallback"):
             _native.check(lib.flooder_finish_faces_f32(
                 _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),

@@ -1536,8 +1536,7 @@ struct CellOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, float* plane_tab,
                  const float* weights, int k1, int R, int64_t ns, float alpha, int32_t* queue,
                  uint32_t* out, int32_t* flag_list, int32_t* flag_count, unsigned long long* stats,
-                 FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, hipStream_t st,
-                 bool heavy_only = false) {
+                 FaceAcc acc, DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       if (!g_cell_density_grid) dg = DensGrid{};
       dg.min_count = g_cell_density_grid;
@@ -1581,10 +1580,7 @@ struct CellOp {
     cp.qblk = qb < 0 ? -1 : (SUPER_ ? (qb > 2 ? qb - 2 : 0) : qb);                                                   \
     hipLaunchKernelGGL((cell_sweep_kernel<DIM, SUPER_, SPL_>), dim3(grid), dim3(256), 0, st, cp);                    \
   } while (0)
-      if (heavy_only) {
-        // (flooder_sweep_cell_heavy_first_f32: the chunks of the listed simplices only, on the caller's side stream)
-        FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue3);
-      } else if (dl.list) {
+      if (dl.list) {
         // runs of four chunks against one shared stage, then whatever they deferred chunk by chunk
         // (split: every simplex is on the heavy list of a short queue - the split kernel was told - and the chunk
         // launch takes them heaviest first)
@@ -1594,7 +1590,7 @@ struct CellOp {
         FLOODER_CELL_LAUNCH(false, SPL_CHUNK, queue);
       }
       // ... and the tiles of the chunks whose neighbourhood overflowed the stage, one sample per lane
-      if (dl.tile_list && !heavy_only) FLOODER_CELL_LAUNCH(false, 1, queue3);
+      if (dl.tile_list) FLOODER_CELL_LAUNCH(false, 1, queue3);
 #undef FLOODER_CELL_LAUNCH
       return check_launch("cell_sweep");
     } else {
@@ -1862,55 +1858,10 @@ __global__ __launch_bounds__(256) void density_leaves_kernel(const float* __rest
   atomicAdd(&grid[fine], (int)(left < LEAF ? left : LEAF));
 }
 
-// flooder_sweep_cell_heavy_first_f32: wtmp = the weights of the simplices heavier than `limit` (-1 for all others: what
-// class_order_kernel lists), and those simplices get weight -2 in place - on no list of the launches that follow
-__global__ __launch_bounds__(256) void heavy_mark_kernel(float* __restrict__ weight, int n, float limit, float* __restrict__ wtmp) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float w = weight[i];
-  const bool heavy = w > limit;
-  wtmp[i] = heavy ? w : -1.f;
-  if (heavy) weight[i] = -2.f;
-}
-
-// The side stream of a calling thread (one per thread and device): created on first use, never destroyed.
-struct SideStream {
-  hipStream_t st = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  int dev = -1;
-  bool pending = false;  // work on `st` that the main stream has not waited for yet
-};
-thread_local SideStream g_side;
-SideStream* side_stream() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (g_side.st && g_side.dev != dev) {  // (the thread moved to another device: start over there)
-    if (g_side.pending) (void)hipStreamSynchronize(g_side.st);
-    g_side = SideStream{};
-  }
-  if (!g_side.st) {
-    if (hipStreamCreateWithFlags(&g_side.st, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) {
-      g_side = SideStream{};
-      return nullptr;
-    }
-    g_side.dev = dev;
-  }
-  return &g_side;
-}
-void side_join(hipStream_t main) {
-  if (g_side.st && g_side.pending) {
-    (void)hipStreamWaitEvent(main, g_side.join, 0);
-    g_side.pending = false;
-  }
-}
-
 int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
                      float* plane_tab, const float* weights, int k1, int R, int64_t n_simplices, float alpha, int32_t* queue,
                      uint32_t* out_d2, int32_t* flag_list, int32_t* flag_count, uint64_t* stats, FaceAcc acc,
-                     DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, void* stream, const char* who,
-                     bool heavy_only = false) {
+                     DeferList dl, int32_t* queue2, int32_t* queue3, DensGrid dg, void* stream, const char* who) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !plane_tab || !weights || !queue || !out_d2 || !flag_list || !flag_count ||
       n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || R < 0 || !(alpha > 0.f))
@@ -1925,7 +1876,7 @@ int sweep_cell_entry(const float* pts_sorted, int64_t n_pts, int dim, const floa
     return fail(FLOODER_E_ARG, "cell sweep: cloud too large for the cell sweep (use the tree sweep)");
   return dispatch_dim<CellOp>(dim, pts_sorted, nodes, lv, verts, plane_tab, weights, k1, R, n_simplices, alpha, queue,
                               out_d2, flag_list, flag_count, reinterpret_cast<unsigned long long*>(stats), acc,
-                              dl, queue2, queue3, dg, (hipStream_t)stream, heavy_only);
+                              dl, queue2, queue3, dg, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -1988,68 +1939,12 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
     dl.tile_c = defer_c + n_chunk_slots;
     dl.tile_count = defer_ctl + 6;
   }
-  const int rc = sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue,
+  return sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue,
                           d2_scratch, flag_list, flag_count, stats,
                           FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list,
                                   top_count, face_slot, flag_key, flag_hist},
                           dl, queue + FLOODER_QUEUE_WORDS, queue + 2 * FLOODER_QUEUE_WORDS, dg,
                           stream, "flooder_sweep_cell_faces_f32: bad argument");
-  side_join((hipStream_t)stream);  // (the chunks flooder_sweep_cell_heavy_first_f32 put on the side stream: what follows needs them)
-  return rc;
-}
-
-int flooder_sweep_join(void* stream) {
-  side_join((hipStream_t)stream);
-  return FLOODER_OK;
-}
-
-int flooder_sweep_cell_heavy_first_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
-                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                                       float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
-                                       int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
-                                       int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
-                                       int32_t* top_list, int32_t* top_count, int32_t* defer_list, float* defer_c,
-                                       int32_t* defer_ctl, float* simplex_weight, float* plane_scratch,
-                                       const int32_t* density_grid, const float* cloud_box, uint64_t* stats,
-                                       float heavier_than, void* stream) {
-  if (n_simplices == 0 || R == 0) return FLOODER_OK;
-  if (!memb || !face_bits || n_faces < 1 || n_faces > 32 || (top && (!top_list || !top_count)) || !defer_list || !defer_c ||
-      !defer_ctl || !simplex_weight || !plane_scratch || (flag_key && (!flag_hist || !top)) || n_simplices > 0x7fffffffLL ||
-      (dim != 2 && dim != 3))
-    return fail(FLOODER_E_ARG, "flooder_sweep_cell_heavy_first_f32: bad argument");
-  if (g_cell_tiles) return FLOODER_OK;  // (the tile launch's half of the deferred buffers is this entry's scratch)
-  if (heavier_than < 0.f) heavier_than = (float)g_wit_weight;  // (the witness sweep's own limit)
-  hipStream_t main = (hipStream_t)stream;
-  SideStream* side = side_stream();
-  if (!side) return FLOODER_OK;  // (no side stream: the launches that follow do everything, one after the other)
-  side_join(main);
-  DensGrid dg;
-  if (density_grid && cloud_box) { dg.grid = density_grid; dg.box = cloud_box; }
-  const int64_t n_chunk_slots = n_simplices * (int64_t)((R + 255) / 256);
-  int32_t* h1_list = defer_list + n_chunk_slots;
-  float* wtmp = defer_c + n_chunk_slots;
-  int32_t* h1_counts = defer_ctl + 8;
-  int rc = launch_simplex_planes(dim, verts, k1, n_simplices, plane_scratch, main);
-  if (rc != FLOODER_OK) return rc;
-  hipLaunchKernelGGL(heavy_mark_kernel, dim3((unsigned)((n_simplices + 255) / 256)), dim3(256), 0, main, simplex_weight,
-                     (int)n_simplices, heavier_than, wtmp);
-  hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, main, wtmp, (int)n_simplices,
-                     (float)g_cell_super_weight, (float)g_cell_super_sparse, g_cell_weight_classes ? 2 : 0, 0, h1_list, h1_list,
-                     h1_counts);
-  if (hipEventRecord(side->fork, main) != hipSuccess || hipStreamWaitEvent(side->st, side->fork, 0) != hipSuccess)
-    return fail(FLOODER_E_LAUNCH, "flooder_sweep_cell_heavy_first_f32: fork failed");
-  DeferList dl{defer_list, defer_c, defer_ctl, nullptr, h1_list, h1_counts, g_cell_super_n0};
-  planes_done_for(verts, plane_scratch, n_simplices, side->st);   // (filled above, on the main stream, before the fork)
-  rc = sweep_cell_entry(pts_sorted, n_pts, dim, nodes, verts, plane_scratch, weights, k1, R, n_simplices, alpha, queue,
-                        d2_scratch, flag_list, flag_count, stats,
-                        FaceAcc{memb, face_bits, n_faces, reinterpret_cast<unsigned long long*>(top), top_list, top_count,
-                                face_slot, flag_key, flag_hist},
-                        dl, queue + FLOODER_QUEUE_WORDS, queue + 2 * FLOODER_QUEUE_WORDS, dg, side->st,
-                        "flooder_sweep_cell_heavy_first_f32: bad argument", true);
-  (void)hipEventRecord(side->join, side->st);
-  side->pending = true;
-  planes_done_for(verts, plane_scratch, n_simplices, main);   // (the witness / cell entries that follow on `stream` skip the table)
-  return rc;
 }
 
 

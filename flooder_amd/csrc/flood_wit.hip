@@ -1148,10 +1148,8 @@ struct WitOp {
                  const float* weights, int k1, int R, int64_t ns, WitPlan plan, int32_t* queue, int32_t* item_list,
                  int32_t* item_count, WitOut out, FaceAcc acc, unsigned long long* stats, hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
-      if (!planes_are_done(verts, plane_tab, ns, st)) {
-        const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
-        if (rc != FLOODER_OK) return rc;
-      }
+      const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
+      if (rc != FLOODER_OK) return rc;
       planes_done_for(verts, plane_tab, ns, st);   // (the cell sweep's entry, next on this stream, need not repeat it)
       hipLaunchKernelGGL(wit_list_kernel, dim3(1), dim3(1024), 0, st, out.weight, (int)ns, (float)g_wit_weight, item_list,
                          item_count);

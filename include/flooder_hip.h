@@ -58,7 +58,7 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *   "bvh_ks": samples per lane of the tree sweep (0 = auto: 1 for R <= 64, else 2);
  *   "bvh_subs": sub-tiles a tree-sweep item may be split into (default 16);
  *   "bvh_grid": persistent workgroups of the tree sweep (default 1024 = 4 per CU);
- *   "cell_grid": persistent workgroups of the cell sweep (default 1024 = the 4 per CU that fit LDS and registers);
+ *   "cell_grid": persistent workgroups of the cell sweep (default 768 = the 3 per CU that fit LDS);
  *   "bvh_refine_pct": threshold of the tree sweep's transposed refine in percent of its cost model (100;
  *                     the full sweep uses three times the value), "bvh_leaf_batch": leaves fetched per step
  *                     by the work-list tree sweep (1, or 4 through LDS);
@@ -374,32 +374,6 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
                                  float* defer_c, int32_t* defer_ctl, const float* simplex_weight,
                                  int32_t* light_list, int32_t* heavy_list, float* plane_scratch,
                                  const int32_t* density_grid, const float* cloud_box, uint64_t* stats, void* stream);
-
-/*
- * The heavy simplices first, beside the witness sweep (replaces the serial order of compute_filtration_kernel's
- * batches, core.py:193-226: any order of the simplices gives the same values).  Called BEFORE flooder_sweep_witness_f32
- * with the buffers flooder_sweep_cell_faces_f32 will get: the simplices heavier than `heavier_than` (the witness
- * sweep's own limit - a negative value: option "wit_weight" as it stands; the witness sweep never tries them) are listed in descending weight class, marked with weight
- * -2 in simplex_weight (READ AND WRITTEN: on no list of the launches that follow) and their chunks are launched on a
- * side stream of the library (one per calling thread and device; forked from `stream` by an event) while the witness
- * sweep runs on `stream`: two persistent launches whose tails - a fifth to a quarter of each - fill each other, and
- * where the witness sweep finds nothing to do (a surface cloud, a dense uniform one) its attempts cost no wall time.
- * flooder_sweep_cell_faces_f32, called next as before, sweeps what is left (the simplices the witness sweep abandoned)
- * and makes `stream` wait for the side stream before it returns; flooder_sweep_join does the same on its own (error
- * paths: buffers must not be freed while the side stream still uses them).  Scratch: the tile half of defer_list /
- * defer_c (not with option "cell_tiles") and defer_ctl[8:11]; queue: the third FLOODER_QUEUE_WORDS block.  Returns
- * FLOODER_OK without doing anything where it does not apply (no side stream, tiles on).
- */
-int flooder_sweep_cell_heavy_first_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes,
-                                       const float* verts, const float* weights, int k1, int R, int64_t n_simplices,
-                                       float alpha, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb,
-                                       int n_faces, uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list,
-                                       int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist, uint64_t* top,
-                                       int32_t* top_list, int32_t* top_count, int32_t* defer_list, float* defer_c,
-                                       int32_t* defer_ctl, float* simplex_weight, float* plane_scratch,
-                                       const int32_t* density_grid, const float* cloud_box, uint64_t* stats,
-                                       float heavier_than, void* stream);
-int flooder_sweep_join(void* stream);
 
 /*
  * Witness sweep (dim 2 and 3): the sparse simplices of the fused path, a whole simplex per wave, BEFORE

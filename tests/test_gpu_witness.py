@@ -167,26 +167,3 @@ def test_witness_sweep_other_shapes(case, dev):
     off = run(pts, lms, False, **kw)
     assert_same(on, off, case)
     assert_same(on, fa.flood_complex(pts, lms, method="bvh", **kw), case + " / tree sweep")
-
-
-@pytest.mark.parametrize("cloud,n,n_lms", [("gauss", 300_000, 400), ("torus", 200_000, 300), ("cube", 400_000, 500), ("two_blobs", 150_000, 250)])
-def test_heavy_simplices_on_the_side_stream_change_nothing(dev, cloud, n, n_lms, monkeypatch):
-    """``flooder_sweep_cell_heavy_first_f32``: the simplices the witness sweep never tries are swept on the library's
-    side stream BESIDE it (tails of two persistent launches filling each other).  Any order of the simplices gives the
-    same face maxima: bit-identical with the launches one after the other, with the witness sweep off, and against
-    the tree sweep; repeated calls (the side stream and its events are reused) and a limit that sends everything /
-    nothing to the side stream."""
-    pts = clouds(cloud, n).to(dev)
-    lms = fa.generate_landmarks(pts, n_lms, start_idx=0)
-    monkeypatch.setattr(core, "CELL_HEAVY_FIRST", False)
-    serial = run(pts, lms, True)
-    monkeypatch.setattr(core, "CELL_HEAVY_FIRST", True)
-    for rep in range(3):
-        assert_same(run(pts, lms, True), serial, f"{cloud}: side stream, call {rep}")
-    assert_same(run(pts, lms, False), serial, f"{cloud}: witness off")
-    assert_same(fa.flood_complex(pts, lms, method="bvh"), serial, f"{cloud}: tree sweep")
-    for limit in (0, 100_000_000):   # everything heavy (the witness sweep tries nothing) / nothing heavy
-        set_options(wit_weight=limit)
-        assert_same(run(pts, lms, True), serial, f"{cloud}: wit_weight {limit}")
-    set_options(wit_weight=WIT_DEFAULTS["wit_weight"])
-    torch.cuda.synchronize()
