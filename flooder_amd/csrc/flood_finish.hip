@@ -54,6 +54,7 @@ struct HardLists {
   int32_t* cnt_out;
   int cap;     // entries per list
   int budget;  // scale of the leaf budget of a tile (0: no hard tiles)
+  int budget_min = 64;  // ... and what a tile of a SHORT list may evaluate at least before it counts as hard (leaves)
 };
 
 constexpr int TEAM_WAVES = 16;
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
   // (top pass: one point query per simplex and about one query per wave - the pass lasts as long as its longest
   // query, so the budget is a fixed few dozen leaves)
   const int64_t budget_raw = mode == 1 ? (int64_t)hl.budget * 4 : (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * 4);
-  const int budget_min = hl.budget < 64 ? hl.budget : 64;
+  // (a short list - cfg 2's 200 tiles, a rank's share - used to get min(budget, 64) = 14 leaves: every dense tile went
+  // to the team launch, 50 us of launch for work the first pass does in 20; cfg 2 finish 0.115 -> 0.082 ms)
+  const int budget_min = hl.budget_min;
   const int budget_eff = (int)(budget_raw < budget_min ? budget_min : (budget_raw > (1 << 20) ? (1 << 20) : budget_raw));
   // stage levels topl (first) and topl - 1 (behind it) when they fit
   const int top_cnt = (int)lv.count[topl];
@@ -710,6 +713,7 @@ struct FinishOp {
     // and list length of the top pass's hard entries, [6], [7] those of the rest pass's
     HardLists a = none, b = none, c = none, d = none;
     a.budget = c.budget = g_finish_budget;
+    a.budget_min = c.budget_min = g_finish_budget_min;
     if (g_finish_top) {
       list(0, false, ctl + 5, a);  // top pass: hard entries -> list 0
       launch(1, q1, a);

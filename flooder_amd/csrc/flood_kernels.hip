@@ -659,6 +659,10 @@ int flooder_set_option(const char* name, int value) {
     g_cell_exh_sparse = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "finish_budget_min") == 0 && value >= 1) {
+    g_finish_budget_min = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "finish_refresh") == 0 && value >= 1) {
     g_finish_refresh = value;
     return FLOODER_OK;

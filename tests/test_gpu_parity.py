@@ -791,14 +791,15 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
     def run(order, budget, cap, top=0):
         monkeypatch.setattr(core, "FINISH_HARD_CAP", cap)
         try:
-            for name, val in ((b"finish_order", order), (b"finish_budget", budget), (b"finish_top", top)):
+            # (finish_budget_min: the floor under a short list's budget - 1 here, so that budget 1 means one leaf)
+            for name, val in ((b"finish_order", order), (b"finish_budget", budget), (b"finish_top", top), (b"finish_budget_min", 1)):
                 assert lib.flooder_set_option(name, val) == 0
             stats.zero_()
             out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=stats)
             torch.cuda.synchronize()
             return out.cpu().numpy(), core.LAST_STATS.hard_entries
         finally:
-            for name, val in ((b"finish_order", 1), (b"finish_budget", 14), (b"finish_top", 0)):
+            for name, val in ((b"finish_order", 1), (b"finish_budget", 14), (b"finish_top", 0), (b"finish_budget_min", 64)):
                 lib.flooder_set_option(name, val)
 
     ref, hard = run(0, 0, 32768)
