@@ -76,23 +76,21 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def make_points(w):
+def make_points(w, device="cpu"):
+    """The workload's cloud.  CPU (default): the draws SURVEY.md 8d prescribes (seed 42, the reference's generators and
+    draw order).  ``device``: the same distributions drawn on the GPU (``flooder_amd.synthetic`` with ``device=``: another
+    random stream, no host round trip - ``--device-cloud``)."""
     import torch
+
+    from flooder_amd.synthetic import generate_noisy_torus_points_3d, generate_swiss_cheese_points
 
     torch.manual_seed(42)
     if w["gen"] == "gauss":
-        return torch.randn(w["n"], w["dim"])
-    if w["gen"] == "torus":
-        theta = torch.rand(w["n"]) * 2 * torch.pi
-        phi = torch.rand(w["n"]) * 2 * torch.pi
-        x = (3.0 + torch.cos(phi)) * torch.cos(theta)
-        y = (3.0 + torch.cos(phi)) * torch.sin(theta)
-        z = torch.sin(phi)
-        p = torch.stack((x, y, z), dim=1)
-        return p + torch.randn_like(p) * 0.02
+        return torch.randn(w["n"], w["dim"], device=device)
+    if w["gen"] == "torus":   # (theta, phi, noise drawn in this order: synthetic_data_generators.py:258-269)
+        return generate_noisy_torus_points_3d(w["n"], R=3.0, r=1.0, noise_std=0.02, seed=42, device=device)
     if w["gen"] == "cheese":
-        from flooder_amd.synthetic import generate_swiss_cheese_points
-        return generate_swiss_cheese_points(w["n"], k=6, seed=42)[0]
+        return generate_swiss_cheese_points(w["n"], k=6, seed=42, device=device)[0]
     raise ValueError(w["gen"])
 
 
@@ -126,6 +124,9 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end flood_complex timing")
     ap.add_argument("--no-kd-order", action="store_true", help="point index in curve order also above 3D (default there: k-d tree order)")
     ap.add_argument("--no-witness", action="store_true", help="no witness sweep: every simplex goes through the cell sweep")
+    ap.add_argument("--device-cloud", action="store_true",
+                    help="draw the synthetic cloud on the GPU (flooder_amd.synthetic with device=: SURVEY.md 8 f-4) instead "
+                         "of on the host; the timed step starts from the cloud in HBM either way")
     ap.add_argument("--extra-workloads", default=None, metavar="cfg3,cfg5",
                     help="further workloads timed by child runs and attached to the line as extra_workloads "
                          "(default: cfg3,cfg5 on the default single-GPU cfg2 run; 'none' to skip)")
@@ -232,12 +233,23 @@ def main():
     if args.cpu_sample is None:
         args.cpu_sample = w.get("cpu_sample", 1200)
     # ------------------------------------------------------------------ untimed setup
-    pts_cpu = make_points(w)
-    torch.cuda.synchronize()
-    t_h0 = time.perf_counter()
-    pts_full = pts_cpu.to(dev)
-    torch.cuda.synchronize()
-    h2d_ms = (time.perf_counter() - t_h0) * 1e3     # pageable host memory -> HBM, once per call (not in the step)
+    gen_ms = None
+    if args.device_cloud:
+        make_points(dict(w, n=1024), dev)               # (warm-up of the generator's kernels)
+        torch.cuda.synchronize()
+        t_g0 = time.perf_counter()
+        pts_full = make_points(w, dev).contiguous()
+        torch.cuda.synchronize()
+        gen_ms = (time.perf_counter() - t_g0) * 1e3     # the whole cloud drawn in HBM
+        pts_cpu = pts_full.cpu()                        # (for the CPU baseline / parity leg only)
+        h2d_ms = 0.0
+    else:
+        pts_cpu = make_points(w)
+        torch.cuda.synchronize()
+        t_h0 = time.perf_counter()
+        pts_full = pts_cpu.to(dev)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t_h0) * 1e3     # pageable host memory -> HBM, once per call (not in the step)
     # BASELINE.json configs[4] "chunked point streaming from host pinned memory": the cloud copied in 2 M-row chunks
     # from pinned memory on a copy stream, every chunk's bounding-box reduction overlapped with the next copy; the
     # streamed index is then checked to be the resident one (same rows, same tree)
@@ -661,7 +673,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not args.device_cloud else f"synthetic, drawn on the device in {gen_ms:.1f} ms (flooder_amd.synthetic)",
         "config": {
             "workload": w["desc"], "points": w["n"], "landmarks": w["n_lms"], "top_simplices": S_all,
             "top_simplices_rank0": S, "swept_dimension": d,

@@ -20,7 +20,7 @@ HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
 PY_LIB = os.path.join(PKG_DIR, "libflooder_py.so")   # CPython-API helpers (loaded with ctypes.PyDLL)
 
 HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
-HOST_SOURCES = ["persistence.cpp"]
+HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp"]
 
 
 def _newer(target: str, sources) -> bool:

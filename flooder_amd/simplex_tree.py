@@ -25,6 +25,7 @@ dimension, monotonise) are vectorised instead of one Python call per simplex.
 from __future__ import annotations
 
 import itertools
+import os
 import math
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -110,8 +111,56 @@ def delaunay_cells(points: np.ndarray) -> np.ndarray:
         # fewer points than a full simplex: a single (n-1)-simplex on all points
         cells = np.arange(n, dtype=np.int64)[None, :]
     else:
-        cells = Delaunay(points).simplices
+        cells = _delaunay3d_native(points) if (dim == 3 and NATIVE_DELAUNAY and n >= 5) else None
+        if cells is None:
+            cells = Delaunay(points).simplices
     return _unique_rows(np.sort(np.asarray(cells, dtype=np.int64), axis=1))
+
+
+NATIVE_DELAUNAY = True   # 3-D: csrc/delaunay3d.cpp (libflooder_host.so) instead of Qhull; falls back to Qhull where it declines
+LAST_DELAUNAY = {"native": False, "code": 0}
+_HOST_DT = False
+
+
+def _delaunay3d_native(points: np.ndarray) -> Optional[np.ndarray]:
+    """Tetrahedra of the 3-D Delaunay triangulation from ``flooder_delaunay3d`` (incremental insertion with exact
+    predicates, host C++), or None where the routine declines the input (duplicate points, all points coplanar,
+    coordinates that do not scale to 58-bit integers - float64 clouds with a wide exponent range) or the library is
+    not there: the caller then asks Qhull as before."""
+    global _HOST_DT
+    if _HOST_DT is False:
+        _HOST_DT = None
+        try:
+            import ctypes
+
+            from . import build
+
+            path = build.HOST_LIB
+            if not os.path.exists(path) or not build._newer(path, [os.path.join(build.CSRC, f) for f in build.HOST_SOURCES]):
+                build.build_host()
+            lib = ctypes.CDLL(path)
+            lib.flooder_delaunay3d.restype = ctypes.c_int64
+            lib.flooder_delaunay3d.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+            _HOST_DT = lib
+        except Exception:
+            _HOST_DT = None
+    LAST_DELAUNAY["native"] = False
+    if _HOST_DT is None:
+        return None
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    cap = 8 * n + 64          # (a 3-D Delaunay triangulation of n points in general position has ~6.8 n tetrahedra)
+    for _ in range(2):
+        out = np.empty((cap, 4), dtype=np.int32)
+        rc = int(_HOST_DT.flooder_delaunay3d(pts.ctypes.data, n, out.ctypes.data, cap))
+        if rc >= 0:
+            LAST_DELAUNAY.update(native=True, code=rc)
+            return out[:rc].astype(np.int64)
+        if rc < -(1 << 40):   # declined
+            LAST_DELAUNAY["code"] = rc
+            return None
+        cap = -rc
+    return None
 
 
 def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
