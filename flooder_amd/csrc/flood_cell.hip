@@ -745,6 +745,15 @@ __global__ __launch_bounds__(256, FLOODER_CELL_WAVES) void cell_sweep_kernel(Cel
       uint32_t fl_key[SPL];
 #pragma unroll
       for (int i = 0; i < SPL; ++i) { fl_on[i] = false; fl_key[i] = 0u; }
+      // lane f: the slot of face f of this simplex and the running maximum it holds now - ONE chain of two loads for
+      // all faces, in flight beside the membership words, where every face of the chunk used to wait for its own slot
+      // look-up in turn (the delivery was a fifth of the sweep's wave time at cfg 2 / cfg 3: serial round trips) -
+      // and a value that cannot raise the maximum is not sent (most deliveries of a shared face are such: every one of
+      // them queued on the word's atomic unit)
+      const int64_t my_slot = lane < acc.n_faces ? acc.slot_of(s, lane) : 0;
+      const uint32_t my_fb = lane < acc.n_faces
+                                 ? __hip_atomic_load(acc.face_bits + my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : 0xffffffffu;
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {
         const bool settled = (q * CHUNK + i * 64 + lane < n_live) && !open[i];
@@ -762,7 +771,8 @@ __global__ __launch_bounds__(256, FLOODER_CELL_WAVES) void cell_sweep_kernel(Cel
           v = b > v ? b : v;
         }
         v = wave_max_u32(v);
-        if (lane == 0 && v > 0u) atomicMax(&acc.face_bits[acc.slot_of(s, f)], v);
+        // (lane f sends its face's value: it holds the slot)
+        if (lane == f && v > my_fb) atomicMax(&acc.face_bits[my_slot], v);
       }
 #pragma unroll
       for (int i = 0; i < SPL; ++i) {

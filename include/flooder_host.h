@@ -1,0 +1,49 @@
+/*
+ * flooder_host.h - C ABI of the HOST-side pieces of the path (libflooder_host.so, plain C++ / g++, no GPU; and
+ * libflooder_py.so, C against the CPython API).  They replace what the reference takes from third-party C++ libraries
+ * on the host either side of the sweep: gudhi's Delaunay triangulation of the landmarks (flooder/core.py:130-138),
+ * gudhi's persistence computation (flooder/cli.py:473-476, tests/test_flooder.py:55-71) and the Python loop that
+ * fills the result dict (flooder/core.py:258-263, 285-288).  Bound with ctypes: flooder_amd/simplex_tree.py,
+ * flooder_amd/persistence.py.
+ */
+#ifndef FLOODER_HOST_H
+#define FLOODER_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Delaunay triangulation of n >= 5 points in THREE dimensions (csrc/delaunay3d.cpp).  Replaces
+ * gudhi.DelaunayComplex(landmarks) of core.py:130-132 (the top cells; core.py:136-138 buckets their faces) and the
+ * Qhull call this build made through scipy.  Incremental Bowyer-Watson with ghost tetrahedra, orient3d / insphere
+ * decided exactly (double filter, then 512-bit integers on a common dyadic grid of the coordinates).
+ *   pts: n x 3 float64, row-major (host).  tets: cap x 4 int32 (host), vertex ids in no particular order.
+ *   returns the number of tetrahedra written; -needed (a small negative number) when cap is too small; a code below
+ *   -(1 << 40) when the routine declines the input - duplicate points, all points coplanar, non-finite values,
+ *   coordinates whose exponents spread over more than 57 bits (float64 clouds with full mantissas) - and the caller
+ *   triangulates with Qhull instead (flooder_amd.simplex_tree.delaunay_cells does).
+ */
+int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tets, int64_t cap);
+
+/*
+ * Z/2 persistent homology of a filtered complex (csrc/persistence.cpp): column reduction with clearing.  Replaces
+ * gudhi.SimplexTree.compute_persistence / persistence_intervals_in_dimension (cli.py:473-476).
+ *   n simplices in filtration order (a face before its cofaces); dims[j] = dimension of simplex j; the boundary of j
+ *   is bidx[bptr[j] .. bptr[j+1]) (indices < j).  pair[j] = the simplex j is paired with, or -1 (essential class).
+ */
+int flooder_persistence_z2(int64_t n, const int32_t* dims, const int64_t* bptr, const int64_t* bidx, int64_t* pair);
+
+/*
+ * libflooder_py.so (csrc/pyhandoff.c; loaded with ctypes.PyDLL, the GIL held): dict[tuple[int, ...], float] entries
+ * for n simplices of k vertices each in one pass - what core.py:258-263 / 285-288 build with zip() over .tolist().
+ *   dict, cache: PyObject* (a dict; a list whose entry v is the int object v, grown as needed).  0 / -1 (exception set).
+ */
+int flooder_dict_update(void* dict, const int64_t* rows, int64_t n, int k, const double* vals, void* cache);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -661,10 +661,16 @@ def test_degenerate_density_clouds_gpu(dev):
         assert_close_filtration(vals[pick], own, P, f"{name} tetrahedra sample")
 
 
-def test_needle_and_sliver_simplices_cell_equals_tree(dev):
+def test_needle_and_sliver_simplices_cell_equals_tree(dev, monkeypatch):
     """Ill-conditioned simplices (near-collinear landmark triples, near-coplanar quadruples), also far from the
     coordinate origin: the cell sweep's face-plane filter must never drop a true nearest neighbour, i.e. the cell
-    sweep equals the tree sweep (which has no such filter) bit for bit, and both match the kd-tree oracle."""
+    sweep equals the tree sweep (which has no such filter) bit for bit, and both match the kd-tree oracle.
+    (The landmarks are near-degenerate ON PURPOSE - twelve collinear, twenty-five coplanar points - so their Delaunay
+    triangulation hangs on round-off: the oracle triangulates with Qhull, and so does the product here; the exact
+    native routine decides the ties differently, tests/test_delaunay.py.)"""
+    from flooder_amd import simplex_tree as stm
+
+    monkeypatch.setattr(stm, "NATIVE_DELAUNAY", False)
     rng = np.random.default_rng(77)
     for case, (offset, eps) in enumerate([(0.0, 1e-4), (0.0, 1e-6), (300.0, 1e-5), (0.0, 0.0)]):
         cloud = rng.normal(size=(30_000, 3)).astype(np.float64)

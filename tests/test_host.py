@@ -131,6 +131,23 @@ def test_native_library_loads_and_exports_header_symbols():
     assert [lib.flooder_padded_dim(d) for d in (1, 2, 3, 4, 5, 8)] == [2, 2, 4, 4, 8, 8]
 
 
+def test_host_libraries_export_header_symbols():
+    """include/flooder_host.h: the host-side entry points (Delaunay of the landmarks, persistence, dict hand-off) are
+    exported by libflooder_host.so / libflooder_py.so."""
+    import ctypes
+
+    from flooder_amd import build
+
+    header = open(os.path.join(ROOT, "include", "flooder_host.h")).read()
+    declared = set(re.findall(r"\b(flooder_[a-z0-9_]+)\s*\(", header))
+    assert declared == {"flooder_delaunay3d", "flooder_persistence_z2", "flooder_dict_update"}
+    build.build_host()
+    host = ctypes.CDLL(build.HOST_LIB)
+    assert hasattr(host, "flooder_delaunay3d") and hasattr(host, "flooder_persistence_z2")
+    if build.build_py():
+        assert hasattr(ctypes.PyDLL(build.PY_LIB), "flooder_dict_update")
+
+
 def test_rocm_tensor_without_library_fails_loudly(monkeypatch):
     """No silent fallback: a missing library is an ImportError for GPU inputs."""
     monkeypatch.setattr(_native, "_lib", None)
