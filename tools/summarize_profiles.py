@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from bench import kernel_source_sha
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-name = sys.argv[2] if len(sys.argv) > 2 else f"r4_{tag}"
+name = sys.argv[2] if len(sys.argv) > 2 else f"r5_{tag}"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 FROM_PMC = "--from-pmc" in sys.argv   # recompute traffic.json from the committed summaries (no raw profiler output)
