@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 for s in $STEPS; do
   case $s in
-    test)   timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
+    test)   timeout 900 python -m pytest tests -m gpu -x -q --timeout 200 --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
     testall) timeout 1500 python -m pytest tests -m gpu -q --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -15 $OUT/pytest_gpu.txt ;;
     bench)  timeout 600 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; cut -c1-600 $OUT/bench_cfg2.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg2.json $OUT/profiles/r5_cfg2_bench.json ;;
     bench3) timeout 900 python bench.py --workload cfg3 --cpu-sample 600 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg3.json $OUT/profiles/r5_cfg3_bench.json ;;
