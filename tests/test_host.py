@@ -424,3 +424,30 @@ def test_to_dict_in_c_equals_the_python_loop():
     assert a == b and list(a) == list(b)
     k = next(iter(a))
     assert type(k) is tuple and type(k[0]) is int and type(a[k]) is float
+
+
+def test_diagnostic_builds_still_compile():
+    """The timer / trace variants the tools build on the GPU box (-DFLOODER_PHASE_TIMERS, _WAVE_END, _WAVE_END_FIN,
+    _SORTED_TIMERS, _WIT_TIMERS) are not part of the product build: a syntax-only device compile of each keeps them
+    from rotting (a renamed parameter had broken the sorted sweep's timer build unnoticed)."""
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    csrc = os.path.join(ROOT, "flooder_amd", "csrc")
+    jobs = [("flood_cell.hip", "-DFLOODER_PHASE_TIMERS"), ("flood_cell.hip", "-DFLOODER_WAVE_END"),
+            ("flood_finish.hip", "-DFLOODER_PHASE_TIMERS"), ("flood_finish.hip", "-DFLOODER_WAVE_END_FIN"),
+            ("flood_sorted.hip", "-DFLOODER_SORTED_TIMERS"), ("flood_wit.hip", "-DFLOODER_WIT_TIMERS")]
+
+    def compile_one(job):
+        src, flag = job
+        p = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-DFLOODER_BUILD", flag, "--cuda-device-only",
+                            "-fsyntax-only", os.path.join(csrc, src)], capture_output=True, text=True)
+        return job, p.returncode, p.stderr[-600:]
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        for job, rc, err in pool.map(compile_one, jobs):
+            assert rc == 0, f"{job}: {err}"
