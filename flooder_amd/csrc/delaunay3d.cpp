@@ -224,18 +224,20 @@ constexpr int Mesh::FACE[4][3];
 
 // Links the faces of freshly made tetrahedra that meet in the new vertex: exactly two of them share every edge of the
 // cavity's boundary.  A small open-addressing table keyed by the edge: the second face to arrive finds the first.
+// Entries carry the stamp of the insertion they belong to, so the table is never cleared.
 struct EdgeLinks {
-  struct Ent { uint64_t key; int tet, face; };
+  struct Ent { uint64_t key; int tet, face; uint32_t stamp; };
   std::vector<Ent> tab;
-  size_t mask = 0, open = 0;
+  size_t mask = 0, open = 0, used = 0;
+  uint32_t stamp = 0;
   bool bad = false;
-  void clear(size_t expected = 64) {
-    size_t cap = 64;
+  void begin(size_t expected) {
+    size_t cap = tab.size() ? tab.size() : 256;
     while (cap < 4 * expected) cap <<= 1;
-    if (tab.size() != cap) tab.assign(cap, Ent{~0ull, -1, -1});
-    else std::fill(tab.begin(), tab.end(), Ent{~0ull, -1, -1});
+    if (tab.size() != cap) { tab.assign(cap, Ent{0, -1, -1, 0}); stamp = 0; }
+    if (++stamp == 0) { std::fill(tab.begin(), tab.end(), Ent{0, -1, -1, 0}); stamp = 1; }
     mask = cap - 1;
-    open = 0;
+    open = used = 0;
     bad = false;
   }
   void add(std::vector<Mesh::Tet>& t, int a, int b, int tet, int face) {
@@ -244,10 +246,10 @@ struct EdgeLinks {
     size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & mask;
     for (size_t probes = 0; probes <= mask; ++probes, h = (h + 1) & mask) {
       Ent& e = tab[h];
-      if (e.key == ~0ull) {
-        e = Ent{key, tet, face};
+      if (e.stamp != stamp) {
+        e = Ent{key, tet, face, stamp};
         ++open;
-        if (4 * open > 3 * (mask + 1)) bad = true;   // (table too full: the caller sized it from the cavity)
+        if (2 * ++used > mask + 1) bad = true;   // (table too full: the caller sized it from the cavity)
         return;
       }
       if (e.key == key) {
@@ -368,7 +370,7 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
       G.nb[3] = t0;
       m.t[(size_t)t0].nb[i] = g[i];
     }
-    links.clear(16);
+    links.begin(16);
     for (int i = 0; i < 4; ++i) {
       const Mesh::Tet G = m.t[(size_t)g[i]];
       links.add(m.t, G.v[1], G.v[2], g[i], 0);
@@ -422,27 +424,30 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
     // ---- cavity: the connected set of tetrahedra in conflict with the point
     cavity.clear();
     stack.assign(1, cur);
-    m.mark[(size_t)cur] = pi;
+    const int in_cav = 2 * pi, not_cav = 2 * pi + 1;   // (marks: in the cavity / tested and not in conflict)
+    m.mark[(size_t)cur] = in_cav;
     while (!stack.empty()) {
       const int c = stack.back();
       stack.pop_back();
       cavity.push_back(c);
       for (int i = 0; i < 4; ++i) {
         const int u = m.t[(size_t)c].nb[i];
-        if (m.mark[(size_t)u] == pi) continue;
+        if (m.mark[(size_t)u] == in_cav || m.mark[(size_t)u] == not_cav) continue;
         if (m.conflict(u, pi)) {
-          m.mark[(size_t)u] = pi;
+          m.mark[(size_t)u] = in_cav;
           stack.push_back(u);
+        } else {
+          m.mark[(size_t)u] = not_cav;
         }
       }
     }
     // ---- a new tetrahedron on every boundary face of the cavity
-    links.clear(8 * cavity.size() + 16);
+    links.begin(3 * cavity.size() + 16);   // (about 2 c + 2 boundary faces, 1.5 distinct edges each)
     fresh.clear();
     for (const int c : cavity) {
       for (int i = 0; i < 4; ++i) {
         const int u = m.t[(size_t)c].nb[i];
-        if (m.mark[(size_t)u] == pi) continue;   // (inside the cavity)
+        if (m.mark[(size_t)u] == in_cav) continue;   // (inside the cavity)
         const int a = m.t[(size_t)c].v[Mesh::FACE[i][0]], b = m.t[(size_t)c].v[Mesh::FACE[i][1]],
                   d = m.t[(size_t)c].v[Mesh::FACE[i][2]];
         const int nt = m.new_tet();   // (may move m.t: no references held across it)
