@@ -35,6 +35,8 @@ def _host_lib():
         lib.flooder_persistence_z2.restype = ctypes.c_int
         lib.flooder_persistence_z2.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p]
+        lib.flooder_filtration_order.restype = ctypes.c_int
+        lib.flooder_filtration_order.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 8
         _HOST_LIB = lib
     return _HOST_LIB
 
@@ -52,6 +54,10 @@ def filtration_order(st):
         return np.zeros(0, np.int32), np.zeros(0), np.zeros(1, np.int64), z, {}
     top = dims_present[-1]
     counts = [st._rows[d].shape[0] if d in st._rows else 0 for d in range(top + 1)]
+    if NATIVE_ORDER:
+        out = _filtration_order_native(st, top, counts)
+        if out is not None:
+            return out
     offs = np.concatenate([[0], np.cumsum(counts)])  # global id = offs[d] + row index
     n = int(offs[-1])
     dims = np.concatenate([np.full(c, d, dtype=np.int32) for d, c in enumerate(counts)])
@@ -92,6 +98,36 @@ def filtration_order(st):
     else:
         bidx = np.zeros(0, np.int64)
     return dims[order].astype(np.int32), filt[order], bptr, bidx.astype(np.int64), order
+
+
+NATIVE_ORDER = True   # filtration order + boundaries in host C++ (flooder_filtration_order); False: the numpy version
+
+
+def _filtration_order_native(st, top: int, counts):
+    """``filtration_order`` through ``flooder_filtration_order`` (csrc/persistence.cpp): one sort and a binary search
+    per facet instead of packed-key ``searchsorted`` passes and a ``lexsort``.  None where it does not apply (a facet
+    missing from its table: the numpy version then raises the error; a missing library)."""
+    try:
+        lib = _host_lib()
+    except Exception:
+        return None
+    n = int(sum(counts))
+    rows = np.concatenate([np.ascontiguousarray(st._rows[d], dtype=np.int64).reshape(-1) if c else np.zeros(0, np.int64)
+                           for d, c in enumerate(counts)])
+    vals = np.concatenate([np.asarray(st._vals[d], dtype=np.float64) if c else np.zeros(0)
+                           for d, c in enumerate(counts)])
+    cnt = np.asarray(counts, dtype=np.int64)
+    nb = int(sum(c * (d + 1) for d, c in enumerate(counts) if d > 0))
+    dims = np.empty(n, dtype=np.int32)
+    filt = np.empty(n, dtype=np.float64)
+    bptr = np.empty(n + 1, dtype=np.int64)
+    bidx = np.empty(max(nb, 1), dtype=np.int64)
+    order = np.empty(n, dtype=np.int64)
+    rc = lib.flooder_filtration_order(top, cnt.ctypes.data, rows.ctypes.data, vals.ctypes.data, dims.ctypes.data,
+                                      filt.ctypes.data, bptr.ctypes.data, bidx.ctypes.data, order.ctypes.data)
+    if rc != 0:
+        return None
+    return dims, filt, bptr, bidx[:nb], order
 
 
 def reduce_pairs(dims: np.ndarray, bptr: np.ndarray, bidx: np.ndarray) -> np.ndarray:

@@ -37,6 +37,18 @@ int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tets, int64_t 
 int flooder_persistence_z2(int64_t n, const int32_t* dims, const int64_t* bptr, const int64_t* bidx, int64_t* pair);
 
 /*
+ * The simplices of a complex in filtration order with their boundaries - the input of flooder_persistence_z2 - from the
+ * per-dimension simplex tables (what gudhi's Simplex_tree hands to its persistence module, cli.py:473-476).
+ *   top: highest dimension; counts[d]: simplices of dimension d; rows: the tables back to back, dimension d as
+ *   (counts[d], d+1) ascending vertex ids, rows in lexicographic order; vals: the filtration values in the same order.
+ *   Order: (value with NaN last, dimension, table position).  Outputs, in filtration order: dims_out, filt_out, bptr
+ *   (n+1), bidx (facet j = the simplex without its j-th vertex, as positions in filtration order), order_out (global
+ *   id = offset of the dimension + row).  0; -1 bad arguments; -2 a facet is missing from its table.
+ */
+int flooder_filtration_order(int top, const int64_t* counts, const int64_t* rows, const double* vals, int32_t* dims_out,
+                             double* filt_out, int64_t* bptr, int64_t* bidx, int64_t* order_out);
+
+/*
  * libflooder_py.so (csrc/pyhandoff.c; loaded with ctypes.PyDLL, the GIL held): dict[tuple[int, ...], float] entries
  * for n simplices of k vertices each in one pass - what core.py:258-263 / 285-288 build with zip() over .tolist().
  *   dict, cache: PyObject* (a dict; a list whose entry v is the int object v, grown as needed).  0 / -1 (exception set).
