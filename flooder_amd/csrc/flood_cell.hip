@@ -155,7 +155,8 @@ struct DeferList {
   int32_t* tile_count = nullptr;
   int64_t tail_items = INT64_MAX;  // only the last so many items of the chunk launch hand dense chunks on to the tiles
   int listed_first = 1;  // chunk launch: the deferred chunks ahead of the heavy simplices (0: behind them)
-  int chunk_major = 0;   // chunk launch: heavy items ordered chunk by chunk instead of simplex by simplex
+  int chunk_major = 0;   // chunk launch: pilots first - chunk 0 of every heavy simplex ahead of all other chunks (2: always)
+  int pilot_min_items = 262144;  // ... also where the heavy list has at least this many chunks (option "cell_chunk_major_max")
   int drop = 0;          // cell query: interior samples whose running minimum cannot raise the simplex's maximum stop early
 };
 
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256, FLOODER_CELL_WAVES) void cell_sweep_kernel(Cel
     n_heavy_items = (!TILES && use_lists && dl.heavy) ? dl.split[1] * chunks : 0;
     // (decided once per launch, wave-uniform: see the item decoding below)
     chunk_major = wave_uniform((!SUPER && !TILES && dl.chunk_major && use_lists && dl.heavy && chunks > 1 &&
-                                3 * (int64_t)(n_heavy_items / chunks) < n_simplices) ? 1 : 0) != 0;
+                                (dl.chunk_major == 2 || 3 * (int64_t)(n_heavy_items / chunks) < n_simplices ||
+                                 n_heavy_items >= dl.pilot_min_items)) ? 1 : 0) != 0;
     // chunk launch: the chunks the runs deferred come FIRST - they are the long items of this launch (a neighbourhood
     // that overflowed the shared stage), and at the end of the queue they were its tail
     lfirst = TILES || dl.listed_first != 0;
@@ -1416,6 +1418,9 @@ s_pts.get4(j, x);
             const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
             int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
             if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
+#ifdef FLOODER_QUERY_DIAG
+            int rows_seen = 0;
+#endif
   #pragma unroll
             for (int rw = 0; rw < NROW; ++rw) {
               int base;
@@ -1430,6 +1435,9 @@ s_pts.get4(j, x);
                 lb = gap2[1][dy + 1];
               }
               if (!(lb < b)) continue;
+#ifdef FLOODER_QUERY_DIAG
+              ++rows_seen;
+#endif
               // the row's outer cells are dropped too when their slab is no closer than the running minimum
               const int first = (lb + gap2[0][0] < b) ? 0 : 1;
               const int last = (lb + gap2[0][2] < b) ? 3 : 2;
@@ -1456,6 +1464,12 @@ s_pts.get4(j, x);
               }
               if (__float_as_uint(b) <= thr_i) b = 0.f;  // (dropped: cannot raise the simplex's maximum)
             }
+#ifdef FLOODER_QUERY_DIAG
+            {  // diagnostic build: rows of cells visited per queried sample, [10]: samples dropped against the maximum
+              unsigned long long* const dst = ARG(stats);
+              if (dst) { atomicAdd(&dst[100 + rows_seen], 1ull); if (b == 0.f) atomicAdd(&dst[110], 1ull); }
+            }
+#endif
             best[i] = b;
             open[i] = !(b <= c_ok);
           }
@@ -1576,7 +1590,12 @@ struct CellOp {
       dl.listed_first = g_cell_listed_first;
       // (chunk-major order costs the L2 locality of a simplex's neighbouring chunks: measured a gain on queues up to
       // ~100 k chunks - cfg 2: 1.290 -> 1.246 ms per step, cfg 3: 4.72 -> 4.69 -, a small loss at cfg 5's 504 k)
-      dl.chunk_major = (g_cell_chunk_major && n_chunks <= (int64_t)g_cell_chunk_major_max && n_chunks > ns) ? 1 : 0;
+      // (pilots first: where the heavy list is the dense rest of a cloud whose sparse simplices the witness sweep took
+      // - cfg 2: 1.290 -> 1.246 ms - and on very long queues, where a simplex's chunks are far apart in time anyway -
+      // cfg 5, 504 k chunks: sweep 6.51 -> 6.42 ms; in between - cfg 3, 110 k chunks, every simplex heavy - it costs
+      // 0.4 %; option "cell_chunk_major" 2: always)
+      dl.chunk_major = g_cell_chunk_major == 2 ? 2 : ((g_cell_chunk_major && n_chunks > ns) ? 1 : 0);
+      dl.pilot_min_items = g_cell_chunk_major_max;
       dl.drop = g_cell_drop;
       CellParams cp{pts, nodes, lv, verts, plane_tab, weights, k1, R, ns, alpha, g_cell_exh_dense, g_cell_exh_sparse,
                     brute_max, g_cell_tries, g_cell_exh_tries, g_cell_retry_pct, g_cell_retry_keep, queue, out, flag_list,

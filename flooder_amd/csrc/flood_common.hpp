@@ -33,7 +33,7 @@ extern int g_cell_weight_classes;   // cell sweep: the simplex lists in descendi
 extern int g_cell_listed_first;     // cell sweep, chunk launch: deferred chunks ahead of the heavy simplices
 extern int g_cell_tail_waves;       // cell_tiles = 2: the tail = the last (this percentage of the launch's waves) items
 extern int g_cell_chunk_major;    // cell sweep, chunk launch: heavy simplices chunk by chunk (all first chunks, then all second ones ...)
-extern int g_cell_chunk_major_max;  // ... for queues of at most this many chunks
+extern int g_cell_chunk_major_max;  // ... also for heavy lists of at least this many chunks (long queues: cfg 5)
 extern int g_cell_drop;           // cell query drops interior samples that cannot raise the simplex's maximum
 extern int g_cell_one_pass;         // cell sweep: dense chunks are classified and evaluated in ONE pass over their candidates
 extern int g_cell_queue_block;     // cell sweep: log2 of the item blocks of the XCD-local work queue (-1: interleaved items, any XCD)

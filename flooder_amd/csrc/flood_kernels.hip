@@ -759,7 +759,7 @@ int flooder_set_option(const char* name, int value) {
     g_wit_max_leaves = value;
     return FLOODER_OK;
   }
-  if (name && strcmp(name, "cell_chunk_major") == 0 && (value == 0 || value == 1)) {
+  if (name && strcmp(name, "cell_chunk_major") == 0 && (value == 0 || value == 1 || value == 2)) {
     g_cell_chunk_major = value;
     return FLOODER_OK;
   }
