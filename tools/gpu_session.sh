@@ -31,7 +31,7 @@ PY
             ;;
     prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
             python tools/summarize_profiles.py ${s#prof:} r5_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
-            mkdir -p $OUT/profiles && cp profiles/r5_${s#prof:}_* profiles/traffic.json $OUT/profiles/
+            mkdir -p $OUT/profiles && cp profiles/r5_${s#prof:}_kernel_stats.csv profiles/r5_${s#prof:}_pmc.json profiles/r5_${s#prof:}_bench_under_rocprof.json profiles/traffic.json $OUT/profiles/
             rm -rf $R/gpurun_out/prof_${s#prof:} ;;   # (only the summaries travel back: gpurun_out is capped at 64 MiB)
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
     emul:*) bash tools/emulate_scaling.sh ${s#emul:} > $OUT/emulate_${s#emul:}.txt 2>&1; cat $OUT/emulate_${s#emul:}.txt ;;
