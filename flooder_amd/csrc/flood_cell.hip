@@ -21,6 +21,8 @@
 //                (flood_bvh.hip, seeded with the minima found here) finishes.
 // A bad c costs time, never correctness; the result equals the exhaustive minimum bit for bit.
 
+#include <type_traits>
+
 #include "flood_common.hpp"
 #include "flood_bvh.hpp"
 
@@ -37,6 +39,9 @@ constexpr int SPL_CHUNK = 4;      // samples per lane of a chunk item (256 sampl
 #endif
 #ifndef FLOODER_CELL_WAVES
 #define FLOODER_CELL_WAVES 4
+#endif
+#ifndef FLOODER_CELL_COMPACT
+#define FLOODER_CELL_COMPACT 0   // 1: the cell query compacts the samples that need more than their own row across lanes (measured: no gain, see there)
 #endif
 constexpr int CAPW = FLOODER_CELL_CAPW;  // points staged per wave (480 + 896 leaves: 13 KB per wave, see the kernel)
 constexpr int MAXLEAF = FLOODER_CELL_MAXLEAF;  // leaves gathered per wave item (896: 14 K points before filtering)
@@ -1388,95 +1393,188 @@ s_pts.get4(j, x);
         thr_top = __hip_atomic_load(acc.face_bits + acc.slot_of(s, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       const uint32_t* const memb = thr_top != 0u ? ARG(acc.memb) : nullptr;
+      // One sample's rows of cells ROW_FROM .. ROW_TO - 1 (of the 3^(dim-1) rows of 3 cells along x around its own cell,
+      // own row first): a row is skipped when even its slab is no closer than the running minimum.  Returns the new
+      // minimum; `more`: a row at or beyond ROW_TO could still lower it.
+      constexpr int NROW = DIM == 3 ? 9 : 3;
+      auto sample_rows = [&](const float (&ps)[DIM], float b, uint32_t thr_i, auto row_from, auto row_to, bool& more) -> float {
+        constexpr int ROW_FROM = decltype(row_from)::value, ROW_TO = decltype(row_to)::value;
+        int ck[DIM];
+        float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
+  #pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          const float tf = (ps[k] - g0[k]) * inv_c;
+          const int t = (int)tf;
+          ck[k] = t < 1 ? 1 : (t > nc[k] - 2 ? nc[k] - 2 : t);
+          const float f = tf - (float)ck[k];  // position inside the (clamped) cell, in cells
+          const float lo_gap = __builtin_fmaxf(f, 0.f) * c * 0.999f;
+          const float hi_gap = __builtin_fmaxf(1.f - f, 0.f) * c * 0.999f;
+          gap2[k][0] = lo_gap * lo_gap;
+          gap2[k][1] = 0.f;
+          gap2[k][2] = hi_gap * hi_gap;
+        }
+        constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+        constexpr int ORD2[3] = {0, -1, 1};
+        // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
+        const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
+        int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
+        if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
+#ifdef FLOODER_QUERY_DIAG
+        int rows_seen = 0;
+#endif
+  #pragma unroll
+        for (int rw = ROW_FROM; rw < ROW_TO; ++rw) {
+          int base;
+          float lb;
+          if constexpr (DIM == 3) {
+            const int dy = ORD3[rw][0], dz = ORD3[rw][1];
+            base = base0 + dy * stride_y + dz * stride_z;
+            lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
+          } else {
+            const int dy = ORD2[rw];
+            base = base0 + dy * stride_y;
+            lb = gap2[1][dy + 1];
+          }
+          if (!(lb < b)) continue;
+#ifdef FLOODER_QUERY_DIAG
+          ++rows_seen;
+#endif
+          // the row's outer cells are dropped too when their slab is no closer than the running minimum
+          const int first = (lb + gap2[0][0] < b) ? 0 : 1;
+          const int last = (lb + gap2[0][2] < b) ? 3 : 2;
+          const int bg = s_cell[base + first];
+          const int en = s_cell[base + last];
+          if (has_stats) n_pairs += (unsigned long long)(en - bg);
+          // whole blocks of four staged points; entries before `bg` and past `en` are real points of other cells or
+          // the +inf pads behind the list - a minimum over more real points is still a valid upper bound, and exact
+          // once verified
+          for (int j = bg & ~3; j < en; j += 4) {
+            float4 x[4];
+            s_pts.get4(j, x);
+  #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float t0 = ps[0] - x[u].x;
+              float d2 = t0 * t0;
+              t0 = ps[1] - x[u].y;
+              d2 = __builtin_fmaf(t0, t0, d2);
+              if constexpr (DIM == 3) {
+                t0 = ps[2] - x[u].z;
+                d2 = __builtin_fmaf(t0, t0, d2);
+              }
+              b = __builtin_fminf(b, d2);
+            }
+          }
+          if (__float_as_uint(b) <= thr_i) b = 0.f;  // (dropped: cannot raise the simplex's maximum)
+        }
+        more = false;
+  #pragma unroll
+        for (int rw = ROW_TO; rw < NROW; ++rw) {
+          float lb;
+          if constexpr (DIM == 3) lb = gap2[1][ORD3[rw][0] + 1] + gap2[DIM - 1][ORD3[rw][1] + 1];
+          else lb = gap2[1][ORD2[rw] + 1];
+          more = more || (lb < b);
+        }
+#ifdef FLOODER_QUERY_DIAG
+        {  // diagnostic build: rows of cells visited per call, [10]: samples dropped against the maximum
+          unsigned long long* const dst = ARG(stats);
+          if (dst) { atomicAdd(&dst[100 + rows_seen], 1ull); if (b == 0.f) atomicAdd(&dst[110], 1ull); }
+        }
+#endif
+        return b;
+      };
+      typedef std::integral_constant<int, 0> Row0;
+      typedef std::integral_constant<int, 1> Row1;
+      typedef std::integral_constant<int, NROW> RowN;
+#if FLOODER_CELL_COMPACT
+      // A queried sample visits 2.1 of its 9 rows on average - 57 - 64 % only their own row (tools/query_rows.py) - but
+      // which ones differs from lane to lane, and a wave that takes its lanes' samples one after the other runs every
+      // one of its four phases to the slowest lane: 6 - 7 rows executed at a quarter of the lanes.  So: (A) every open
+      // sample visits its OWN row; (B) the samples that another row could still improve - a third - are compacted
+      // ACROSS lanes through LDS (the leaf list's storage, idle during the query: coordinates, minimum, threshold) and
+      // worked off 64 at a time, whatever lane they came from; their minima go back the same way.
+      // MEASURED (round 5, bit-identical on all 171 GPU tests): the rows executed per chunk fall by a third as
+      // predicted, the time does not - cfg 5 sweep 6.41 vs 6.37 ms, cfg 3 2.22 vs 2.16, cfg 2 0.907 vs 0.902: a row
+      // executed for three lanes ends after the one or two blocks of points those lanes have, a row executed for 64
+      // lanes runs to the longest of 64 lists, and the second phase costs 29 spilled VGPRs at the 128-register cap.
+      // Off by default.
+      auto query_cells = [&]() -> bool {
+        uint32_t flags = 0u;  // bit i: sample i goes on to phase B; bit 8 + i: it is an interior sample (threshold applies)
+  #pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          if (open[i]) {
+            const bool interior = thr_top != 0u && memb[row[i]] == 1u;
+            bool more;
+            best[i] = sample_rows(p[i], best[i], interior ? thr_top : 0u, Row0{}, Row1{}, more);
+            flags |= (more ? 1u : 0u) << i | (interior ? 256u : 0u) << i;
+            if (!more) open[i] = !(best[i] <= c_ok);
+          }
+        }
+        float4* const s_x = reinterpret_cast<float4*>(s_leaf);            // 64 entries: x, y, z, minimum
+        uint32_t* const s_t = reinterpret_cast<uint32_t*>(s_leaf) + 256;  // 64 thresholds
+        static_assert(MAXLEAF * sizeof(int) >= 64 * 16 + 64 * 4, "the compacted samples fit the leaf list's storage");
+        unsigned long long m[SPL];
+        int n_surv = 0;
+  #pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          m[i] = __ballot(((flags >> i) & 1u) != 0u);
+          n_surv += __popcll(m[i]);
+        }
+        for (int b0 = 0; b0 < n_surv; b0 += 64) {  // (wave-uniform)
+          int off = 0;
+  #pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            const int pos = off + lane_rank(m[i]) - b0;
+            if (((flags >> i) & 1u) && pos >= 0 && pos < 64) {
+              s_x[pos] = make_float4(p[i][0], p[i][1], DIM > 2 ? p[i][DIM > 2 ? 2 : 0] : 0.f, best[i]);
+              s_t[pos] = ((flags >> (8 + i)) & 1u) ? thr_top : 0u;
+            }
+            off += __popcll(m[i]);
+          }
+          wave_lds_sync();
+          if (b0 + lane < n_surv) {
+            const float4 e = s_x[lane];
+            float ps[DIM];
+            ps[0] = e.x;
+            ps[1] = e.y;
+            if constexpr (DIM == 3) ps[2] = e.z;
+            bool more;
+            const float bq = sample_rows(ps, e.w, s_t[lane], Row1{}, RowN{}, more);
+            s_x[lane].w = bq;
+          }
+          wave_lds_sync();
+          off = 0;
+  #pragma unroll
+          for (int i = 0; i < SPL; ++i) {
+            const int pos = off + lane_rank(m[i]) - b0;
+            if (((flags >> i) & 1u) && pos >= 0 && pos < 64) {
+              best[i] = s_x[pos].w;
+              open[i] = !(best[i] <= c_ok);
+            }
+            off += __popcll(m[i]);
+          }
+          wave_lds_sync();
+        }
+        bool any_open = false;
+  #pragma unroll
+        for (int i = 0; i < SPL; ++i) any_open = any_open || open[i];
+        return any_open;
+      };
+#else
       auto query_cells = [&]() -> bool {
         bool any_open = false;
   #pragma unroll
         for (int i = 0; i < SPL; ++i) {
           if (open[i]) {
             const uint32_t thr_i = (thr_top != 0u && memb[row[i]] == 1u) ? thr_top : 0u;
-            int ck[DIM];
-            float gap2[DIM][3];  // squared distance from the sample to the cell slab at offset -1 / 0 / +1
-  #pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-              const float tf = (p[i][k] - g0[k]) * inv_c;
-              const int t = (int)tf;
-              ck[k] = t < 1 ? 1 : (t > nc[k] - 2 ? nc[k] - 2 : t);
-              const float f = tf - (float)ck[k];  // position inside the (clamped) cell, in cells
-              const float lo_gap = __builtin_fmaxf(f, 0.f) * c * 0.999f;
-              const float hi_gap = __builtin_fmaxf(1.f - f, 0.f) * c * 0.999f;
-              gap2[k][0] = lo_gap * lo_gap;
-              gap2[k][1] = 0.f;
-              gap2[k][2] = hi_gap * hi_gap;
-            }
-            float b = best[i];
-            // rows of 3 cells along x, nearest first; a row is skipped when even its slab is no closer
-            // than the running minimum
-            constexpr int NROW = DIM == 3 ? 9 : 3;
-            constexpr int ORD3[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-            constexpr int ORD2[3] = {0, -1, 1};
-            // (row strides are wave-uniform; 24-bit multiplies run at full rate, 32-bit ones at a quarter)
-            const int stride_y = nc[0], stride_z = DIM == 3 ? nc[0] * nc[1] : 0;
-            int base0 = __mul24(ck[1], stride_y) + ck[0] - 1;
-            if constexpr (DIM == 3) base0 += __mul24(ck[DIM - 1], stride_z);
-#ifdef FLOODER_QUERY_DIAG
-            int rows_seen = 0;
-#endif
-  #pragma unroll
-            for (int rw = 0; rw < NROW; ++rw) {
-              int base;
-              float lb;
-              if constexpr (DIM == 3) {
-                const int dy = ORD3[rw][0], dz = ORD3[rw][1];
-                base = base0 + dy * stride_y + dz * stride_z;
-                lb = gap2[1][dy + 1] + gap2[DIM - 1][dz + 1];
-              } else {
-                const int dy = ORD2[rw];
-                base = base0 + dy * stride_y;
-                lb = gap2[1][dy + 1];
-              }
-              if (!(lb < b)) continue;
-#ifdef FLOODER_QUERY_DIAG
-              ++rows_seen;
-#endif
-              // the row's outer cells are dropped too when their slab is no closer than the running minimum
-              const int first = (lb + gap2[0][0] < b) ? 0 : 1;
-              const int last = (lb + gap2[0][2] < b) ? 3 : 2;
-              const int bg = s_cell[base + first];
-              const int en = s_cell[base + last];
-              if (has_stats) n_pairs += (unsigned long long)(en - bg);
-              // 4 LDS reads in flight; entries past `en` are real points of later cells or the +inf pads behind
-              // the list - a minimum over more real points is still a valid upper bound, and exact once verified
-              for (int j = bg & ~3; j < en; j += 4) {
-                float4 x[4];
-  s_pts.get4(j, x);
-  #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  float t0 = p[i][0] - x[u].x;
-                  float d2 = t0 * t0;
-                  t0 = p[i][1] - x[u].y;
-                  d2 = __builtin_fmaf(t0, t0, d2);
-                  if constexpr (DIM == 3) {
-                    t0 = p[i][2] - x[u].z;
-                    d2 = __builtin_fmaf(t0, t0, d2);
-                  }
-                  b = __builtin_fminf(b, d2);
-                }
-              }
-              if (__float_as_uint(b) <= thr_i) b = 0.f;  // (dropped: cannot raise the simplex's maximum)
-            }
-#ifdef FLOODER_QUERY_DIAG
-            {  // diagnostic build: rows of cells visited per queried sample, [10]: samples dropped against the maximum
-              unsigned long long* const dst = ARG(stats);
-              if (dst) { atomicAdd(&dst[100 + rows_seen], 1ull); if (b == 0.f) atomicAdd(&dst[110], 1ull); }
-            }
-#endif
-            best[i] = b;
-            open[i] = !(b <= c_ok);
+            bool more;
+            best[i] = sample_rows(p[i], best[i], thr_i, Row0{}, RowN{}, more);
+            open[i] = !(best[i] <= c_ok);
           }
           any_open = any_open || open[i];
         }
         return any_open;
       };
+#endif
       if constexpr (SUPER) {
         for (int sub = n_sub - 1; sub >= 0; --sub) {  // (the last chunk's samples are still in registers)
           q = q_first + sub;
