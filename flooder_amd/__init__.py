@@ -7,7 +7,7 @@ script is ``python -m flooder_amd.cli``.  ROCm tensors run hand-written HIP kern
 """
 
 from .core import (flood_complex, generate_landmarks, generate_grid, generate_uniform_weights, PointIndex,
-                   index_from_host)
+                   index_from_host, forget_index)
 from .simplex_tree import SimplexTree, DelaunayComplex
 from .io import save_to_disk
 from .synthetic import (
@@ -26,6 +26,7 @@ __all__ = [
     "generate_uniform_weights",
     "PointIndex",
     "index_from_host",
+    "forget_index",
     "SimplexTree",
     "DelaunayComplex",
     "save_to_disk",
