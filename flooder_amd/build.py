@@ -20,7 +20,8 @@ HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
 PY_LIB = os.path.join(PKG_DIR, "libflooder_py.so")   # CPython-API helpers (loaded with ctypes.PyDLL)
 
 HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
-HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp"]
+HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp", "delaunay2d.cpp"]
+HOST_HEADERS = ["exact_int.hpp"]
 
 
 def _newer(target: str, sources) -> bool:
@@ -86,7 +87,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not srcs:
         return ""
-    if not force and _newer(HOST_LIB, srcs):
+    if not force and _newer(HOST_LIB, srcs + [os.path.join(CSRC, h) for h in HOST_HEADERS]):
         return HOST_LIB
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:

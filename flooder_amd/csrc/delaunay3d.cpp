@@ -18,75 +18,9 @@
 //   returns the number of tetrahedra written (vertex ids in no particular order), -needed when cap is too small,
 //   or a FLOODER_DELAUNAY_* code < -(1 << 40) when the input is not one this routine takes (duplicates, all points
 //   coplanar, coordinates that do not scale to 58-bit integers, an inconsistent cavity): the caller uses Qhull then.
-#include <algorithm>
-#include <cmath>
-#include <cstdint>
-#include <cstring>
-#include <vector>
+#include "exact_int.hpp"
 
 namespace {
-
-constexpr int64_t E_BASE = -((int64_t)1 << 40);
-constexpr int64_t E_FEW = E_BASE - 1, E_RANGE = E_BASE - 2, E_FLAT = E_BASE - 3, E_DUP = E_BASE - 4, E_CAVITY = E_BASE - 5,
-                  E_LOCATE = E_BASE - 6;
-
-// ---- 512-bit two's complement integers: just enough for the exact predicates
-struct Big {
-  static constexpr int L = 8;
-  uint64_t w[L];
-};
-inline Big big_from(__int128 v) {
-  Big r;
-  r.w[0] = (uint64_t)v;
-  r.w[1] = (uint64_t)(v >> 64);
-  const uint64_t ext = v < 0 ? ~0ull : 0ull;
-  for (int i = 2; i < Big::L; ++i) r.w[i] = ext;
-  return r;
-}
-inline bool big_neg(const Big& a) { return (a.w[Big::L - 1] >> 63) != 0; }
-inline Big big_add(const Big& a, const Big& b) {
-  Big r;
-  unsigned __int128 c = 0;
-  for (int i = 0; i < Big::L; ++i) {
-    c += (unsigned __int128)a.w[i] + b.w[i];
-    r.w[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  return r;
-}
-inline Big big_negate(const Big& a) {
-  Big r;
-  unsigned __int128 c = 1;
-  for (int i = 0; i < Big::L; ++i) {
-    c += (unsigned __int128)(~a.w[i]);
-    r.w[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  return r;
-}
-inline Big big_sub(const Big& a, const Big& b) { return big_add(a, big_negate(b)); }
-inline Big big_mul(const Big& a, const Big& b) {  // (magnitudes stay far below 2^511 here: no overflow check)
-  const bool na = big_neg(a), nb = big_neg(b);
-  const Big x = na ? big_negate(a) : a, y = nb ? big_negate(b) : b;
-  Big r;
-  std::memset(r.w, 0, sizeof(r.w));
-  for (int i = 0; i < Big::L; ++i) {
-    if (!x.w[i]) continue;
-    unsigned __int128 c = 0;
-    for (int j = 0; i + j < Big::L; ++j) {
-      c += (unsigned __int128)x.w[i] * y.w[j] + r.w[i + j];
-      r.w[i + j] = (uint64_t)c;
-      c >>= 64;
-    }
-  }
-  return na != nb ? big_negate(r) : r;
-}
-inline int big_sign(const Big& a) {
-  if (big_neg(a)) return -1;
-  for (int i = 0; i < Big::L; ++i)
-    if (a.w[i]) return 1;
-  return 0;
-}
 
 struct Mesh {
   int64_t n = 0;
@@ -100,6 +34,10 @@ struct Mesh {
   std::vector<int> free_slots, mark;
   int INF = 0;
   long exact_calls = 0;
+  // static filters (first stage of both predicates): with every coordinate difference bounded by D = the largest
+  // extent of the bounding box, the permanent of Shewchuk's bound is at most 6 D^3 (orient) / 72 D^5 (insphere); a
+  // determinant beyond that error needs neither the permanent nor the exact stage
+  double orient_static = 0.0, insphere_static = 0.0;
 
   // face opposite vertex i, oriented so that (face, v[i]) is an even permutation of (v0, v1, v2, v3)
   static constexpr int FACE[4][3] = {{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}};
@@ -126,6 +64,8 @@ struct Mesh {
     const double bdxcdy = bdx * cdy, cdxbdy = cdx * bdy, cdxady = cdx * ady, adxcdy = adx * cdy, adxbdy = adx * bdy,
                  bdxady = bdx * ady;
     const double det = adz * (bdxcdy - cdxbdy) + bdz * (cdxady - adxcdy) + cdz * (adxbdy - bdxady);
+    if (det > orient_static) return 1;
+    if (-det > orient_static) return -1;
     const double perm = (std::fabs(bdxcdy) + std::fabs(cdxbdy)) * std::fabs(adz) +
                         (std::fabs(cdxady) + std::fabs(adxcdy)) * std::fabs(bdz) +
                         (std::fabs(adxbdy) + std::fabs(bdxady)) * std::fabs(cdz);
@@ -178,6 +118,8 @@ struct Mesh {
     const double alift = aex * aex + aey * aey + aez * aez, blift = bex * bex + bey * bey + bez * bez;
     const double clift = cex * cex + cey * cey + cez * cez, dlift = dex * dex + dey * dey + dez * dez;
     const double det = (dlift * abc - clift * dab) + (blift * cda - alift * bcd);
+    if (det > insphere_static) return 1;
+    if (-det > insphere_static) return -1;
     const double az = std::fabs(aez), bz = std::fabs(bez), cz = std::fabs(cez), dz = std::fabs(dez);
     const double perm =
         ((std::fabs(cexdey) + std::fabs(dexcey)) * bz + (std::fabs(dexbey) + std::fabs(bexdey)) * cz + (std::fabs(bexcey) + std::fabs(cexbey)) * dz) * alift +
@@ -279,7 +221,15 @@ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
   return spread(x) | spread(y) << 1 | spread(z) << 2;
 }
 
+int g_local_max = 160;   // boundary vertices up to which the edges of a cavity's boundary are linked through the local table
+
 }  // namespace
+
+extern "C" int flooder_delaunay3d_local_edges(int max_vertices) {
+  const int old = g_local_max;
+  if (max_vertices >= 0 && max_vertices <= 4096) g_local_max = max_vertices;
+  return old;
+}
 
 extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tets, int64_t cap) {
   if (!pts || n < 5 || n > 0x3fffffff) return E_FEW;
@@ -288,18 +238,8 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
   m.p = pts;
   m.INF = (int)n;
   // ---- integer coordinates on a common dyadic grid
-  int emin = 1 << 30, emax = -(1 << 30);
-  for (int64_t i = 0; i < 3 * n; ++i) {
-    const double x = pts[i];
-    if (!std::isfinite(x)) return E_RANGE;
-    if (x == 0.0) continue;
-    int e;
-    const double f = std::frexp(std::fabs(x), &e);          // |x| = f 2^e, f in [0.5, 1)
-    const uint64_t M = (uint64_t)std::ldexp(f, 53);          // 53-bit integer mantissa
-    const int low = e - 53 + __builtin_ctzll(M);             // exponent of the lowest set bit
-    emin = low < emin ? low : emin;
-    emax = e > emax ? e : emax;
-  }
+  int emin, emax;
+  if (!dyadic_range(pts, 3 * n, emin, emax)) return E_RANGE;
   if (emin > emax) return E_FLAT;            // (all coordinates zero)
   if (emax - emin > 57) return E_RANGE;      // would not fit 58-bit integers: not for this routine
   m.q.resize(3 * (size_t)n);
@@ -312,6 +252,15 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
       lo[k] = std::min(lo[k], pts[3 * i + k]);
       hi[k] = std::max(hi[k], pts[3 * i + k]);
     }
+  {
+    // (1 + 2^-20: room for the roundings of the bound itself; differences of points inside the box are at most D,
+    // rounded differences at most D (1 + eps), which the factor covers as well)
+    double D = 0.0;
+    for (int k = 0; k < 3; ++k) D = std::max(D, hi[k] - lo[k]);
+    D *= 1.000001;
+    m.orient_static = 7.771561172376103e-16 * 6.0 * D * D * D * 1.000001;
+    m.insphere_static = 1.7763568394002532e-15 * 72.0 * D * D * D * D * D * 1.000001;
+  }
   std::vector<std::pair<uint64_t, int>> order((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
     uint32_t c[3];
@@ -380,7 +329,13 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
     if (!links.done()) return E_CAVITY;
   }
   int last = 0;  // a finite tetrahedron to start the walk from
-  std::vector<int> cavity, stack, fresh;
+  std::vector<int> cavity, stack, fresh, bfaces;
+  struct LocalEdge { uint32_t stamp; int tf; };   // tf: 4 * tetrahedron + face waiting on this edge, -1 once matched
+  const int LOCAL_MAX = g_local_max;
+  std::vector<LocalEdge> etab;
+  std::vector<uint32_t> vstamp((size_t)n + 1, 0u);
+  std::vector<int> vloc((size_t)n + 1, 0);
+  uint32_t vstamp_now = 0, estamp = 0;
   std::vector<char> used((size_t)n, 0);
   for (int i = 0; i < 4; ++i) used[(size_t)s[i]] = 1;
 
@@ -441,37 +396,85 @@ extern "C" int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tet
         }
       }
     }
-    // ---- a new tetrahedron on every boundary face of the cavity
-    links.begin(3 * cavity.size() + 16);   // (about 2 c + 2 boundary faces, 1.5 distinct edges each)
-    fresh.clear();
+    // ---- a new tetrahedron on every boundary face of the cavity.  The faces of the new tetrahedra that meet in the
+    // new vertex are linked through the boundary's edges: exactly two of them share every edge.  The boundary has a
+    // few dozen vertices: they are numbered locally (stamped per insertion) and an edge is a cell of a K x K table -
+    // no hashing, no probing (the hashed EdgeLinks, 66 cycles per face, was over half of an insertion); a boundary
+    // of more than LOCAL_MAX vertices falls back to it.
+    bfaces.clear();
+    int K = 0;
+    if (++vstamp_now == 0) { std::fill(vstamp.begin(), vstamp.end(), 0u); vstamp_now = 1; }
     for (const int c : cavity) {
       for (int i = 0; i < 4; ++i) {
         const int u = m.t[(size_t)c].nb[i];
         if (m.mark[(size_t)u] == in_cav) continue;   // (inside the cavity)
-        const int a = m.t[(size_t)c].v[Mesh::FACE[i][0]], b = m.t[(size_t)c].v[Mesh::FACE[i][1]],
-                  d = m.t[(size_t)c].v[Mesh::FACE[i][2]];
-        const int nt = m.new_tet();   // (may move m.t: no references held across it)
-        m.mark[(size_t)nt] = -1;
-        Mesh::Tet& N = m.t[(size_t)nt];
-        N.v[0] = a; N.v[1] = b; N.v[2] = d; N.v[3] = pi;
-        N.nb[3] = u;
-        Mesh::Tet& U = m.t[(size_t)u];
-        int back = -1;
-        for (int j = 0; j < 4; ++j)
-          if (U.nb[j] == c) {
-            // (two tetrahedra can share two faces only in degenerate cavities: the face must also match)
-            const int x = U.v[Mesh::FACE[j][0]], y = U.v[Mesh::FACE[j][1]], z = U.v[Mesh::FACE[j][2]];
-            if ((x == a || x == b || x == d) && (y == a || y == b || y == d) && (z == a || z == b || z == d)) back = j;
-          }
-        if (back < 0) return E_CAVITY;
-        U.nb[back] = nt;
+        bfaces.push_back(4 * c + i);
+        for (int k = 0; k < 3; ++k) {
+          const int v = m.t[(size_t)c].v[Mesh::FACE[i][k]];
+          if (vstamp[(size_t)v] != vstamp_now) { vstamp[(size_t)v] = vstamp_now; vloc[(size_t)v] = K++; }
+        }
+      }
+    }
+    const bool local = K <= LOCAL_MAX;
+    if (local) {
+      if (etab.size() < (size_t)K * (size_t)K) etab.resize((size_t)K * (size_t)K, LocalEdge{0u, -1});
+      if (++estamp == 0) { std::fill(etab.begin(), etab.end(), LocalEdge{0u, -1}); estamp = 1; }
+    } else {
+      links.begin(3 * cavity.size() + 16);   // (about 2 c + 2 boundary faces, 1.5 distinct edges each)
+    }
+    int open_edges = 0;
+    bool bad_edge = false;
+    auto link_local = [&](int a, int b, int tet, int face) {
+      int la = vloc[(size_t)a], lb = vloc[(size_t)b];
+      if (la > lb) std::swap(la, lb);
+      LocalEdge& e = etab[(size_t)la * (size_t)K + (size_t)lb];
+      if (e.stamp != estamp) {
+        e.stamp = estamp;
+        e.tf = 4 * tet + face;
+        ++open_edges;
+      } else if (e.tf < 0) {
+        bad_edge = true;                          // a third face on this edge: not a manifold boundary
+      } else {
+        const int ot = e.tf >> 2, of = e.tf & 3;
+        m.t[(size_t)ot].nb[of] = tet;
+        m.t[(size_t)tet].nb[face] = ot;
+        e.tf = -1;                                // matched
+        --open_edges;
+      }
+    };
+    fresh.clear();
+    for (const int cf : bfaces) {
+      const int c = cf >> 2, i = cf & 3;
+      const int u = m.t[(size_t)c].nb[i];
+      const int a = m.t[(size_t)c].v[Mesh::FACE[i][0]], b = m.t[(size_t)c].v[Mesh::FACE[i][1]],
+                d = m.t[(size_t)c].v[Mesh::FACE[i][2]];
+      const int nt = m.new_tet();   // (may move m.t: no references held across it)
+      m.mark[(size_t)nt] = -1;
+      Mesh::Tet& N = m.t[(size_t)nt];
+      N.v[0] = a; N.v[1] = b; N.v[2] = d; N.v[3] = pi;
+      N.nb[3] = u;
+      Mesh::Tet& U = m.t[(size_t)u];
+      int back = -1;
+      for (int j = 0; j < 4; ++j)
+        if (U.nb[j] == c) {
+          // (two tetrahedra can share two faces only in degenerate cavities: the face must also match)
+          const int x = U.v[Mesh::FACE[j][0]], y = U.v[Mesh::FACE[j][1]], z = U.v[Mesh::FACE[j][2]];
+          if ((x == a || x == b || x == d) && (y == a || y == b || y == d) && (z == a || z == b || z == d)) back = j;
+        }
+      if (back < 0) return E_CAVITY;
+      U.nb[back] = nt;
+      if (local) {
+        link_local(b, d, nt, 0);
+        link_local(a, d, nt, 1);
+        link_local(a, b, nt, 2);
+      } else {
         links.add(m.t, b, d, nt, 0);
         links.add(m.t, a, d, nt, 1);
         links.add(m.t, a, b, nt, 2);
-        fresh.push_back(nt);
       }
+      fresh.push_back(nt);
     }
-    if (!links.done()) return E_CAVITY;
+    if (local ? (bad_edge || open_edges != 0) : !links.done()) return E_CAVITY;
     for (const int c : cavity) {
       m.t[(size_t)c].v[0] = -2;   // dead
       m.mark[(size_t)c] = -1;

@@ -111,22 +111,22 @@ def delaunay_cells(points: np.ndarray) -> np.ndarray:
         # fewer points than a full simplex: a single (n-1)-simplex on all points
         cells = np.arange(n, dtype=np.int64)[None, :]
     else:
-        cells = _delaunay3d_native(points) if (dim == 3 and NATIVE_DELAUNAY and n >= 5) else None
+        cells = _delaunay_native(points) if (dim in (2, 3) and NATIVE_DELAUNAY and n >= dim + 2) else None
         if cells is None:
             cells = Delaunay(points).simplices
     return _unique_rows(np.sort(np.asarray(cells, dtype=np.int64), axis=1))
 
 
-NATIVE_DELAUNAY = True   # 3-D: csrc/delaunay3d.cpp (libflooder_host.so) instead of Qhull; falls back to Qhull where it declines
+NATIVE_DELAUNAY = True   # 2-D / 3-D: csrc/delaunay2d.cpp, delaunay3d.cpp (libflooder_host.so) instead of Qhull; falls back to Qhull where they decline
 LAST_DELAUNAY = {"native": False, "code": 0}
 _HOST_DT = False
 
 
-def _delaunay3d_native(points: np.ndarray) -> Optional[np.ndarray]:
-    """Tetrahedra of the 3-D Delaunay triangulation from ``flooder_delaunay3d`` (incremental insertion with exact
-    predicates, host C++), or None where the routine declines the input (duplicate points, all points coplanar,
-    coordinates that do not scale to 58-bit integers - float64 clouds with a wide exponent range) or the library is
-    not there: the caller then asks Qhull as before."""
+def _delaunay_native(points: np.ndarray) -> Optional[np.ndarray]:
+    """Cells of the 2-D / 3-D Delaunay triangulation from ``flooder_delaunay2d`` / ``flooder_delaunay3d`` (incremental
+    insertion with exact predicates, host C++), or None where the routine declines the input (duplicate points, all
+    points collinear / coplanar, coordinates that do not scale to 58-bit integers - float64 clouds with a wide
+    exponent range) or the library is not there: the caller then asks Qhull as before."""
     global _HOST_DT
     if _HOST_DT is False:
         _HOST_DT = None
@@ -135,12 +135,10 @@ def _delaunay3d_native(points: np.ndarray) -> Optional[np.ndarray]:
 
             from . import build
 
-            path = build.HOST_LIB
-            if not os.path.exists(path) or not build._newer(path, [os.path.join(build.CSRC, f) for f in build.HOST_SOURCES]):
-                build.build_host()
-            lib = ctypes.CDLL(path)
-            lib.flooder_delaunay3d.restype = ctypes.c_int64
-            lib.flooder_delaunay3d.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+            lib = ctypes.CDLL(build.build_host())
+            for f in (lib.flooder_delaunay2d, lib.flooder_delaunay3d):
+                f.restype = ctypes.c_int64
+                f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
             _HOST_DT = lib
         except Exception:
             _HOST_DT = None
@@ -148,11 +146,13 @@ def _delaunay3d_native(points: np.ndarray) -> Optional[np.ndarray]:
     if _HOST_DT is None:
         return None
     pts = np.ascontiguousarray(points, dtype=np.float64)
-    n = pts.shape[0]
-    cap = 8 * n + 64          # (a 3-D Delaunay triangulation of n points in general position has ~6.8 n tetrahedra)
+    n, dim = pts.shape
+    fn = _HOST_DT.flooder_delaunay3d if dim == 3 else _HOST_DT.flooder_delaunay2d
+    # (n points in general position: ~6.8 n tetrahedra, at most 2 n triangles)
+    cap = 8 * n + 64 if dim == 3 else 2 * n + 16
     for _ in range(2):
-        out = np.empty((cap, 4), dtype=np.int32)
-        rc = int(_HOST_DT.flooder_delaunay3d(pts.ctypes.data, n, out.ctypes.data, cap))
+        out = np.empty((cap, dim + 1), dtype=np.int32)
+        rc = int(fn(pts.ctypes.data, n, out.ctypes.data, cap))
         if rc >= 0:
             LAST_DELAUNAY.update(native=True, code=rc)
             return out[:rc].astype(np.int64)
@@ -161,6 +161,9 @@ def _delaunay3d_native(points: np.ndarray) -> Optional[np.ndarray]:
             return None
         cap = -rc
     return None
+
+
+_delaunay3d_native = _delaunay_native   # (name of the round-5 3-D entry point, kept for tools and tests)
 
 
 def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,

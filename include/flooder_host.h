@@ -16,7 +16,8 @@ extern "C" {
 #endif
 
 /*
- * Delaunay triangulation of n >= 5 points in THREE dimensions (csrc/delaunay3d.cpp).  Replaces
+ * Delaunay triangulation of n >= 5 points in THREE dimensions (csrc/delaunay3d.cpp; two dimensions: below; other
+ * dimensions stay with Qhull).  Replaces
  * gudhi.DelaunayComplex(landmarks) of core.py:130-132 (the top cells; core.py:136-138 buckets their faces) and the
  * Qhull call this build made through scipy.  Incremental Bowyer-Watson with ghost tetrahedra, orient3d / insphere
  * decided exactly (double filter, then 512-bit integers on a common dyadic grid of the coordinates).
@@ -27,6 +28,23 @@ extern "C" {
  *   triangulates with Qhull instead (flooder_amd.simplex_tree.delaunay_cells does).
  */
 int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tets, int64_t cap);
+
+/*
+ * The same in TWO dimensions (csrc/delaunay2d.cpp; n >= 3 points, the reference's 2-D clouds: annulus, figure eight):
+ * ghost triangles, orient2d / incircle behind a static bound, Shewchuk's bound, then exact integers.
+ *   pts: n x 2 float64, row-major (host).  tris: cap x 3 int32 (host), vertex ids counter-clockwise.
+ *   returns as flooder_delaunay3d: triangles written; -needed; or a code below -(1 << 40) when it declines (duplicate
+ *   points, all points collinear, non-finite values, an exponent spread of more than 57 bits).
+ */
+int64_t flooder_delaunay2d(const double* pts, int64_t n, int32_t* tris, int64_t cap);
+
+/*
+ * Test hook of flooder_delaunay3d: the new tetrahedra of an insertion are linked to each other through the edges of
+ * the cavity's boundary - a table over the boundary's locally numbered vertices while there are at most
+ * `max_vertices` of them (default 160), a hash table beyond.  0 forces the hash table.  Returns the previous value;
+ * a value outside 0 .. 4096 only reads it.  Either way the triangulation is the same.
+ */
+int flooder_delaunay3d_local_edges(int max_vertices);
 
 /*
  * Z/2 persistent homology of a filtered complex (csrc/persistence.cpp): column reduction with clearing.  Replaces

@@ -140,10 +140,11 @@ def test_host_libraries_export_header_symbols():
 
     header = open(os.path.join(ROOT, "include", "flooder_host.h")).read()
     declared = set(re.findall(r"\b(flooder_[a-z0-9_]+)\s*\(", header))
-    assert declared == {"flooder_delaunay3d", "flooder_persistence_z2", "flooder_filtration_order", "flooder_dict_update"}
+    assert declared == {"flooder_delaunay3d", "flooder_delaunay2d", "flooder_delaunay3d_local_edges", "flooder_persistence_z2",
+                        "flooder_filtration_order", "flooder_dict_update"}
     build.build_host()
     host = ctypes.CDLL(build.HOST_LIB)
-    assert all(hasattr(host, f) for f in ("flooder_delaunay3d", "flooder_persistence_z2", "flooder_filtration_order"))
+    assert all(hasattr(host, f) for f in declared - {"flooder_dict_update"})
     if build.build_py():
         assert hasattr(ctypes.PyDLL(build.PY_LIB), "flooder_dict_update")
 
