@@ -67,11 +67,14 @@ KERNEL_OF_SPAN = {"sweep": "wit_sweep_kernel + cell_sweep_kernel", "sweep_bvh": 
 
 
 def kernel_source_sha() -> str:
-    """Fingerprint of the kernel sources: profiles/traffic.json entries carry the value they were measured with."""
+    """Fingerprint of the kernel sources (the .hip files and the headers they include; not the host-only headers of
+    libflooder_host.so): profiles/traffic.json entries carry the value they were measured with."""
+    from flooder_amd.build import HOST_HEADERS
+
     h = hashlib.sha256()
     d = os.path.join(ROOT, "flooder_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp")) and name not in HOST_HEADERS:
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -710,8 +713,9 @@ def main():
                         "walk: 350 leaf tests and 60 node expansions per 90 evaluated leaves of a 64-sample tile in 6D, "
                         "7 waves per SIMD; the leaf rows come from the Infinity Cache (the cloud fits)"
                         if args.method == "bvh" else
-                        "fp32 VALU issue + dependent-latency chains (LDS round trips, tree-node loads) at 3 waves per "
-                        "SIMD (cell sweep) / 4 (witness sweep); HBM traffic is a few percent of peak"),
+                        "fp32 VALU issue (cell sweep: the vector pipe ~70 % busy by SQ_INSTS_VALU x 2 cycles, half of its "
+                        "instructions the pair arithmetic) + dependent-step chains (LDS round trips, tree-node loads, "
+                        "cross-lane reductions) at 4 waves per SIMD in both launches; HBM traffic is a few percent of peak"),
             "samples_resolved": int(S) * int(R),
             "samples_per_ns": round(int(S) * int(R) / (dom_rec["ms_per_step"] * 1e6), 3),
             "note": ("achieved counts EVALUATED pairs only (exact nearest-neighbour culling by the box tree)"

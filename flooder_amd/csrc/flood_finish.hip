@@ -30,6 +30,12 @@ constexpr int SHORT_LIST = 1024;
 #ifndef FLOODER_TOP_NODES
 #define FLOODER_TOP_NODES 1024
 #endif
+#ifndef FLOODER_FINISH_PRIO_AFTER
+#define FLOODER_FINISH_PRIO_AFTER 32  // leaves after which a tile's wave raises its issue priority (0: never)
+#endif
+#ifndef FLOODER_FINISH_PRIO
+#define FLOODER_FINISH_PRIO 3
+#endif
 #ifndef FLOODER_FINISH_WAVES
 #define FLOODER_FINISH_WAVES 4
 #endif
@@ -45,6 +51,11 @@ constexpr int TOP_NODES = FLOODER_TOP_NODES;  // nodes of the two top tree level
 // wave j descends only into the level-1 nodes j, j + 16, ... (an interleaved 1/16 of the sorted cloud).  At the end
 // of a round the minima are combined in LDS (integer atomic min), wave 0 delivers, and the next round starts - all
 // rounds of the tile back to back, three workgroup barriers each.
+// Before that (late round 5): a search is a chain of DEPENDENT steps - select, test, fetch, evaluate, reduce - that
+// uses a quarter of its wave's issue slots, and four such waves share a SIMD: a long search is long mostly because it
+// waits for its turn.  A wave whose tile has evaluated FLOODER_FINISH_PRIO_AFTER leaves raises its issue priority
+// (s_setprio): the few long searches run nearly unimpeded, the many short ones give up slots they were not the tail
+// of.  cfg 3: pass 1.87 -> 1.60 ms with the budget at 40 instead of 14 (fewer tiles need the team launch at all).
 struct HardLists {
   const unsigned long long* ent_in;   // item | sub << 32 | subs << 40 | one_round_only << 48
   const unsigned long long* mask_in;  // lanes of the focus samples of the abandoned round
@@ -397,6 +408,10 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
     bool aborted = false;
     bool on_budget = budgeted;
     int evals = 0;  // leaves evaluated for this tile (all rounds)
+#if FLOODER_FINISH_PRIO_AFTER > 0
+    int evals_all = 0;
+    __builtin_amdgcn_s_setprio(0);
+#endif
     for (;;) {
       // (TEAM: every wave of the workgroup computes the same focus set from the same minima and face maxima.  An
       // entry of the top pass asks for one sample only: its first round takes the lanes recorded with the entry.)
@@ -494,8 +509,14 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
         }
         if (__ballot(focus && (lbp * SAFE < best)) == 0ull) { FIN_PHASE(2); continue; }
         FIN_PHASE(2);  // leaf selection + test
+        const float best_before = best;
         eval_leaf(c);
         FIN_PHASE(3);  // leaf evaluation
+#if FLOODER_FINISH_PRIO_AFTER > 0
+        // a search that has outlasted the median one by far is the tail of the pass in the making: its wave takes
+        // precedence over the three it shares the SIMD with (issue is arbitrated by priority, then age)
+        if (!TEAM && ++evals_all == FLOODER_FINISH_PRIO_AFTER) __builtin_amdgcn_s_setprio(FLOODER_FINISH_PRIO);
+#endif
         if (!TEAM && on_budget && ++evals > budget_eff) {
           // a hard round: hand the tile to the next launch (unless its list is full: then carry on alone)
           const unsigned long long fm = __ballot(focus && mine);
@@ -519,7 +540,9 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
           refresh();  // other waves may have raised the face maxima meanwhile: focus samples may drop out
           focus = focus && live;
           rebound();
-        } else {
+        } else if (__ballot(focus && best != best_before) != 0ull) {
+          // (the pruning radius is the largest bound of the focus samples: it moves only when one of THEIR bounds did -
+          // in the far field a leaf in ten; the reduction is a chain of six dependent cross-lane steps)
           Mf = wave_max_f32(focus ? best : -1.f);
         }
         FIN_PHASE(4);  // bounds / live set upkeep

@@ -217,12 +217,13 @@ __global__ __launch_bounds__(256) void fps2_bucket_init_kernel(const float* __re
 // Block record of a launch (plain stores by the block that owns it, read by every wave of the next launch):
 //   b1 best point of the block's buckets | hb = best minimum of the other points of THAT point's bucket once b1 is a
 //   landmark: max over the bucket of min(m(x), d2(x, b1)) | bo best of every other point of the block (an upper
-//   bound) | landmarks applied after the launch | coordinates of the b1 point.  32-bit words:
+//   bound) | landmarks applied after the launch | m2 = the minimum of the second-best point of b1's bucket (what bounds
+//   the points behind b1 while b1 is NOT a landmark) | coordinates of the b1 point.  32-bit words:
 // (sections of 16 bytes or whole padded rows: a record is read with 16-byte loads)
 template <int DP>
 struct Rec {
   static constexpr int DPR = DP < 4 ? 4 : DP;  // row section (floats)
-  static constexpr int B1 = 0, HB = 2, BO = 4, IT = 6, T0 = 8, C = 12, WORDS = 12 + DPR;
+  static constexpr int B1 = 0, HB = 2, BO = 4, IT = 6, M2 = 7, T0 = 8, C = 12, WORDS = 12 + DPR;
 };
 constexpr int NREC = 4;  // records per lane: at most 256 blocks
 
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     brad = __uint_as_float((uint32_t)keys[3 * b + 2]);
   }
   u64 a[NREC];
-  float ac[NREC][DIM], ahb[NREC];
+  float ac[NREC][DIM], ahb[NREC], am2[NREC];
   u64 bo = 0ull;
   int it_rec = 0;
 #pragma unroll
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     const int idx = lane + 64 * t;
     a[t] = 0ull;
     ahb[t] = 0.f;
+    am2[t] = 0.f;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) ac[t][k] = 0.f;
     if (!init_only && idx < (int)gridDim.x) {
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
       const uint4 h1 = *reinterpret_cast<const uint4*>(r + RC::BO);   // bo, landmarks so far
       a[t] = ((u64)h0.y << 32) | (u64)h0.x;
       ahb[t] = __uint_as_float(h0.z);
+      am2[t] = __uint_as_float(h1.w);
       const u64 o = ((u64)h1.y << 32) | (u64)h1.x;
       bo = o > bo ? o : bo;
       if (t == 0) it_rec = (int)h1.z;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     // hidden behind one (the points hidden behind a winner are accounted for at acceptance).  All candidates are
     // ranked at once: compacted through LDS (one per lane), each lane counts the candidates above its own.
     __shared__ u64 s_ckey[4][64];
-    __shared__ float s_cdat[4][64][DIM + 1];
+    __shared__ float s_cdat[4][64][DIM + 2];
     u64 B = wave_max_key(bo);
     int total = 0;
 #pragma unroll
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
         if (is) {
           s_ckey[wv][slot] = a[t];
           s_cdat[wv][slot][DIM] = ahb[t];
+          s_cdat[wv][slot][DIM + 1] = am2[t];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) s_cdat[wv][slot][k] = ac[t][k];
         }
@@ -362,12 +366,13 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     u64 key = 0ull;
-    float ci[DIM], hbi = 0.f;
+    float ci[DIM], hbi = 0.f, m2i = 0.f;
 #pragma unroll
     for (int k = 0; k < DIM; ++k) ci[k] = 0.f;
     if (lane < n_c) {
       key = s_ckey[wv][lane];
       hbi = s_cdat[wv][lane][DIM];
+      m2i = s_cdat[wv][lane][DIM + 1];
 #pragma unroll
       for (int k = 0; k < DIM; ++k) ci[k] = s_cdat[wv][lane][k];
     }
@@ -376,45 +381,73 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     for (int j = 0; j < n_c; ++j) rank += readlane_u64(key, j) > key ? 1 : 0;
     const float mi = __uint_as_float((uint32_t)(key >> 32));
     // ---- acceptance, candidate by candidate in ranking order; every lane tracks its own candidate against the
-    // accepted ones (within its own minimum of one of them? below the points hidden behind one of them?), so a step
-    // costs a few cross-lane reads, not a reduction
-    u64 ck[KMAX];
-    float cc[KMAX][DIM];   // coordinates of the accepted candidates
-    bool conflict = false;
+    // accepted ones (how far has its minimum fallen? is it below the points hidden behind one of them?), so a step
+    // costs a few cross-lane reads, not a reduction.  A candidate whose minimum an accepted landmark has LOWERED is
+    // not the next landmark at its old rank - but it does not close the batch either (that closed 56 - 73 % of the
+    // batches): it is skipped, and what it and the points of its bucket can still amount to - its lowered key, the
+    // minimum m2 of its bucket's second-best point - bounds every later acceptance (`low`).  The next candidate in
+    // the ranking with an untouched minimum above that bound, above B and above the hidden points is the arg-max of
+    // the sequential selection: unprocessed candidates and the points behind them are below it by the ranking,
+    // skipped ones by `low`, everything else by B / hmax.
+    u64 acc_key = 0ull;    // lane i: the i-th accepted candidate
+    float acc_c[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) acc_c[k] = 0.f;
+    float mlow = mi;       // this lane's candidate: its minimum after the landmarks accepted so far
     float hmax = 0.f;      // largest bound of the points hidden in an accepted candidate's own bucket
-    bool open = true;
+    u64 low = 0ull;        // bound of the skipped candidates and the points behind them
     int why = 4;           // (diagnostic, record word 3 of block 0) what closed the batch: 1 nothing above B, 2 a
-                           // candidate within its own minimum of an accepted one, 3 hidden points, 4 KMAX / the end
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      ck[j] = 0ull;
-#pragma unroll
-      for (int k = 0; k < DIM; ++k) cc[j][k] = 0.f;
-      if (open && j < n_lms - it) {  // (wave-uniform)
-        const u64 sm = __ballot(valid && rank == j);
-        if (sm == 0ull) {
-          why = 1;
-          open = false;
-        } else {
-          const int src = __builtin_ctzll(sm);
-          const bool hidden = !(mi > 0.f && mi > hmax);
-          const u64 fm = __ballot(conflict || hidden);
-          if (j > 0 && ((fm >> src) & 1ull)) {
-            why = ((__ballot(conflict) >> src) & 1ull) ? 2 : 3;
-            open = false;
-          } else {
-            ck[j] = readlane_u64(key, src);
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) cc[j][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci[k]), src));
-            const float hbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hbi), src));
-            nb = j + 1;
-            if (valid && rank > j) {
-              conflict = conflict || dist2<DIM>(ci, cc[j]) < mi;
-              hmax = __builtin_fmaxf(hmax, hbj);
-            }
-          }
+                           // skipped candidate (or the points behind it) may come first, 3 hidden points, 4 KMAX / the end
+    const int nb_max = KMAX < n_lms - it ? KMAX : n_lms - it;
+    for (int j = 0; j < 64; ++j) {   // (wave-uniform)
+      if (nb >= nb_max) break;
+      const u64 sm = __ballot(valid && rank == j);
+      if (sm == 0ull) {
+        why = 1;
+        break;
+      }
+      const int src = __builtin_ctzll(sm);
+      const u64 ksrc = readlane_u64(key, src);
+      if (j > 0) {
+        const float msrc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mi), src));
+        const float lsrc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mlow), src));
+        if (lsrc < msrc) {   // lowered: skipped
+          const float m2s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m2i), src));
+          const u64 lk = ((u64)__float_as_uint(lsrc) << 32) | (ksrc & 0xffffffffull);
+          const u64 bk = ((u64)__float_as_uint(m2s) << 32) | 0xffffffffull;
+          low = lk > low ? lk : low;
+          low = bk > low ? bk : low;
+          continue;
+        }
+        if (!(msrc > 0.f && msrc > hmax)) {
+          why = 3;
+          break;
+        }
+        if (!(ksrc > low)) {
+          why = 2;
+          break;
         }
       }
+      float cj[DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) cj[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ci[k]), src));
+      const float hbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hbi), src));
+      if (lane == nb) {
+        acc_key = ksrc;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) acc_c[k] = cj[k];
+      }
+      ++nb;
+      if (valid && rank > j) mlow = __builtin_fminf(mlow, dist2<DIM>(ci, cj));
+      hmax = __builtin_fmaxf(hmax, hbj);
+    }
+    u64 ck[KMAX];
+    float cc[KMAX][DIM];   // coordinates of the accepted candidates
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      ck[j] = readlane_u64(acc_key, j);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) cc[j][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_c[k]), j));
     }
     s_why = why;
     if (nb > n_lms - it) nb = n_lms - it;
@@ -537,7 +570,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
   }
   // ---- this block's record for the next launch
   __shared__ u64 s_w1[4], s_oth[4];
-  __shared__ float s_hb[4];
+  __shared__ float s_hb[4], s_m2[4];
   __shared__ float s_c[4][DIM];
   {
     const u64 w1 = wave_max_key(k1);
@@ -545,7 +578,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     const u64 oth = wave_max_key(lane == wl ? 0ull : k1);  // (the other buckets' second-best points are below their best)
     const float m2 = __uint_as_float((uint32_t)(readlane_u64(k2, wl) >> 32));
     const float rd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(brad), wl));
-    if (lane == 0) { s_w1[wv] = w1; s_oth[wv] = oth; s_hb[wv] = rd < m2 ? rd : m2; }  // (rd <= m2 already)
+    if (lane == 0) { s_w1[wv] = w1; s_oth[wv] = oth; s_hb[wv] = rd < m2 ? rd : m2; s_m2[wv] = m2; }  // (rd <= m2 already)
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
       const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc[k]), wl));
@@ -566,6 +599,7 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     r[RC::HB] = __float_as_uint(s_hb[wb]);
     r[RC::HB + 1] = (uint32_t)s_why;
     r[RC::IT] = (uint32_t)(it + nb);
+    r[RC::M2] = __float_as_uint(s_m2[wb]);
     r[RC::T0] = t_start;
     r[RC::T0 + 1] = (uint32_t)wall_clock64();
     *reinterpret_cast<u64*>(r + RC::BO) = bo;
