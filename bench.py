@@ -397,10 +397,16 @@ def main():
     stats = torch.zeros(40, dtype=torch.int64, device=dev)   # [0:9] cell sweep, [9:16] finish, [16:40] witness sweep
     plan = core.SamplePlan(weights, faces)
     # one running maximum per DISTINCT face of the complex, as flood_complex uses on one GPU (shards keep (S, F))
-    slots = None
-    if args.method == "cell" and mine is None and hook is None and not args.unfused and not args.no_slots:
+    # (a shard of the simplices shares the words as well - flood_complex does since round 5 -: a rank holds +inf for the
+    # faces of the other ranks' simplices and the ranks are combined with MIN; slots_all maps the combined vector back
+    # to (S_all, F) for the parity check)
+    slots = slots_all = None
+    if args.method == "cell" and hook is None and not args.unfused and not args.no_slots:
         rows = stree._locate(d, np.sort(simp.cpu().numpy(), axis=1))      # rows of the top table, in sweep order
-        slots = core.shared_face_slots(stree, d, rows, [v.cpu().numpy() for v in vertex_idxs], dev)
+        slots_all = core.shared_face_slots(stree, d, rows, [v.cpu().numpy() for v in vertex_idxs], dev)
+        slots = slots_all
+        if mine is not None and slots_all is not None:
+            slots = (slots_all[0][mine].contiguous(), slots_all[1], slots_all[2])
 
     sub_rows = []   # (block-sharded: rows of the sub-cloud this rank indexes)
     cloud_box_full = core.cloud_box(shard_raw) if args.shard == "blocks" else None
@@ -445,7 +451,11 @@ def main():
         else:
             out, _ = core._sweep_dimension_hip(index[0], index[1], axis, w["dim"], verts, centers, radii, weights,
                                                faces, hook, timer=timer)
-        if mine is not None:  # simplex sharding: every rank ends with all (S_all, F) values
+        if mine is not None and slots is not None:  # simplex sharding: every rank ends with the values of all distinct faces
+            with core._span(timer, "reduce"):
+                out = core.shard_slot_values(out, slots[0])
+                face_hook(out)
+        elif mine is not None:  # ... or with all (S_all, F) values
             full = torch.full((S_all, out.shape[1]), float("inf"), dtype=out.dtype, device=dev)
             full[mine] = out
             with core._span(timer, "reduce"):
@@ -547,7 +557,7 @@ def main():
     stats_step_identical = bool(torch.equal(out.view(torch.int32), out_timed.view(torch.int32)))
     out = out_timed
     if slots is not None:
-        out = out[slots[0].long()]     # (n_slots,) values per distinct face -> (S, F) for the parity check below
+        out = out[slots_all[0].long()]     # (n_slots,) values per distinct face -> (S_all, F) for the parity check below
 
     # ------------------------------------------------------------------ per-kernel numbers (rank 0's share)
     k_ms = {k: v / args.steps for k, v in timer.totals_ms().items()}   # HIP events on the launch stream

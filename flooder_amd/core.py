@@ -750,6 +750,15 @@ def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.nda
     return torch.as_tensor(slot, device=device), total, offsets
 
 
+def shard_slot_values(values: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
+    """The (n_slots,) per-face values of a rank that swept only the simplices of ``slot`` (its rows of the
+    ``shared_face_slots`` table): +inf in the words none of them touches, ready for ``all_reduce(MIN)``."""
+    covered = torch.zeros(values.shape[0], dtype=torch.bool, device=values.device)
+    if slot.numel():
+        covered[slot.reshape(-1).long()] = True
+    return torch.where(covered, values, torch.full_like(values, float("inf")))
+
+
 def simplex_order(index: "PointIndex", verts: torch.Tensor) -> torch.Tensor:
     """Work order of the simplices for the culled sweeps: descending estimated number of cloud points inside the
     simplex's bounding box (``flooder_simplex_weight_f32``).  Work per simplex is heavy-tailed - a tetrahedron in
@@ -1349,7 +1358,9 @@ def flood_complex(
     (callers that sweep one cloud several times, and every rank of a multi-GPU run; the caller vouches that
     ``points`` has not changed since: only the shape is checked).  ``simplex_shard=(rank, world)`` sweeps this rank's
     share of the simplices only (the other rows of the (S, F) values are +inf until ``face_reduce_hook`` combines
-    them): every ``world``-th simplex of the queue, or - ``shard_blocks=True``, float32 ROCm tensors, methods
+    them; on the default cell-sweep path the ranks share ONE word per distinct face of the complex as a single GPU
+    does, and what ``face_reduce_hook`` receives is that (n_slots,) vector, +inf for the faces none of this rank's
+    simplices has): every ``world``-th simplex of the queue, or - ``shard_blocks=True``, float32 ROCm tensors, methods
     ``"cell"``/``"bvh"``, landmarks that are POINTS OF THE CLOUD (the caller vouches; true for every
     ``generate_landmarks`` result) - a contiguous block of the queue, swept against an index of the sub-cloud inside
     the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too.  A dimension
@@ -1539,9 +1550,18 @@ def flood_complex(
         sv = simplex_vertices if mine is None else simplex_vertices[mine]
         if blocks and sv.shape[0] > 0:
             index = PointIndex(block_subcloud(pts32, sv, d, box=block_box))
-        if on_gpu and blocks and sv.shape[0] == 0:   # (more ranks than simplices)
-            slots = None
-            face_dev = torch.empty((0, faces.n_faces), dtype=torch.float32, device=device)
+        # one running maximum per DISTINCT face of the complex (the simplices that share a triangle / an edge / a vertex
+        # share its word): also on a shard of the simplices - a rank then holds the (n_slots,) vector, +inf for the
+        # faces none of its simplices has, and the ranks are combined with MIN as before (round 5: a rank's finish
+        # used to search every shared face once per simplex)
+        slots = None
+        if (on_gpu and method == "cell" and not use_f64 and SHARED_FACE_SLOTS and FUSED_FACES and num_rand is None
+                and reduce_hook is None and faces.n_faces <= 32):
+            slots = shared_face_slots(stree, d, order_np if mine is None else order_np[mine.cpu().numpy()], v_idx_np,
+                                      device)
+        if on_gpu and sv.shape[0] == 0 and (blocks or slots is not None):   # (more ranks than simplices)
+            face_dev = (torch.full((slots[1],), float("inf"), dtype=torch.float32, device=device) if slots is not None
+                        else torch.empty((0, faces.n_faces), dtype=torch.float32, device=device))
         elif on_gpu:
             if method == "ball":
                 face_dev, _ = _sweep_dimension_hip(pts_pad, search, axis, dim, sv,
@@ -1549,13 +1569,8 @@ def flood_complex(
                                                    radii if mine is None else radii[mine], weights, faces,
                                                    reduce_hook)
             elif use_f64:
-                slots = None
                 face_dev, _ = _sweep_dimension_f64(index, pts64_sorted, sv, weights, faces, reduce_hook)
             elif method == "cell":
-                slots = None
-                if (SHARED_FACE_SLOTS and FUSED_FACES and num_rand is None and mine is None and reduce_hook is None
-                        and faces.n_faces <= 32):
-                    slots = shared_face_slots(stree, d, order_np, v_idx_np, device)
                 face_dev, _ = _sweep_dimension_cell(index, sv, weights, faces, reduce_hook, plan=plan,
                                                     face_slots=None if slots is None else slots[:2])
             else:
@@ -1567,7 +1582,13 @@ def flood_complex(
             if reduce_hook is not None:
                 reduce_hook(dist)
             face_dev = _face_max_cpu(dist, faces)
-        if mine is not None:
+        if mine is not None and slots is not None:
+            # every distinct face is on some rank, and whoever has it holds its exact value; the faces none of this
+            # rank's simplices has are +inf until the hook's MIN brings them in
+            face_dev = shard_slot_values(face_dev, slots[0])
+            if face_reduce_hook is not None:
+                face_reduce_hook(face_dev)
+        elif mine is not None:
             full = torch.full((num_simplices, faces.n_faces), float("inf"), dtype=face_dev.dtype, device=device)
             full[mine] = face_dev
             if face_reduce_hook is not None:

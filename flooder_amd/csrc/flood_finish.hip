@@ -55,7 +55,9 @@ constexpr int TOP_NODES = FLOODER_TOP_NODES;  // nodes of the two top tree level
 // uses a quarter of its wave's issue slots, and four such waves share a SIMD: a long search is long mostly because it
 // waits for its turn.  A wave whose tile has evaluated FLOODER_FINISH_PRIO_AFTER leaves raises its issue priority
 // (s_setprio): the few long searches run nearly unimpeded, the many short ones give up slots they were not the tail
-// of.  cfg 3: pass 1.87 -> 1.60 ms with the budget at 40 instead of 14 (fewer tiles need the team launch at all).
+// of.  cfg 3: pass 1.87 -> 1.67 ms (1.60 with the budget at 40 instead of 14 - but a rank's share of the simplices,
+// whose budget shrinks with its list, then hands its long searches over late AND still needs the team launch:
+// 1.54 instead of 1.21 ms on a half, so 14 it stays).
 struct HardLists {
   const unsigned long long* ent_in;   // item | sub << 32 | subs << 40 | one_round_only << 48
   const unsigned long long* mask_in;  // lanes of the focus samples of the abandoned round

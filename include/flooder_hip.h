@@ -420,7 +420,7 @@ int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, c
  *   size of flag_list - a counting sort by descending bound puts the long searches first in the last pass's queue
  *   (option "finish_order" 0 turns it off);
  *   hard_scratch / hard_cap: NULL / 0, or 4 * hard_cap uint64 of scratch - a tile that has evaluated more leaves
- *   than option "finish_budget" (40; a wave raises its issue priority after 32 leaves, so a long search runs ahead of
+ *   than option "finish_budget" (14; a wave raises its issue priority after 32 leaves, so a long search runs ahead of
  *   the three it shares its SIMD with) times the tiles per wave of the whole list is taken off its wave and put on a
  *   list of at most hard_cap entries; the next launch gives every such tile to a workgroup of 16 waves, each
  *   searching an interleaved share of the level-1 nodes of the box tree, the minima combined in LDS round by round

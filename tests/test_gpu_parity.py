@@ -805,7 +805,7 @@ def test_finish_hard_tiles_and_ordering_change_nothing(dev, cloud, monkeypatch):
             torch.cuda.synchronize()
             return out.cpu().numpy(), core.LAST_STATS.hard_entries
         finally:
-            for name, val in ((b"finish_order", 1), (b"finish_budget", 40), (b"finish_top", 0), (b"finish_budget_min", 64)):
+            for name, val in ((b"finish_order", 1), (b"finish_budget", 14), (b"finish_top", 0), (b"finish_budget_min", 64)):
                 lib.flooder_set_option(name, val)
 
     ref, hard = run(0, 0, 32768)
