@@ -407,6 +407,7 @@ def main():
         slots = slots_all
         if mine is not None and slots_all is not None:
             slots = (slots_all[0][mine].contiguous(), slots_all[1], slots_all[2])
+            slot_fill = core.shard_slot_fill(slots[0], slots[1])
 
     sub_rows = []   # (block-sharded: rows of the sub-cloud this rank indexes)
     cloud_box_full = core.cloud_box(shard_raw) if args.shard == "blocks" else None
@@ -453,7 +454,7 @@ def main():
                                                faces, hook, timer=timer)
         if mine is not None and slots is not None:  # simplex sharding: every rank ends with the values of all distinct faces
             with core._span(timer, "reduce"):
-                out = core.shard_slot_values(out, slots[0])
+                out = torch.maximum(out, slot_fill)   # (+inf in the words none of this rank's simplices touches)
                 face_hook(out)
         elif mine is not None:  # ... or with all (S_all, F) values
             full = torch.full((S_all, out.shape[1]), float("inf"), dtype=out.dtype, device=dev)

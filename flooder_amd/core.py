@@ -750,13 +750,14 @@ def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.nda
     return torch.as_tensor(slot, device=device), total, offsets
 
 
-def shard_slot_values(values: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
-    """The (n_slots,) per-face values of a rank that swept only the simplices of ``slot`` (its rows of the
-    ``shared_face_slots`` table): +inf in the words none of them touches, ready for ``all_reduce(MIN)``."""
-    covered = torch.zeros(values.shape[0], dtype=torch.bool, device=values.device)
+def shard_slot_fill(slot: torch.Tensor, n_slots: int) -> torch.Tensor:
+    """For a rank that sweeps only the simplices of ``slot`` (its rows of the ``shared_face_slots`` table): the
+    (n_slots,) vector with 0 in the words its simplices touch and +inf in the others - ``torch.maximum(values, fill)``
+    is what the rank contributes to ``all_reduce(MIN)`` (values are non-negative)."""
+    fill = torch.full((n_slots,), float("inf"), dtype=torch.float32, device=slot.device)
     if slot.numel():
-        covered[slot.reshape(-1).long()] = True
-    return torch.where(covered, values, torch.full_like(values, float("inf")))
+        fill[slot.reshape(-1).long()] = 0.0
+    return fill
 
 
 def simplex_order(index: "PointIndex", verts: torch.Tensor) -> torch.Tensor:
@@ -1585,7 +1586,7 @@ def flood_complex(
         if mine is not None and slots is not None:
             # every distinct face is on some rank, and whoever has it holds its exact value; the faces none of this
             # rank's simplices has are +inf until the hook's MIN brings them in
-            face_dev = shard_slot_values(face_dev, slots[0])
+            face_dev = torch.maximum(face_dev, shard_slot_fill(slots[0], slots[1]))
             if face_reduce_hook is not None:
                 face_reduce_hook(face_dev)
         elif mine is not None:
