@@ -4,9 +4,11 @@ The reference is single-device.  Two decompositions are provided.
 
 ``mode="simplices"`` (default): every rank holds the whole cloud (12 MB per million 3D points - nothing
 against 288 GB) and sweeps every W-th simplex of the sorted simplex list; the per-face filtration values
-(S x F floats, +inf where another rank is responsible) are combined with one ``all_reduce(MIN)``.  The
-culled sweeps do work proportional to the number of SAMPLES, not points, so this is the decomposition that
-scales; the exchanged buffer is a few hundred KB.
+(+inf where another rank is responsible) are combined with one ``all_reduce(MIN)``.  On the default cell-sweep path
+(2-D / 3-D, float32) the buffer is ONE word per distinct face of the complex - the simplices of a rank that share a
+triangle, an edge or a vertex share its running maximum, as on a single GPU (``core.shared_face_slots``,
+``core.shard_slot_fill``) -, otherwise the (S, F) matrix.  The culled sweeps do work proportional to the number of
+SAMPLES, not points, so this is the decomposition that scales; the exchanged buffer is about a hundred KB.
 
 Above 3 dimensions, where a dimension pass runs through the sorted-sample sweep (tiles of 64 spatially consecutive
 samples of ALL simplices, ``csrc/flood_sorted.hip``), ``mode="simplices"`` shards the TILES of the sorted order

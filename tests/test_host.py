@@ -452,3 +452,26 @@ def test_diagnostic_builds_still_compile():
     with ThreadPoolExecutor(max_workers=6) as pool:
         for job, rc, err in pool.map(compile_one, jobs):
             assert rc == 0, f"{job}: {err}"
+
+
+def test_shard_slot_fill_marks_the_faces_a_rank_does_not_have():
+    """Simplex shards of the cell sweep keep one word per distinct face of the complex (core.shared_face_slots):
+    what a rank contributes to all_reduce(MIN) is +inf in the words none of its simplices touches
+    (core.shard_slot_fill) - the minimum over the ranks is then the value of whichever rank has the face."""
+    import torch
+
+    from flooder_amd import core
+
+    slot_all = torch.tensor([[0, 1, 2], [1, 3, 4], [2, 4, 5], [6, 7, 8]], dtype=torch.int32)
+    values_true = torch.arange(1, 10, dtype=torch.float32)
+    combined = torch.full((9,), float("inf"))
+    for rank in range(2):
+        mine = slot_all[rank::2]
+        fill = core.shard_slot_fill(mine, 9)
+        touched = torch.zeros(9, dtype=torch.bool)
+        touched[mine.reshape(-1).long()] = True
+        assert torch.equal(torch.isinf(fill), ~touched) and torch.all(fill[touched] == 0)
+        part = torch.where(touched, values_true, torch.zeros(9))      # what the sweep leaves: zeros where untouched
+        combined = torch.minimum(combined, torch.maximum(part, fill))
+    assert torch.equal(combined, values_true)
+    assert torch.all(torch.isinf(core.shard_slot_fill(slot_all[:0], 9)))   # a rank without simplices
