@@ -74,13 +74,40 @@ struct CellCfg {
   static constexpr int NC = DIM == 2 ? 32 * 32 : 10 * 10 * 10;  // cells in the grid
 };
 
+// Inclusive prefix sum over the 64 lanes on the DPP network: seven adds (three neighbours of the own row first, then
+// shifts by 4 and 8 inside the row, then the totals of the rows before), no LDS - the __shfl_up form is six
+// ds_bpermute round trips with a select each, and the cell table's prefix runs it sixteen times per chunk.
+// (All 64 lanes must be active.  s_nop 1: the wait states of a DPP read after the write of its source.)
+#ifndef FLOODER_DPP_SCAN
+#define FLOODER_DPP_SCAN FLOODER_DPP_ASM
+#endif
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#if FLOODER_DPP_SCAN
+  int r;
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "=&v"(r)
+               : "v"(v));
+  return r;
+#else
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(v, o);
     if (lane >= o) v += t;
   }
   return v;
+#endif
 }
 
 // LDS hand-off between lanes of ONE wave: make earlier LDS writes/atomics of every lane visible to
@@ -1341,7 +1368,7 @@ s_pts.get4(j, x);
         const int cnt = ci < ncells ? s_cell[ci + 1] : 0;
         const int incl = wave_incl_scan(cnt, lane);
         if (ci < ncells) s_cell_w[ci + 1] = (uint16_t)(total + incl - cnt);
-        total += wave_uniform(__shfl(incl, 63));
+        total += __builtin_amdgcn_readlane(incl, 63);
       }
       wave_lds_sync();
       if (total > CAPW) { give_up = true; break; }

@@ -173,12 +173,34 @@ __device__ __forceinline__ int64_t queue_pop_local(int32_t* __restrict__ heads, 
 }
 
 // ---- 64-lane reductions on the DPP network (no LDS): result is wave-uniform.
+// FLOODER_DPP_ASM (default): every step is ONE instruction - the operation itself with the DPP lane pattern on its
+// first operand (v_min_f32_dpp x, x, x quad_perm:...; a lane whose source lane is masked off keeps x).  Written through
+// __builtin_amdgcn_update_dpp the compiler emits a copy, the permuting move, a canonicalising max (floats) or a
+// compare + select (unsigned) and the operation: 3 - 4 vector instructions per step, 18 - 24 per reduction, in
+// kernels whose searches are chains of such reductions.  (s_nop 1: the two wait states a DPP read needs after the
+// vector write of its source, which the compiler cannot place inside an asm block.)
+#ifndef FLOODER_DPP_ASM
+#define FLOODER_DPP_ASM 1
+#endif
+#define FLOODER_DPP_REDUCE(OP, x)                                                   \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+               "s_nop 1"                                                            \
+               : "+v"(x))
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
 }
 
 __device__ __forceinline__ float wave_min_f32(float x) {
+#if FLOODER_DPP_ASM
+  FLOODER_DPP_REDUCE("v_min_f32_dpp", x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+#endif
   x = __builtin_fminf(x, dpp_move<0xB1, 0xF>(x));   // quad_perm [1,0,3,2]
   x = __builtin_fminf(x, dpp_move<0x4E, 0xF>(x));   // quad_perm [2,3,0,1]
   x = __builtin_fminf(x, dpp_move<0x141, 0xF>(x));  // row_half_mirror
@@ -189,6 +211,10 @@ __device__ __forceinline__ float wave_min_f32(float x) {
 }
 
 __device__ __forceinline__ float wave_max_f32(float x) {
+#if FLOODER_DPP_ASM
+  FLOODER_DPP_REDUCE("v_max_f32_dpp", x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+#endif
   x = __builtin_fmaxf(x, dpp_move<0xB1, 0xF>(x));
   x = __builtin_fmaxf(x, dpp_move<0x4E, 0xF>(x));
   x = __builtin_fmaxf(x, dpp_move<0x141, 0xF>(x));
@@ -204,6 +230,10 @@ __device__ __forceinline__ uint32_t dpp_move_u32(uint32_t x) {
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+#if FLOODER_DPP_ASM
+  FLOODER_DPP_REDUCE("v_min_u32_dpp", x);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#endif
   uint32_t t;
   t = dpp_move_u32<0xB1, 0xF>(x); x = t < x ? t : x;
   t = dpp_move_u32<0x4E, 0xF>(x); x = t < x ? t : x;
@@ -215,6 +245,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#if FLOODER_DPP_ASM
+  FLOODER_DPP_REDUCE("v_max_u32_dpp", x);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#endif
   uint32_t t;
   t = dpp_move_u32<0xB1, 0xF>(x); x = t > x ? t : x;
   t = dpp_move_u32<0x4E, 0xF>(x); x = t > x ? t : x;
@@ -226,6 +260,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 }
 
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+#if FLOODER_DPP_ASM
+  FLOODER_DPP_REDUCE("v_or_b32_dpp", x);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#endif
   x |= dpp_move_u32<0xB1, 0xF>(x);
   x |= dpp_move_u32<0x4E, 0xF>(x);
   x |= dpp_move_u32<0x141, 0xF>(x);

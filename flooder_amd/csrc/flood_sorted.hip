@@ -68,8 +68,28 @@ constexpr int SUBSZ = 64 / NSUB;
 static_assert(NSUB == 1 || NSUB == 4 || NSUB == 8 || NSUB == 16, "sub-tiles of 64, 16, 8 or 4 lanes");
 
 // all-reduce inside runs of SUBSZ lanes (aligned): every lane ends up with its run's value
+#define FLOODER_SUB_STEP(OP, x, PATTERN) \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " PATTERN " row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x))
 template <bool MAX>
 __device__ __forceinline__ float sub_reduce(float x) {
+#if FLOODER_DPP_ASM
+  // (one instruction per step: flood_common.hpp, FLOODER_DPP_ASM)
+  if constexpr (SUBSZ == 64) {
+    return MAX ? wave_max_f32(x) : wave_min_f32(x);
+  } else if constexpr (MAX) {
+    FLOODER_SUB_STEP("v_max_f32_dpp", x, "quad_perm:[1,0,3,2]");
+    FLOODER_SUB_STEP("v_max_f32_dpp", x, "quad_perm:[2,3,0,1]");
+    if constexpr (SUBSZ >= 8) FLOODER_SUB_STEP("v_max_f32_dpp", x, "row_half_mirror");
+    if constexpr (SUBSZ >= 16) FLOODER_SUB_STEP("v_max_f32_dpp", x, "row_mirror");
+    return x;
+  } else {
+    FLOODER_SUB_STEP("v_min_f32_dpp", x, "quad_perm:[1,0,3,2]");
+    FLOODER_SUB_STEP("v_min_f32_dpp", x, "quad_perm:[2,3,0,1]");
+    if constexpr (SUBSZ >= 8) FLOODER_SUB_STEP("v_min_f32_dpp", x, "row_half_mirror");
+    if constexpr (SUBSZ >= 16) FLOODER_SUB_STEP("v_min_f32_dpp", x, "row_mirror");
+    return x;
+  }
+#endif
   auto op = [](float a, float b) { return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
   x = op(x, dpp_move<0xB1, 0xF>(x));                            // quad_perm [1,0,3,2]
   x = op(x, dpp_move<0x4E, 0xF>(x));                            // quad_perm [2,3,0,1]
