@@ -53,7 +53,18 @@ constexpr int BSLOTS = 64;    // arg-max slots per iteration of the brute-force 
 #ifndef FLOODER_FPS_KMAX
 #define FLOODER_FPS_KMAX 8
 #endif
-constexpr int KMAX = FLOODER_FPS_KMAX;  // landmarks per launch at most
+constexpr int KMAX = FLOODER_FPS_KMAX;  // landmarks per launch at most (buckets of 64 rows: clouds below 4 M points)
+#ifndef FLOODER_FPS_KMAX_LARGE
+#define FLOODER_FPS_KMAX_LARGE 32
+#endif
+// ... and with buckets of 256 rows (RPL = 4, larger clouds).  There two batches in three used to end at the cap of 8
+// while a launch takes 12 us whatever it selects (tools/fps_batches.py), so the cap is 32 and the loops over the
+// accepted landmarks run over the lanes that hold them instead of unrolled register arrays (a cap that costs no
+// registers): 16 M / 4 k 12.9 -> 11.3 ms.  The small clouds keep the unrolled form - the same loops are 5 - 10 %
+// slower there (1 M / 1 k 2.31 -> 2.38 ms, 2 M in 6-D 9.6 -> 10.5) and only a third of their batches reach the cap.
+constexpr int KMAX_LARGE = FLOODER_FPS_KMAX_LARGE;
+template <int RPL> struct BatchCap { static constexpr bool DYN = RPL > 1; static constexpr int CAP = DYN ? KMAX_LARGE : KMAX; };
+static_assert(KMAX >= 1 && KMAX <= 64 && KMAX_LARGE >= 1 && KMAX_LARGE <= 64, "one accepted candidate per lane");
 
 typedef unsigned long long u64;
 
@@ -398,7 +409,9 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
     u64 low = 0ull;        // bound of the skipped candidates and the points behind them
     int why = 4;           // (diagnostic, record word 3 of block 0) what closed the batch: 1 nothing above B, 2 a
                            // skipped candidate (or the points behind it) may come first, 3 hidden points, 4 KMAX / the end
-    const int nb_max = KMAX < n_lms - it ? KMAX : n_lms - it;
+    constexpr bool DYN = BatchCap<RPL>::DYN;
+    constexpr int CAP = BatchCap<RPL>::CAP;
+    const int nb_max = CAP < n_lms - it ? CAP : n_lms - it;
     for (int j = 0; j < 64; ++j) {   // (wave-uniform)
       if (nb >= nb_max) break;
       const u64 sm = __ballot(valid && rank == j);
@@ -441,36 +454,51 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
       if (valid && rank > j) mlow = __builtin_fminf(mlow, dist2<DIM>(ci, cj));
       hmax = __builtin_fmaxf(hmax, hbj);
     }
-    u64 ck[KMAX];
-    float cc[KMAX][DIM];   // coordinates of the accepted candidates
+    // (lane i holds the i-th accepted candidate.  DYN: the loops below run over the nb accepted ones with their
+    // coordinates read out of that lane; else they are unrolled over register copies)
+    float cc[DYN ? 1 : KMAX][DIM];   // coordinates of the accepted candidates
+    if constexpr (!DYN) {
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      ck[j] = readlane_u64(acc_key, j);
+      for (int j = 0; j < KMAX; ++j) {
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) cc[j][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_c[k]), j));
+        for (int k = 0; k < DIM; ++k) cc[j][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_c[k]), j));
+      }
     }
     s_why = why;
     if (nb > n_lms - it) nb = n_lms - it;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-#pragma unroll
-      for (int i = 0; i < KMAX; ++i)
-        if (i < nb) out_idx[it + i] = (int64_t)(0xffffffffu - (uint32_t)ck[i]);
-      ctr[L + 1] = it + nb;
-      report_progress(progress, progress_tag, L + 1, it + nb);
+    if (blockIdx.x == 0 && wv == 0) {
+      if (lane < nb) out_idx[it + lane] = (int64_t)(0xffffffffu - (uint32_t)acc_key);
+      if (lane == 0) {
+        ctr[L + 1] = it + nb;
+        report_progress(progress, progress_tag, L + 1, it + nb);
+      }
     }
     // ---- which of this wave's buckets can still change?  (lower bound of d2 from a landmark to the bucket's box)
     bool touched = false;
     const float mk1 = __uint_as_float((uint32_t)(k1 >> 32));
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      if (i < nb) {
+    if constexpr (DYN) {
+      for (int i = 0; i < nb; ++i) {   // (wave-uniform)
         float lb = 0.f;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-          const float g = __builtin_fmaxf(__builtin_fmaxf(blo[k] - cc[i][k], cc[i][k] - bhi[k]), 0.f);
+          const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_c[k]), i));
+          const float g = __builtin_fmaxf(__builtin_fmaxf(blo[k] - c, c - bhi[k]), 0.f);
           lb = __builtin_fmaf(g, g, lb);
         }
         touched = touched || lb < mk1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        if (i < nb) {
+          float lb = 0.f;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            const float g = __builtin_fmaxf(__builtin_fmaxf(blo[k] - cc[i][k], cc[i][k] - bhi[k]), 0.f);
+            lb = __builtin_fmaf(g, g, lb);
+          }
+          touched = touched || lb < mk1;
+        }
       }
     }
     u64 tm = __ballot(touched && has);
@@ -510,18 +538,37 @@ __global__ __launch_bounds__(256) void fps2_batch_step_kernel(
           float bx[DIM];
 #pragma unroll
           for (int k = 0; k < DIM; ++k) bx[k] = 0.f;
+          float mnew[RPL];
 #pragma unroll
-          for (int u = 0; u < RPL; ++u) {
-            const int64_t j = tb * (RPL * 64) + u * 64 + lane;
-            if (j < n) {
-              float m = m0[g][u];
+          for (int u = 0; u < RPL; ++u) mnew[u] = m0[g][u];
+          if constexpr (DYN) {
+            for (int i = 0; i < nb; ++i) {   // (wave-uniform; rows past the end hold a copy of the last row: harmless)
+              float c[DIM];
+#pragma unroll
+              for (int k = 0; k < DIM; ++k) c[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_c[k]), i));
+#pragma unroll
+              for (int u = 0; u < RPL; ++u) {
+                const float d2 = dist2<DIM>(x[g][u], c);
+                mnew[u] = d2 < mnew[u] ? d2 : mnew[u];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
 #pragma unroll
               for (int i = 0; i < KMAX; ++i) {
                 if (i < nb) {
                   const float d2 = dist2<DIM>(x[g][u], cc[i]);
-                  m = d2 < m ? d2 : m;
+                  mnew[u] = d2 < mnew[u] ? d2 : mnew[u];
                 }
               }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < RPL; ++u) {
+            const int64_t j = tb * (RPL * 64) + u * 64 + lane;
+            if (j < n) {
+              const float m = mnew[u];
               if (m < m0[g][u]) minsq[j] = m;
               m0[g][u] = m;
               const u64 k = make_key(m, o[g][u]);
@@ -771,7 +818,7 @@ int run_batched(const float* pts, int64_t n, int ld, const float* pts_sorted, co
     prev_round = round;
     const double est = (double)(n_lms - done) / rate;
     round = est > 24.0 ? (int)(est * 0.8) : (int)(est * 1.25) + 1;
-    const int least = (n_lms - done + KMAX - 1) / KMAX;
+    const int least = (n_lms - done + BatchCap<RPL>::CAP - 1) / BatchCap<RPL>::CAP;
     if (round < least) round = least;
   }
   if (launches_out) *launches_out = launches;

@@ -5,7 +5,8 @@ usage: python tools/stress_fps.py [cases]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
-from flooder_amd import core
+from flooder_amd import core, _native
+lib = _native.load()
 
 dev = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -37,10 +38,17 @@ for case in range(n_cases):
     start = int(rng.integers(0, n))
     index = core.PointIndex(pts)
     core.FPS_BATCHED = True
-    got = core.fps_indices(pts, k, start, method="bucket", index=index).cpu()
+    # every other case through the form for large clouds (buckets of 256 rows, cap of 32 landmarks per launch, loops over
+    # the lanes that hold the accepted candidates), which clouds of this size would not take by themselves
+    rpl = 4 if case % 2 else 0
+    assert lib.flooder_set_option(b"fps_rpl", rpl) == 0
+    try:
+        got = core.fps_indices(pts, k, start, method="bucket", index=index).cpu()
+    finally:
+        lib.flooder_set_option(b"fps_rpl", 0)
     ref = core.fps_indices(pts, k, start, method="brute").cpu()
     same = bool(torch.equal(got, ref))
     bad += 0 if same else 1
     first = int((got != ref).nonzero()[0]) if not same else -1
-    print(f"case {case:3d} {kind:9s} dim={dim} n={n:7d} landmarks={k:6d} start={start:7d} batched==brute={same}" + ("" if same else f"  FIRST DIFFERENCE at {first}"), flush=True)
+    print(f"case {case:3d} {kind:9s} dim={dim} n={n:7d} landmarks={k:6d} start={start:7d} rpl={rpl or 1} batched==brute={same}" + ("" if same else f"  FIRST DIFFERENCE at {first}"), flush=True)
 print(f"{n_cases} cases, {bad} failed, {time.time() - t0:.0f} s")
