@@ -475,3 +475,45 @@ def test_shard_slot_fill_marks_the_faces_a_rank_does_not_have():
         combined = torch.minimum(combined, torch.maximum(part, fill))
     assert torch.equal(combined, values_true)
     assert torch.all(torch.isinf(core.shard_slot_fill(slot_all[:0], 9)))   # a rank without simplices
+
+
+def test_built_kernels_hold_no_vector_exec_writes_before_dpp_asm():
+    """csrc/flood_common.hpp writes the wave reductions as DPP instructions inside asm blocks and places the wait states
+    a DPP read needs itself.  One hazard it does not cover: five wait states after a VECTOR instruction that writes
+    EXEC (v_cmpx).  hipcc's wave64 control flow uses scalar EXEC writes only; if a compiler ever emits v_cmpx into
+    these kernels this test says so.  Also: the asm blocks are really there (v_min_f32_dpp)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from flooder_amd import build
+
+    lib = build.HIP_LIB if hasattr(build, "HIP_LIB") else os.path.join(ROOT, "flooder_amd", "libflooder_hip.so")
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(bundler) and os.path.exists(objdump)):
+        pytest.skip("no built library or no LLVM tools here")
+    with tempfile.TemporaryDirectory() as tmp:
+        # the shared object embeds the gfx950 code object in its .hip_fatbin section
+        fat = os.path.join(tmp, "fat.bin")
+        objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+        if not os.path.exists(objcopy):
+            pytest.skip("no llvm-objcopy")
+        subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(tmp, "unused.so")], check=True)
+        # (one offload bundle per translation unit, back to back)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        assert len(starts) >= 10, "one bundle per .hip source expected"
+        asm = ""
+        for n, a in enumerate(starts):
+            part = os.path.join(tmp, f"b{n}.bin")
+            open(part, "wb").write(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            co = os.path.join(tmp, f"dev{n}.co")
+            p = subprocess.run([bundler, "--unbundle", "--type=o", f"--input={part}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
+            if p.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                pytest.skip("could not unbundle the device code: " + p.stderr[-200:])
+            asm += subprocess.run([objdump, "-d", co], capture_output=True, text=True, check=True).stdout
+    assert "v_min_f32_dpp" in asm and "v_max_u32_dpp" in asm and "v_add_u32_dpp" in asm
+    assert "v_cmpx" not in asm
