@@ -17,7 +17,17 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libflooder_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "libflooder_host.so")
-PY_LIB = os.path.join(PKG_DIR, "libflooder_py.so")   # CPython-API helpers (loaded with ctypes.PyDLL)
+# CPython-API helpers (loaded with ctypes.PyDLL): built against ONE interpreter's headers with non-limited-API macros,
+# so the file name carries that interpreter's ABI tag - another CPython sharing the checkout builds its own
+import sysconfig as _sysconfig
+
+PY_LIB = os.path.join(PKG_DIR, f"libflooder_py.{_sysconfig.get_config_var('SOABI') or 'abi-unknown'}.so")
+
+
+def _tmp(path: str) -> str:
+    """Per-process temporary name next to ``path``: ranks of one fresh multi-rank start all build, and os.replace
+    must never publish another process's half-written file."""
+    return f"{path}.{os.getpid()}.tmp"
 
 HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
 HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp", "delaunay2d.cpp"]
@@ -66,20 +76,20 @@ def _build_hip_to(HIP_LIB: str, force: bool, verbose: bool) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(obj_dir, f"{os.path.basename(src)}.{tag}.o")
         if force or not _newer(obj, [src] + hdrs):
-            cmd = [hipcc, *flags, "-c", src, "-o", obj + ".tmp"]
+            cmd = [hipcc, *flags, "-c", src, "-o", _tmp(obj)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
-            os.replace(obj + ".tmp", obj)
+            os.replace(_tmp(obj), obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", HIP_LIB + ".tmp"] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", _tmp(HIP_LIB)] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(HIP_LIB + ".tmp", HIP_LIB)
+    os.replace(_tmp(HIP_LIB), HIP_LIB)
     return HIP_LIB
 
 
@@ -92,11 +102,11 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("g++ not found")
-    cmd = [cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", HOST_LIB + ".tmp"] + srcs
+    cmd = [cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", _tmp(HOST_LIB)] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(HOST_LIB + ".tmp", HOST_LIB)
+    os.replace(_tmp(HOST_LIB), HOST_LIB)
     return HOST_LIB
 
 
@@ -112,11 +122,11 @@ def build_py(force: bool = False, verbose: bool = False) -> str:
     inc = sysconfig.get_paths()["include"]
     if cc is None or not os.path.exists(os.path.join(inc, "Python.h")):
         return ""   # (no compiler or no headers: simplex_tree.to_dict falls back to the Python loop)
-    cmd = [cc, "-O2", "-shared", "-fPIC", f"-I{inc}", "-o", PY_LIB + ".tmp", src]
+    cmd = [cc, "-O2", "-shared", "-fPIC", f"-I{inc}", "-o", _tmp(PY_LIB), src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(PY_LIB + ".tmp", PY_LIB)
+    os.replace(_tmp(PY_LIB), PY_LIB)
     return PY_LIB
 
 

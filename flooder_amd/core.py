@@ -30,6 +30,7 @@ The (S, R, dim) tensor of sample points the reference materialises (``core.py:18
 from __future__ import annotations
 
 import itertools
+import os
 import weakref
 import warnings
 from numbers import Integral
@@ -110,7 +111,8 @@ def generate_uniform_weights(num_rand: int, dim: int, device, dtype) -> torch.Te
 
 # ------------------------------------------------------------------------------ landmarks
 def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int] = None,
-                       start_idx: Union[int, None] = None, *, index: Optional["PointIndex"] = None) -> torch.Tensor:
+                       start_idx: Union[int, None] = None, *, index: Optional["PointIndex"] = None,
+                       return_index: bool = False):
     """Farthest-point-sampling landmarks (interface of ``core.py:291-343``).
 
     The reference delegates to ``fpsample.bucket_fps_kdline_sampling`` on the CPU (a kd-tree
@@ -120,6 +122,10 @@ def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int]
     ``PointIndex`` of ``points`` to reuse) or, for small clouds and dim > 3, one distance-update + arg-max
     sweep of the cloud per landmark (``flooder_fps_f32``) - and in numpy for CPU tensors.
     Returns ``points[index_set]`` in selection order, same device and dtype as ``points``.
+    ``return_index=True`` (keyword-only extension): returns ``(landmarks, index)`` where ``index`` is the
+    ``PointIndex`` the selection used (built here if none was passed; ``None`` for CPU tensors and the brute-force
+    selection) - the handle to give to ``flood_complex(points, landmarks, index=index)`` so that the curve-sorted
+    copy of the cloud is built once for both steps.
     """
     if n_lms <= 0:
         raise RuntimeError(f"Number of landmarks ({n_lms}) must be positive")
@@ -129,7 +135,10 @@ def generate_landmarks(points: torch.Tensor, n_lms: int, fps_h: Union[None, int]
         start_idx = int(torch.randint(n_pts, (1,)).item())
     if not (0 <= start_idx < n_pts):
         raise RuntimeError(f"start_idx ({start_idx}) out of range for {n_pts} points")
-    index_set = fps_indices(points, n_lms, start_idx, index=index)
+    used: List = []
+    index_set = fps_indices(points, n_lms, start_idx, index=index, _used_index=used)
+    if return_index:
+        return points[index_set], (used[0] if used else None)
     return points[index_set]
 
 
@@ -143,7 +152,7 @@ LAST_FPS_DIAG: Dict[str, object] = {}
 
 
 def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Optional[str] = None,
-                index: Optional["PointIndex"] = None) -> torch.Tensor:
+                index: Optional["PointIndex"] = None, _used_index: Optional[List] = None) -> torch.Tensor:
     """Indices of the exact FPS order starting at ``start_idx`` (int64, on ``points.device``).
 
     ROCm tensors: ``method="bucket"`` (default for large clouds) runs ``flooder_fps_batched_f32`` - exact FPS over
@@ -177,7 +186,10 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
                 index = _recall_index(points)
                 if index is None:
                     index = PointIndex(pts)
+                    index.source = (points.data_ptr(), _tensor_version(points))
                     _remember_index(points, index)
+            if _used_index is not None:
+                _used_index.append(index)
             nb = int(lib.flooder_fps_bucket_count(n))
             dp = index.dp
             minsq = torch.empty(n, dtype=torch.float32, device=pts.device)
@@ -202,7 +214,7 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
                                      words=12 + max(dp, 4))
             return out_idx
         if method == "bucket":
-            return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, points)
+            return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, points, _used_index)
         work_min = torch.empty(4 * n, dtype=torch.float32, device=pts.device)
         work_best = torch.zeros(64 * n_lms, dtype=torch.int64, device=pts.device)
         with torch.cuda.device(pts.device):
@@ -223,14 +235,17 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
     return torch.as_tensor(idx, device=points.device)
 
 
-def _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, source=None):
+def _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, source=None, used=None):
     """``flooder_fps_indexed_f32``: bucketed exact FPS, one launch per landmark (dim <= 3)."""
     if index is None:
         index = _recall_index(source) if source is not None else None
         if index is None:
             index = PointIndex(pts)
             if source is not None:
+                index.source = (source.data_ptr(), _tensor_version(source))
                 _remember_index(source, index)
+    if used is not None:
+        used.append(index)
     nb = int(lib.flooder_fps_bucket_count(n))
     rows = torch.empty(4 * index.pts.shape[0], dtype=torch.float32, device=pts.device)
     box = torch.empty(8 * nb, dtype=torch.float32, device=pts.device)
@@ -525,20 +540,30 @@ def _tensor_version(t: torch.Tensor):
         return None
 
 
-# The last PointIndex built from a caller's tensor (generate_landmarks / flood_complex), remembered by the IDENTITY of
-# that tensor (a weak reference: a freed tensor's address can be handed to another one) and its version counter:
-#     lms = generate_landmarks(points, 1000); flood_complex(points, lms)        # the second call reuses the index
-# - and so does every rank of flood_complex_sharded, where the replicated index build is the part that does not divide
-# (16 M points: 0.97 ms of a 3 ms rank step).  One entry; INDEX_CACHE = False switches it off.
-INDEX_CACHE = True
+# Cross-call reuse of a PointIndex.  OFF by default (the reference keeps no state between calls): the explicit ways
+# are ``lms, idx = generate_landmarks(points, n, return_index=True); flood_complex(points, lms, index=idx)`` and
+# ``flood_complex(points, <int>)``, where the library builds the index once for both steps itself.  With
+# ``INDEX_CACHE = True`` (or FLOODER_INDEX_CACHE=1 in the environment) the last index built from a caller's tensor is
+# remembered by the IDENTITY of that tensor and its version counter, so that plain
+#     lms = generate_landmarks(points, 1000); flood_complex(points, lms)
+# builds it once.  CAVEAT of that mode, why it is opt-in: torch's ``_version`` does not move when the buffer is
+# written through ``.data``, by a raw-pointer kernel or through a DLPack / cupy alias - such a write is not seen and
+# the stale sorted copy would be swept.  The entry holds the index strongly but dies WITH the tensor (weakref
+# callback): a freed cloud's 16 B / point copy does not stay in HBM.
+INDEX_CACHE = os.environ.get("FLOODER_INDEX_CACHE", "0") not in ("", "0", "false", "False")
 _LAST_INDEX: List = [None, None, None]   # weakref to the source tensor, its version, the PointIndex
+
+
+def _index_owner_died(ref) -> None:
+    if _LAST_INDEX[0] is ref:
+        _LAST_INDEX[:] = [None, None, None]
 
 
 def _remember_index(points: torch.Tensor, index: "PointIndex") -> None:
     ver = _tensor_version(points)
     if INDEX_CACHE and ver is not None:
         try:
-            _LAST_INDEX[:] = [weakref.ref(points), ver, index]
+            _LAST_INDEX[:] = [weakref.ref(points, _index_owner_died), ver, index]
         except TypeError:
             _LAST_INDEX[:] = [None, None, None]
 
@@ -552,8 +577,25 @@ def _recall_index(points: torch.Tensor) -> Optional["PointIndex"]:
     return None
 
 
+CHECK_RANK_CONSISTENCY = True   # sharded runs: one 6-word MIN before the first face collective of a dimension pass
+
+
+def _assert_ranks_agree(min_hook: Callable[[torch.Tensor], None], device, *counts: int) -> None:
+    """Every rank passes the same ``counts``?  ``min_hook`` is the caller's in-place elementwise MIN over the ranks:
+    MIN of (c, -c) gives (min c, -max c), equal in magnitude only if all ranks hold the same c."""
+    c = torch.tensor([x for v in counts for x in (int(v), -int(v))], dtype=torch.int64, device=device)
+    min_hook(c)
+    got = c.cpu().tolist()
+    if any(got[i] != -got[i + 1] for i in range(0, len(got), 2)):
+        raise RuntimeError("flood_complex: the ranks of this sharded run do not hold the same complex "
+                           f"(simplices / faces per simplex / face slots: min {got[0::2]}, max {[-x for x in got[1::2]]}) - "
+                           "different landmarks, or a different Delaunay code path on some rank (native library "
+                           "missing on one of them?)")
+
+
 def forget_index() -> None:
-    """Drop the remembered PointIndex (it keeps a padded, sorted copy of the last cloud alive: 16 B per 3-D point)."""
+    """Drop the remembered PointIndex (``INDEX_CACHE`` mode; it keeps a padded, sorted copy of the last cloud alive
+    for as long as that tensor lives: 16 B per 3-D point)."""
     _LAST_INDEX[:] = [None, None, None]
 
 
@@ -1332,6 +1374,7 @@ def flood_complex(
     face_reduce_hook: Optional[Callable[[torch.Tensor], None]] = None,
     index: Optional["PointIndex"] = None,
     shard_blocks: bool = False,
+    landmarks_in_cloud: Optional[bool] = None,
 ):
     """Flood complex of ``points`` over the Delaunay triangulation of ``landmarks``.
 
@@ -1364,7 +1407,9 @@ def flood_complex(
     simplices has): every ``world``-th simplex of the queue, or - ``shard_blocks=True``, float32 ROCm tensors, methods
     ``"cell"``/``"bvh"``, landmarks that are POINTS OF THE CLOUD (the caller vouches; true for every
     ``generate_landmarks`` result) - a contiguous block of the queue, swept against an index of the sub-cloud inside
-    the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too.  A dimension
+    the block's bounding balls only (``block_subcloud``): the index build shrinks with the share, too
+    (``landmarks_in_cloud=True``: the caller vouches that the landmarks are rows of ``points`` and the O(n log n)
+    membership check with its host synchronisation is skipped; ``None``: checked; ``False``: refused).  A dimension
     pass that runs the sorted-sample sweep (above 3D; ``shards_sorted_tiles``) shards the TILES of the sorted sample
     order instead: this rank's (S, F) values are the maxima over ITS samples (0 where it has none), and
     ``face_reduce_hook`` - an in-place elementwise MIN over the ranks, whatever it is given - receives the NEGATED
@@ -1446,7 +1491,10 @@ def flood_complex(
     if blocks:
         pts32 = points.to(torch.float32).contiguous()
         block_box = shared_index.box if shared_index is not None else cloud_box(pts32)
-        if not _rows_are_subset(landmarks.to(torch.float32), pts32):
+        # (the membership test hashes and sorts the whole cloud and synchronises with the host: a caller whose
+        # landmarks come from generate_landmarks vouches with landmarks_in_cloud=True and skips it)
+        if landmarks_in_cloud is False or (landmarks_in_cloud is None
+                                           and not _rows_are_subset(landmarks.to(torch.float32), pts32)):
             raise ValueError("shard_blocks / mode='blocks' needs landmarks that are rows of `points` (every "
                              "generate_landmarks result is): a block's sub-cloud holds only the rows inside its "
                              "simplices' bounding balls, which bound the nearest neighbours of the samples only then "
@@ -1583,6 +1631,11 @@ def flood_complex(
             if reduce_hook is not None:
                 reduce_hook(dist)
             face_dev = _face_max_cpu(dist, faces)
+        if simplex_shard is not None and face_reduce_hook is not None and simplex_shard[1] > 1 and CHECK_RANK_CONSISTENCY:
+            # the collective's buffer must have the same shape on every rank: the complexes agree (same Delaunay code
+            # path, same landmarks) or we stop here instead of hanging in a mismatched all-reduce
+            _assert_ranks_agree(face_reduce_hook, device, num_simplices, faces.n_faces,
+                                -1 if slots is None else int(slots[1]))
         if mine is not None and slots is not None:
             # every distinct face is on some rank, and whoever has it holds its exact value; the faces none of this
             # rank's simplices has are +inf until the hook's MIN brings them in

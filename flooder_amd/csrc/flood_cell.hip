@@ -77,14 +77,16 @@ struct CellCfg {
 // Inclusive prefix sum over the 64 lanes on the DPP network: seven adds (three neighbours of the own row first, then
 // shifts by 4 and 8 inside the row, then the totals of the rows before), no LDS - the __shfl_up form is six
 // ds_bpermute round trips with a select each, and the cell table's prefix runs it sixteen times per chunk.
-// (All 64 lanes must be active.  s_nop 1: the wait states of a DPP read after the write of its source.)
+// (All 64 lanes must be active.  s_nop 1: the wait states of a DPP read after the write of its source; the block opens
+// with s_nop 4 - the five a DPP read needs after a VALU write of EXEC, which the compiler's hazard recognizer cannot
+// place inside an asm block.)
 #ifndef FLOODER_DPP_SCAN
 #define FLOODER_DPP_SCAN FLOODER_DPP_ASM
 #endif
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #if FLOODER_DPP_SCAN
   int r;
-  asm volatile("s_nop 1\n\t"
+  asm volatile("s_nop 4\n\t"
                "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"

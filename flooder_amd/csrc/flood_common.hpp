@@ -178,12 +178,14 @@ __device__ __forceinline__ int64_t queue_pop_local(int32_t* __restrict__ heads, 
 // __builtin_amdgcn_update_dpp the compiler emits a copy, the permuting move, a canonicalising max (floats) or a
 // compare + select (unsigned) and the operation: 3 - 4 vector instructions per step, 18 - 24 per reduction, in
 // kernels whose searches are chains of such reductions.  (s_nop 1: the two wait states a DPP read needs after the
-// vector write of its source, which the compiler cannot place inside an asm block.)
+// vector write of its source, which the compiler cannot place inside an asm block; the block OPENS with s_nop 4: five
+// wait states cover a VALU write of EXEC directly in front of it as well - hipcc's wave64 control flow writes EXEC with
+// scalar instructions today, tests/test_host.py greps the ISA for v_cmpx, but nothing here depends on that any more.)
 #ifndef FLOODER_DPP_ASM
 #define FLOODER_DPP_ASM 1
 #endif
 #define FLOODER_DPP_REDUCE(OP, x)                                                   \
-  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+  asm volatile("s_nop 4\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
                "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
                "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
                "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \

@@ -69,7 +69,7 @@ static_assert(NSUB == 1 || NSUB == 4 || NSUB == 8 || NSUB == 16, "sub-tiles of 6
 
 // all-reduce inside runs of SUBSZ lanes (aligned): every lane ends up with its run's value
 #define FLOODER_SUB_STEP(OP, x, PATTERN) \
-  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " PATTERN " row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x))
+  asm volatile("s_nop 4\n\t" OP " %0, %0, %0 " PATTERN " row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(x))
 template <bool MAX>
 __device__ __forceinline__ float sub_reduce(float x) {
 #if FLOODER_DPP_ASM

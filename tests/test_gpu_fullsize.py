@@ -86,12 +86,12 @@ def test_cfg5_full_size_16m_cheese(cheese16m, dev):
     assert all(st.filtration([i]) == 0.0 for i in range(0, 4000, 97))
     P, L = pts.numpy(), lms.cpu().numpy()
     if (os.cpu_count() or 1) >= 32:
-        n = assert_tree_matches_kdtree(st, P, L, 30, 3, "cfg5", lower=True)
+        n = assert_tree_matches_kdtree(st, P, L, 30, 3, "cfg5", lower=True, strict=True)
         assert n == len(tets) + len(st.simplices_of_dimension(2)) + len(st.simplices_of_dimension(1))
     else:   # (125 M queries over 16 M points: on a few cores the 200 deepest + 2000 random tetrahedra)
         rng = np.random.default_rng(1)
         pick = np.unique(np.concatenate([np.argsort(-vals)[:200], rng.choice(len(tets), size=2000, replace=False)]))
-        assert assert_tree_matches_kdtree(st, P, L, 30, 3, "cfg5 tetrahedra", pick_top=pick, lower=False) >= 2000
+        assert assert_tree_matches_kdtree(st, P, L, 30, 3, "cfg5 tetrahedra", pick_top=pick, lower=False, strict=True) >= 2000
     big = np.argsort(-vals)[:200]                     # the 200 tetrahedra reaching deepest into the voids
     assert float(vals[big].min()) > 5 * float(np.median(vals))
     for d in (1, 2, 3):  # monotone: faces never above cofaces (tests/test_flooder.py:207-211)
@@ -122,11 +122,11 @@ def test_cfg4_full_size_2m_6d(dev):
     tree = cKDTree(P)
     if (os.cpu_count() or 1) >= 32:
         ref = kdtree_face_values(tree, L, tris, 8, 2)          # (n, 36) samples each, 6-D kd-tree, all host cores
-        assert_close_filtration(vals, ref, P, "cfg4: every triangle")
+        assert_close_filtration(vals, ref, P, "cfg4: every triangle", strict=True)
     else:   # (38 M six-dimensional queries take minutes on a few cores: the 100 largest + 2000 random triangles there)
         rng = np.random.default_rng(2)
         pick = np.unique(np.concatenate([np.argsort(-vals)[:100], rng.choice(len(tris), size=2000, replace=False)]))
-        assert_close_filtration(vals[pick], kdtree_face_values(tree, L, tris[pick], 8, 2), P, "cfg4 triangle sample")
+        assert_close_filtration(vals[pick], kdtree_face_values(tree, L, tris[pick], 8, 2), P, "cfg4 triangle sample", strict=True)
     e = st.simplices_of_dimension(1)
     ev = st.filtrations_of_dimension(1)
     assert np.isfinite(ev).all() and (st.filtrations_of_dimension(0) == 0.0).all()
@@ -134,7 +134,7 @@ def test_cfg4_full_size_2m_6d(dev):
         loc = st._locate(1, np.delete(tris, j, axis=1))
         assert (loc >= 0).all() and (ev[loc] <= vals).all()
     # edges: their own samples (the 8 lattice points of the edge) against the kd-tree
-    assert_close_filtration(ev, kdtree_face_values(tree, L, e, 8, 1), P, "cfg4: every edge")
+    assert_close_filtration(ev, kdtree_face_values(tree, L, e, 8, 1), P, "cfg4: every edge", strict=True)
 
 
 @pytest.mark.parametrize("case", ["gauss1m", "torus300k", "eight2d", "line1d", "dups"])

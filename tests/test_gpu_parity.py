@@ -606,7 +606,7 @@ def test_full_size_properties_1m_gaussian(dev):
         for j in range(d + 1):
             idx = st._locate(d - 1, np.delete(rows, j, axis=1))
             assert (st.filtrations_of_dimension(d - 1)[idx] <= own).all()
-    n = assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, "cfg2 1M gaussian")
+    n = assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, "cfg2 1M gaussian", strict=True)
     assert n == sum(len(st.simplices_of_dimension(d)) for d in (1, 2, 3)) and n > 25_000
 
 
@@ -626,7 +626,7 @@ def test_full_size_far_field_clouds_match_oracle_sample(dev, cloud):
     st = fa.flood_complex(tp, lms, return_simplex_tree=True)
     vals = st.filtrations_of_dimension(3)
     assert np.isfinite(vals).all()
-    assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, f"{cloud} full check")
+    assert_tree_matches_kdtree(st, pts.numpy(), lms.cpu().numpy(), 30, 3, f"{cloud} full check", strict=True)
     big = np.argsort(-vals)[:15]                      # the farthest-reaching tetrahedra: tube interior / voids
     assert float(vals[big].min()) > 5 * float(np.median(vals))    # the complex really contains far-field tetrahedra
 
@@ -899,9 +899,20 @@ def test_the_index_of_generate_landmarks_is_reused_by_flood_complex(dev, monkeyp
 
     monkeypatch.setattr(core.PointIndex, "__init__", spy)
     core.forget_index()
+    # default: no state between calls (the reference keeps none) - the explicit handle is the way to share the index
+    assert core.INDEX_CACHE is False
+    lms, idx = fa.generate_landmarks(pts, 150, start_idx=0, return_index=True)
+    assert len(built) == 1 and isinstance(idx, core.PointIndex)
+    a0 = fa.flood_complex(pts, lms, points_per_edge=8, index=idx)
+    assert len(built) == 1
+    assert fa.flood_complex(pts, lms, points_per_edge=8) == a0 and len(built) == 2   # plain call: its own index
+    assert fa.flood_complex(pts, 150, points_per_edge=8) == a0 and len(built) == 3   # integer landmarks: ONE index for both steps
+    built.clear()
+    monkeypatch.setattr(core, "INDEX_CACHE", True)                     # opt-in: remembered by tensor identity + version
     lms = fa.generate_landmarks(pts, 150, start_idx=0)
     assert len(built) == 1
     a = fa.flood_complex(pts, lms, points_per_edge=8)
+    assert a == a0
     assert len(built) == 1, "flood_complex rebuilt the index generate_landmarks had just built"
     b = fa.flood_complex(pts.clone(), lms, points_per_edge=8)          # another tensor: its own index
     assert len(built) == 2 and a == b
@@ -921,6 +932,13 @@ def test_the_index_of_generate_landmarks_is_reused_by_flood_complex(dev, monkeyp
         n0 = len(built)
         fa.flood_complex(pin, lin, points_per_edge=6)
         assert len(built) == n0 + 1
+    import gc
+    tmp = torch.randn(100_000, 3, generator=g).to(dev)                  # the entry dies with its tensor
+    fa.generate_landmarks(tmp, 80, start_idx=0)
+    assert core._LAST_INDEX[2] is not None
+    del tmp
+    gc.collect()
+    assert core._LAST_INDEX[2] is None
     monkeypatch.setattr(core, "INDEX_CACHE", False)
     core.forget_index()
     fa.flood_complex(pts, lms, points_per_edge=8)
