@@ -30,8 +30,8 @@ def _tmp(path: str) -> str:
     return f"{path}.{os.getpid()}.tmp"
 
 HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
-HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp", "delaunay2d.cpp"]
-HOST_HEADERS = ["exact_int.hpp"]
+HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp", "delaunay2d.cpp", "delaunay_nd.cpp", "cell_faces.cpp"]
+HOST_HEADERS = ["exact_int.hpp", "host_parallel.hpp"]
 
 
 def _newer(target: str, sources) -> bool:
@@ -102,7 +102,9 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("g++ not found")
-    cmd = [cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", _tmp(HOST_LIB)] + srcs
+    # (no -march: the library travels to other hosts; delaunay_nd.cpp carries AVX2 / AVX-512 clones of its one hot loop
+    # and picks at run time)
+    cmd = [cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _tmp(HOST_LIB)] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

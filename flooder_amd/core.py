@@ -280,7 +280,7 @@ def _build_complex(landmarks: torch.Tensor, max_dimension: int):
         simplices = [np.array(b, dtype=np.int64).reshape(-1, d + 1) for d, b in enumerate(buckets)]
         return stree, simplices
     # Qhull cells; the face tables up to max_dimension now, the higher ones when somebody asks for them
-    stree = SimplexTree.from_cells(delaunay_cells(lm), lm.shape[0], eager=max_dimension)
+    stree = SimplexTree.from_cells(delaunay_cells(lm), lm.shape[0], eager=max_dimension, trusted=True)
     simplices = [stree.simplices_of_dimension(d) for d in range(max_dimension + 1)]
     return stree, simplices
 
@@ -1631,7 +1631,8 @@ def flood_complex(
             if reduce_hook is not None:
                 reduce_hook(dist)
             face_dev = _face_max_cpu(dist, faces)
-        if simplex_shard is not None and face_reduce_hook is not None and simplex_shard[1] > 1 and CHECK_RANK_CONSISTENCY:
+        if (simplex_shard is not None and face_reduce_hook is not None and simplex_shard[1] > 1 and CHECK_RANK_CONSISTENCY
+                and getattr(face_reduce_hook, "checks_ranks", False)):   # (hooks of distributed.min_reduce_hook: real collectives)
             # the collective's buffer must have the same shape on every rank: the complexes agree (same Delaunay code
             # path, same landmarks) or we stop here instead of hanging in a mismatched all-reduce
             _assert_ranks_agree(face_reduce_hook, device, num_simplices, faces.n_faces,

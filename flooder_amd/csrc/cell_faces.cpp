@@ -1,0 +1,175 @@
+// cell_faces.cpp - the k-vertex faces of the top cells of a complex as a sorted table of distinct rows, on all host
+// cores.
+//
+// What the reference collects in Python from `stree.get_simplices()` (flooder/core.py:135-138: every simplex of the
+// Delaunay complex bucketed by dimension) and what this build's SimplexTree enumerated with numpy: every cell's
+// C(width, k) faces packed into 64-bit keys and `np.unique`d - one thread sorting 51 million keys for the triangles
+// of BASELINE cfg 4 (1.47 M 6-simplices x 35), 5.6 s around a 34 ms sweep.  Here the keys go through a lock-free
+// hash set (the distinct faces are few: 1.24 M), the distinct keys are bucketed, sorted and unpacked in parallel.
+//
+// C ABI (include/flooder_host.h): flooder_cell_faces.
+#include "exact_int.hpp"
+#include "host_parallel.hpp"
+
+#include <cstdlib>
+#include <memory>
+
+namespace {
+
+// combinations of k positions out of w, lexicographic (the order of itertools.combinations)
+std::vector<std::vector<int>> combos(int w, int k) {
+  std::vector<std::vector<int>> out;
+  std::vector<int> c((size_t)k);
+  for (int i = 0; i < k; ++i) c[(size_t)i] = i;
+  for (;;) {
+    out.push_back(c);
+    int i = k - 1;
+    while (i >= 0 && c[(size_t)i] == w - k + i) --i;
+    if (i < 0) break;
+    ++c[(size_t)i];
+    for (int j = i + 1; j < k; ++j) c[(size_t)j] = c[(size_t)j - 1] + 1;
+  }
+  return out;
+}
+
+}  // namespace
+
+extern "C" int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int k, int64_t n_points,
+                                      int n_threads, int32_t** out_rows) {
+  if (!cells || !out_rows || n_cells < 0 || width < 1 || width > 16 || k < 1 || k > width || n_points < 1) return E_FEW;
+  *out_rows = nullptr;
+  // keys: the face's vertex ids as digits to the base n_points, first vertex most significant
+  {
+    long double bits = 0;
+    for (int i = 0; i < k; ++i) bits += std::log2((long double)n_points);
+    if (bits >= 62.0L) return E_RANGE;
+  }
+  const uint64_t base = (uint64_t)n_points;
+  const std::vector<std::vector<int>> cb = combos(width, k);
+  const int64_t ncb = (int64_t)cb.size();
+  Pool pool(host_threads(n_threads));
+
+  // ---- distinct keys through a lock-free set (0 = empty: keys are stored + 1); grown and refilled when it gets full
+  size_t cap = 1024;
+  while (cap < (size_t)std::max<int64_t>(4 * n_cells, 1024)) cap <<= 1;
+  std::unique_ptr<std::atomic<uint64_t>[]> tab;
+  std::atomic<int64_t> distinct{0};
+  for (;;) {
+    tab.reset(new std::atomic<uint64_t>[cap]);
+    pool.parallel_for((int64_t)cap, 1 << 16, [&](int64_t a, int64_t b, int) {
+      for (int64_t i = a; i < b; ++i) tab[(size_t)i].store(0, std::memory_order_relaxed);
+    });
+    distinct.store(0);
+    std::atomic<int> full{0};
+    const int64_t limit = (int64_t)(cap / 2);
+    pool.parallel_for(n_cells, 256, [&](int64_t a, int64_t b, int) {
+      int64_t mine = 0;
+      for (int64_t c = a; c < b && !full.load(std::memory_order_relaxed); ++c) {
+        const int32_t* v = cells + c * width;
+        for (int64_t f = 0; f < ncb; ++f) {
+          uint64_t key = 0;
+          for (int i = 0; i < k; ++i) key = key * base + (uint64_t)(uint32_t)v[cb[(size_t)f][(size_t)i]];
+          size_t slot = (size_t)mix64(key) & (cap - 1);
+          for (;;) {
+            uint64_t cur = tab[slot].load(std::memory_order_relaxed);
+            if (cur == key + 1) break;
+            if (cur == 0) {
+              if (tab[slot].compare_exchange_strong(cur, key + 1, std::memory_order_relaxed)) { ++mine; break; }
+              if (cur == key + 1) break;
+            }
+            slot = (slot + 1) & (cap - 1);
+          }
+        }
+      }
+      if (distinct.fetch_add(mine, std::memory_order_relaxed) + mine > limit) full.store(1);
+    });
+    if (!full.load()) break;
+    cap <<= 1;
+  }
+  const int64_t nd = distinct.load();
+
+  // ---- collect, sort, unpack
+  std::vector<uint64_t> keys((size_t)nd);
+  {
+    std::atomic<int64_t> pos{0};
+    pool.parallel_for((int64_t)cap, 1 << 14, [&](int64_t a, int64_t b, int) {
+      uint64_t buf[512];
+      int m = 0;
+      auto flush = [&] {
+        const int64_t at = pos.fetch_add(m, std::memory_order_relaxed);
+        std::memcpy(&keys[(size_t)at], buf, sizeof(uint64_t) * (size_t)m);
+        m = 0;
+      };
+      for (int64_t i = a; i < b; ++i) {
+        const uint64_t v = tab[(size_t)i].load(std::memory_order_relaxed);
+        if (v) {
+          buf[m++] = v - 1;
+          if (m == 512) flush();
+        }
+      }
+      if (m) flush();
+    });
+  }
+  tab.reset();
+  if (nd > 1) {
+    // buckets over the key range, every bucket sorted by one thread
+    long double top = 1;
+    for (int i = 0; i < k; ++i) top *= (long double)base;
+    const int64_t nb = std::max<int64_t>(1, std::min<int64_t>(4096, nd / 1024));
+    const long double scale = (long double)nb / top;
+    auto bucket_of = [&](uint64_t key) {
+      const int64_t b = (int64_t)((long double)key * scale);
+      return b < 0 ? 0 : (b >= nb ? nb - 1 : b);
+    };
+    const int nt = pool.nt;
+    const int64_t per = (nd + nt - 1) / nt;
+    std::vector<int64_t> hist((size_t)nt * (size_t)nb, 0), start((size_t)nb + 1, 0);
+    pool.run([&](int tid) {
+      const int64_t a = tid * per, b = std::min(nd, a + per);
+      int64_t* h = &hist[(size_t)tid * (size_t)nb];
+      for (int64_t i = a; i < b; ++i) ++h[bucket_of(keys[(size_t)i])];
+    });
+    for (int64_t b = 0; b < nb; ++b) {
+      int64_t c = 0;
+      for (int t = 0; t < nt; ++t) {
+        const int64_t v = hist[(size_t)t * (size_t)nb + (size_t)b];
+        hist[(size_t)t * (size_t)nb + (size_t)b] = start[(size_t)b] + c;
+        c += v;
+      }
+      start[(size_t)b + 1] = start[(size_t)b] + c;
+    }
+    std::vector<uint64_t> tmp((size_t)nd);
+    pool.run([&](int tid) {
+      const int64_t a = tid * per, b = std::min(nd, a + per);
+      int64_t* h = &hist[(size_t)tid * (size_t)nb];
+      for (int64_t i = a; i < b; ++i) tmp[(size_t)h[bucket_of(keys[(size_t)i])]++] = keys[(size_t)i];
+    });
+    pool.parallel_for(nb, 1, [&](int64_t b0, int64_t b1, int) {
+      for (int64_t b = b0; b < b1; ++b) std::sort(tmp.begin() + start[(size_t)b], tmp.begin() + start[(size_t)b + 1]);
+    });
+    keys.swap(tmp);
+  }
+  int32_t* out = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nd, 1) * (size_t)k);
+  if (!out) return E_FEW;
+  pool.parallel_for(nd, 1 << 14, [&](int64_t a, int64_t b, int) {
+    for (int64_t i = a; i < b; ++i) {
+      uint64_t key = keys[(size_t)i];
+      for (int j = k - 1; j >= 0; --j) {
+        out[i * k + j] = (int32_t)(key % base);
+        key /= base;
+      }
+    }
+  });
+  *out_rows = out;
+  return nd;
+}
+
+// int32 rows widened into a caller-owned int64 array on all cores (the tables above are handed over as int32; numpy
+// wants int64 index arrays, and its single-threaded astype of 10 million entries costs as much as building them)
+extern "C" void flooder_widen_i32(const int32_t* src, int64_t count, int64_t* dst, int n_threads) {
+  if (!src || !dst || count <= 0) return;
+  Pool pool(count < (1 << 18) ? 1 : host_threads(n_threads));
+  pool.parallel_for(count, 1 << 16, [&](int64_t a, int64_t b, int) {
+    for (int64_t i = a; i < b; ++i) dst[i] = src[i];
+  });
+}

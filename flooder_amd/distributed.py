@@ -72,6 +72,9 @@ def min_reduce_hook(group: Optional[dist.ProcessGroup] = None, always: bool = Fa
         if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
             dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=group)
 
+    # a real collective: flood_complex first lets the ranks compare the shape of what they are about to reduce (a
+    # six-word MIN through this same hook) and raises on every rank instead of hanging in a mismatched all-reduce
+    hook.checks_ranks = True
     return hook
 
 

@@ -111,22 +111,54 @@ def delaunay_cells(points: np.ndarray) -> np.ndarray:
         # fewer points than a full simplex: a single (n-1)-simplex on all points
         cells = np.arange(n, dtype=np.int64)[None, :]
     else:
-        cells = _delaunay_native(points) if (dim in (2, 3) and NATIVE_DELAUNAY and n >= dim + 2) else None
+        cells = _delaunay_native(points) if (2 <= dim <= 8 and NATIVE_DELAUNAY and n >= dim + 2) else None
+        if cells is not None and dim > 3:
+            return cells      # (flooder_delaunay_nd: distinct rows of ascending ids, already in lexicographic order)
         if cells is None:
             cells = Delaunay(points).simplices
     return _unique_rows(np.sort(np.asarray(cells, dtype=np.int64), axis=1))
 
 
-NATIVE_DELAUNAY = True   # 2-D / 3-D: csrc/delaunay2d.cpp, delaunay3d.cpp (libflooder_host.so) instead of Qhull; falls back to Qhull where they decline
+NATIVE_DELAUNAY = True   # csrc/delaunay2d.cpp, delaunay3d.cpp, delaunay_nd.cpp (4 .. 8 dimensions, all host cores) in libflooder_host.so instead of Qhull; falls back to Qhull where they decline
+DELAUNAY_THREADS = 0     # threads of the 4 .. 8-dimensional routine: 0 = the CPUs of this process's share (see _host_threads)
 LAST_DELAUNAY = {"native": False, "code": 0}
 _HOST_DT = False
 
 
-def _delaunay_native(points: np.ndarray) -> Optional[np.ndarray]:
-    """Cells of the 2-D / 3-D Delaunay triangulation from ``flooder_delaunay2d`` / ``flooder_delaunay3d`` (incremental
-    insertion with exact predicates, host C++), or None where the routine declines the input (duplicate points, all
-    points collinear / coplanar, coordinates that do not scale to 58-bit integers - float64 clouds with a wide
-    exponent range) or the library is not there: the caller then asks Qhull as before."""
+def _host_threads() -> int:
+    """Threads for the host-parallel Delaunay routine: ``DELAUNAY_THREADS`` / FLOODER_HOST_THREADS if set, else the
+    CPUs this process may run on divided by the ranks of this node (LOCAL_WORLD_SIZE: one process per GPU all
+    triangulating the same landmarks at once), at most 128."""
+    import os
+
+    if DELAUNAY_THREADS > 0:
+        return int(DELAUNAY_THREADS)
+    env = os.environ.get("FLOODER_HOST_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        return int(env)
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    local = os.environ.get("LOCAL_WORLD_SIZE", "1")
+    local = int(local) if local.isdigit() and int(local) > 0 else 1
+    return max(1, min(128, cpus // local))
+
+
+def _take_rows(lib, out, count: int, width: int, threads: int) -> np.ndarray:
+    """The library's malloc'ed (count, width) int32 table as an int64 array (widened on all cores), buffer released."""
+    import ctypes
+
+    try:
+        rows = np.empty((count, width), dtype=np.int64)
+        lib.flooder_widen_i32(ctypes.cast(out, ctypes.c_void_p), count * width, rows.ctypes.data, threads)
+        return rows
+    finally:
+        lib.flooder_host_free(out)
+
+
+def _load_host():
+    """``libflooder_host.so`` with the Delaunay / face-table entry points bound (built on first use), or None."""
     global _HOST_DT
     if _HOST_DT is False:
         _HOST_DT = None
@@ -139,14 +171,39 @@ def _delaunay_native(points: np.ndarray) -> Optional[np.ndarray]:
             for f in (lib.flooder_delaunay2d, lib.flooder_delaunay3d):
                 f.restype = ctypes.c_int64
                 f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+            lib.flooder_delaunay_nd.restype = ctypes.c_int64
+            lib.flooder_delaunay_nd.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))]
+            lib.flooder_host_free.restype = None
+            lib.flooder_host_free.argtypes = [ctypes.c_void_p]
+            lib.flooder_delaunay_nd_stat.restype = ctypes.c_long
+            lib.flooder_delaunay_nd_stat.argtypes = [ctypes.c_int]
+            lib.flooder_widen_i32.restype = None
+            lib.flooder_widen_i32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+            lib.flooder_cell_faces.restype = ctypes.c_int64
+            lib.flooder_cell_faces.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))]
             _HOST_DT = lib
         except Exception:
             _HOST_DT = None
+    return _HOST_DT
+
+
+def _delaunay_native(points: np.ndarray) -> Optional[np.ndarray]:
+    """Cells of the Delaunay triangulation from ``flooder_delaunay2d`` / ``flooder_delaunay3d`` (incremental insertion
+    with exact predicates, host C++) or, in 4 .. 8 dimensions, ``flooder_delaunay_nd`` (gift wrapping over the facets on
+    all host cores, exact where floating point cannot decide), or None where the routine declines the input
+    (duplicate points, all points collinear / coplanar, coordinates that do not scale to 58-bit (121-bit: nd) integers
+    - float64 clouds with a wide exponent range -, above 3-D also an exact tie: cospherical points) or the library is
+    not there: the caller then asks Qhull as before."""
+    _load_host()
     LAST_DELAUNAY["native"] = False
     if _HOST_DT is None:
         return None
     pts = np.ascontiguousarray(points, dtype=np.float64)
     n, dim = pts.shape
+    if dim > 3:
+        return _delaunay_nd(pts)
     fn = _HOST_DT.flooder_delaunay3d if dim == 3 else _HOST_DT.flooder_delaunay2d
     # (n points in general position: ~6.8 n tetrahedra, at most 2 n triangles)
     cap = 8 * n + 64 if dim == 3 else 2 * n + 16
@@ -154,16 +211,70 @@ def _delaunay_native(points: np.ndarray) -> Optional[np.ndarray]:
         out = np.empty((cap, dim + 1), dtype=np.int32)
         rc = int(fn(pts.ctypes.data, n, out.ctypes.data, cap))
         if rc >= 0:
-            LAST_DELAUNAY.update(native=True, code=rc)
+            LAST_DELAUNAY.update(native=True, code=rc, routine="incremental")
             return out[:rc].astype(np.int64)
         if rc < -(1 << 40):   # declined
             LAST_DELAUNAY["code"] = rc
+            if rc == E_RANGE:
+                # coordinates that do not scale to 58-bit integers (float64 values with full mantissas): the
+                # d-dimensional routine works on a grid of up to 121 bits with multi-word integers - slower, exact all the same
+                cells = _delaunay_nd(pts)
+                return None if cells is None else _unique_rows(np.sort(cells, axis=1))
             return None
         cap = -rc
     return None
 
 
+E_RANGE = -(1 << 40) - 2     # csrc/exact_int.hpp: the coordinates do not fit the routine's integer grid
+
+
+def _delaunay_nd(pts: np.ndarray) -> Optional[np.ndarray]:
+    """``flooder_delaunay_nd``: (count, dim + 1) int64 rows of ascending ids in lexicographic order, or None."""
+    import ctypes
+
+    n, dim = pts.shape
+    out = ctypes.POINTER(ctypes.c_int32)()
+    threads = _host_threads()
+    rc = int(_HOST_DT.flooder_delaunay_nd(pts.ctypes.data, n, dim, threads, ctypes.byref(out)))
+    if rc < 0:
+        LAST_DELAUNAY["code"] = rc
+        return None
+    cells = _take_rows(_HOST_DT, out, rc, dim + 1, threads)
+    LAST_DELAUNAY.update(native=True, code=rc, threads=threads, routine="nd",
+                         exact_calls=int(_HOST_DT.flooder_delaunay_nd_stat(0)))
+    return cells
+
+
 _delaunay3d_native = _delaunay_native   # (name of the round-5 3-D entry point, kept for tools and tests)
+
+_C32_CACHE: list = [None, None]
+NATIVE_FACES_MIN = 2_000_000   # faces (cells x combinations) from which the table is enumerated by flooder_cell_faces
+
+
+def _faces_native(cells: np.ndarray, d: int, n_points: int) -> Optional[np.ndarray]:
+    """Sorted table of the distinct d-faces of ``cells`` from ``flooder_cell_faces`` (all host cores), or None where
+    the packed keys would not fit / the library is not there."""
+    import ctypes
+
+    lib = _load_host() if NATIVE_DELAUNAY else None
+    if lib is None:
+        return None
+    import weakref
+
+    if _C32_CACHE[0] is not None and _C32_CACHE[0]() is cells:   # (several dimensions' tables from the same cells)
+        c32 = _C32_CACHE[1]
+    else:
+        c32 = np.ascontiguousarray(cells, dtype=np.int32)
+        try:
+            _C32_CACHE[:] = [weakref.ref(cells, lambda _r: _C32_CACHE.__setitem__(slice(None), [None, None])), c32]
+        except TypeError:
+            _C32_CACHE[:] = [None, None]
+    out = ctypes.POINTER(ctypes.c_int32)()
+    rc = int(lib.flooder_cell_faces(c32.ctypes.data, c32.shape[0], c32.shape[1], d + 1,
+                                    max(int(n_points), int(c32.max()) + 1), _host_threads(), ctypes.byref(out)))
+    if rc < 0:
+        return None
+    return _take_rows(lib, out, rc, d + 1, _host_threads())
 
 
 def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
@@ -180,7 +291,7 @@ def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
     combos = list(itertools.combinations(range(width), d + 1))
     if d == 0 and n_points > 0:
         table = np.arange(n_points, dtype=np.int64)[:, None]
-        return table, cells.copy()            # (face j of a cell = its j-th vertex = row id)
+        return table, (cells.copy() if want_index else None)            # (face j of a cell = its j-th vertex = row id)
     base = int(cells.max()) + 1
     k = d + 1
     if want_index and base ** k < 2 ** 62:
@@ -193,6 +304,10 @@ def faces_of_cells(cells: np.ndarray, d: int, n_points: int = 0,
             table[:, j] = rest % base
             rest = rest // base
         return table, inv.reshape(keys.shape).astype(np.int64)
+    if not want_index and cells.shape[0] * len(combos) >= NATIVE_FACES_MIN:
+        table = _faces_native(cells, d, n_points)
+        if table is not None:
+            return table, None
     if base ** k < 2 ** 62:  # packed keys, one combination at a time (no (n_cells x n_combos, k) intermediate)
         mult = base ** np.arange(k - 1, -1, -1, dtype=np.int64)
         rest = np.unique(np.concatenate([cells[:, c] @ mult for c in combos]))
@@ -235,7 +350,8 @@ class SimplexTree:
         self._monotone = False                        # make_filtration_non_decreasing has run: late tables inherit
 
     @classmethod
-    def from_cells(cls, cells: np.ndarray, n_points: int, eager: Optional[int] = None) -> "SimplexTree":
+    def from_cells(cls, cells: np.ndarray, n_points: int, eager: Optional[int] = None,
+                   trusted: bool = False) -> "SimplexTree":
         """Complex spanned by top-dimensional ``cells`` (unique rows of ascending vertex ids) over ``n_points``
         vertices, filtration values NaN (what ``gudhi.DelaunayComplex(...).create_simplex_tree()`` returns).  Face
         tables of dimension <= ``eager`` (default: all) are enumerated now, the others when first touched - the
@@ -247,7 +363,9 @@ class SimplexTree:
         # of them, so its samples (weights x vertices, same fma order) and its value are bit-identical from every
         # cell - which is why "last writer wins" (assign_cell_faces) and "max per distinct face" (the fused
         # shared-slot sweep) agree bit for bit, and why sharded and unsharded runs are bit-equal.
-        if cells.shape[1] > 1 and not (np.diff(cells, axis=1) > 0).all():
+        # (``trusted``: rows that come straight from delaunay_cells, ascending by construction - the check is a pass over
+        # ten million entries for the 6-D complex of cfg 4)
+        if not trusted and cells.shape[1] > 1 and not (np.diff(cells, axis=1) > 0).all():
             raise ValueError("SimplexTree.from_cells: every cell must list its vertex ids in ascending order")
         st._cells = cells
         st._n_points = int(n_points)

@@ -16,8 +16,8 @@ extern "C" {
 #endif
 
 /*
- * Delaunay triangulation of n >= 5 points in THREE dimensions (csrc/delaunay3d.cpp; two dimensions: below; other
- * dimensions stay with Qhull).  Replaces
+ * Delaunay triangulation of n >= 5 points in THREE dimensions (csrc/delaunay3d.cpp; two dimensions: below; four to
+ * eight: flooder_delaunay_nd).  Replaces
  * gudhi.DelaunayComplex(landmarks) of core.py:130-132 (the top cells; core.py:136-138 buckets their faces) and the
  * Qhull call this build made through scipy.  Incremental Bowyer-Watson with ghost tetrahedra, orient3d / insphere
  * decided exactly (double filter, then 512-bit integers on a common dyadic grid of the coordinates).
@@ -37,6 +37,45 @@ int64_t flooder_delaunay3d(const double* pts, int64_t n, int32_t* tets, int64_t 
  *   points, all points collinear, non-finite values, an exponent spread of more than 57 bits).
  */
 int64_t flooder_delaunay2d(const double* pts, int64_t n, int32_t* tris, int64_t cap);
+
+/*
+ * Delaunay triangulation in 2 .. 8 dimensions on all host cores (csrc/delaunay_nd.cpp) - what flood_complex uses above
+ * three dimensions, where the reference's gudhi.DelaunayComplex (core.py:130-132) runs CGAL's d-dimensional
+ * triangulation and this build used to run Qhull (one thread: 8 s for the 2000 6-D landmarks of BASELINE cfg 4).
+ * Gift wrapping over the facets, level by level: the simplex beyond a facet of a Delaunay simplex is found by one
+ * pass over the points (two linear forms per point: power to the circumsphere, barycentric coordinate), the open
+ * facets of a level are spread over `n_threads` threads (<= 0: one per CPU of the affinity mask, at most 128), new
+ * simplices are deduplicated and their facets matched in lock-free tables.  Floating-point forms with rigorous error
+ * bounds decide almost every comparison; what they cannot decide is decided exactly over multi-word integers.
+ *   pts: n x dim float64, row-major (host).  *out_cells: malloc'ed (count, dim + 1) int32, ascending vertex ids per
+ *   row, rows in no particular order - release with flooder_host_free.
+ *   returns the number of simplices, or a code below -(1 << 40) when the routine declines the input (duplicate
+ *   points; an exact tie: dim + 2 cospherical points or dim + 1 points on a hyperplane met by a pivot; non-finite
+ *   values; an exponent spread of more than 120 bits; dim outside 2 .. 8): the caller triangulates with Qhull then.
+ */
+int64_t flooder_delaunay_nd(const double* pts, int64_t n, int dim, int n_threads, int32_t** out_cells);
+void flooder_host_free(void* p);
+/* diagnostics of the last flooder_delaunay_nd call: 0 exact predicate evaluations, 1 contenders that reached the exact
+ * stage, 2 threads used.  flooder_delaunay_nd_isa: test hook, forces the scan's instruction set (0 generic, 1 AVX2,
+ * 2 AVX-512, -1 detect); returns the previous value. */
+long flooder_delaunay_nd_stat(int what);
+int flooder_delaunay_nd_isa(int isa);
+
+/*
+ * The k-vertex faces of the top cells of a complex as ONE sorted table of distinct rows, on all host cores
+ * (csrc/cell_faces.cpp).  Replaces the Python loop of core.py:135-138 that buckets `stree.get_simplices()` by
+ * dimension (and this build's numpy enumeration: every cell's C(width, k) faces packed into keys and np.unique'd -
+ * 51 million keys for the triangles of the 6-D complex of BASELINE cfg 4).
+ *   cells: n_cells x width int32, ascending vertex ids < n_points per row (host).  *out_rows: malloc'ed (count, k) int32,
+ *   ascending ids per row, rows in lexicographic order - release with flooder_host_free.
+ *   returns the number of distinct faces, or a code below -(1 << 40): bad arguments, or n_points^k >= 2^62 (the packed
+ *   keys would not fit: the caller enumerates with numpy then).
+ */
+int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int k, int64_t n_points, int n_threads,
+                           int32_t** out_rows);
+
+/* count int32 values widened into a caller-owned int64 array, on all cores (numpy's index dtype). */
+void flooder_widen_i32(const int32_t* src, int64_t count, int64_t* dst, int n_threads);
 
 /*
  * Test hook of flooder_delaunay3d: the new tetrahedra of an insertion are linked to each other through the edges of

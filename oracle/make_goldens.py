@@ -242,9 +242,35 @@ def make_generator_vectors():
     print("generators:", {k: v.shape for k, v in gen.items()})
 
 
+def make_visualization_vectors():
+    """Section 5 on its own: ``python oracle/make_goldens.py visualization``.
+
+    The reference commits three 1000-landmark clouds together with the simplices gudhi (CGAL) produced for them and
+    their filtration values (``docs/visualization/{virus,coral,lockwasher}/{landmarks,edges,triangles,tetrahedra}.csv``,
+    the data behind ``docs/visualizations.md``).  They are the only output of the REAL ``gudhi.DelaunayComplex`` in the
+    repository: the fixtures keep the numbers - landmark coordinates as float64, vertex ids as int32, values as float64 -
+    so that the native Delaunay routines are pinned to gudhi itself, not only to Qhull."""
+    os.makedirs(OUT, exist_ok=True)
+    for name in ("virus", "coral", "lockwasher"):
+        d = os.path.join(REF, "docs", "visualization", name)
+        lms = np.loadtxt(os.path.join(d, "landmarks.csv"), delimiter=",", dtype=np.float64)
+        out = {"landmarks": lms}
+        for kind in ("edges", "triangles", "tetrahedra"):
+            t = np.loadtxt(os.path.join(d, f"{kind}.csv"), delimiter=",", dtype=np.float64)
+            ids = t[:, :-1]
+            assert (ids == np.round(ids)).all()
+            out[kind] = ids.astype(np.int32)
+            out[f"{kind}_filtration"] = t[:, -1]
+        np.savez_compressed(os.path.join(OUT, f"docs_visualization_{name}.npz"), **out)
+        print(f"visualization {name}: {lms.shape[0]} landmarks, "
+              f"{ {k: v.shape[0] for k, v in out.items() if k in ('edges', 'triangles', 'tetrahedra')} }")
+
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["generators"]:
         make_generator_vectors()
+    elif sys.argv[1:] == ["visualization"]:
+        make_visualization_vectors()
     else:
         main()
+        make_visualization_vectors()

@@ -147,8 +147,17 @@ def test_degenerate_inputs_give_a_valid_delaunay_triangulation(case):
 def test_inputs_the_routine_declines_fall_back_to_qhull():
     rng = np.random.default_rng(5)
     P = rng.normal(size=(200, 3))                       # float64 with full mantissas: does not scale to 58-bit integers
-    assert native(P) is None and stm.LAST_DELAUNAY["code"] < -(1 << 40)
+    import ctypes
+
+    out = np.empty((2000, 4), dtype=np.int32)
+    assert int(stm._load_host().flooder_delaunay3d(P.ctypes.data, 200, out.ctypes.data, 2000)) == stm.E_RANGE
+    # ... round 6: the d-dimensional routine (a grid of up to 121 bits) takes what the incremental one declines for RANGE
+    got = native(P)
+    assert got is not None and stm.LAST_DELAUNAY["routine"] == "nd" and np.array_equal(got, qhull(P))
     assert np.array_equal(stm.delaunay_cells(P), qhull(P))
+    huge = P.copy()
+    huge[0, 0], huge[1, 0] = 2.0 ** 90, 2.0 ** -40        # beyond that grid too: Qhull
+    assert native(huge) is None and stm.LAST_DELAUNAY["code"] < -(1 << 40)
     Q = rng.normal(size=(50, 3)).astype(np.float32)
     Q[7] = Q[3]                                          # a duplicate point
     assert native(Q) is None
@@ -255,7 +264,10 @@ def test_degenerate_2d_inputs_give_a_valid_delaunay_triangulation(case):
 def test_2d_inputs_the_routine_declines_fall_back_to_qhull():
     rng = np.random.default_rng(14)
     P = rng.normal(size=(200, 2))                       # float64 with full mantissas
-    assert native(P) is None and stm.LAST_DELAUNAY["code"] < -(1 << 40)
+    out = np.empty((800, 3), dtype=np.int32)
+    assert int(stm._load_host().flooder_delaunay2d(P.ctypes.data, 200, out.ctypes.data, 800)) == stm.E_RANGE
+    got = native(P)                                      # (round 6: taken by the d-dimensional routine instead)
+    assert got is not None and stm.LAST_DELAUNAY["routine"] == "nd" and np.array_equal(got, qhull(P))
     assert np.array_equal(stm.delaunay_cells(P), qhull(P))
     Q = rng.normal(size=(50, 2)).astype(np.float32)
     Q[7] = Q[3]                                          # a duplicate point

@@ -12,10 +12,10 @@ for s in $STEPS; do
   case $s in
     test)   timeout 900 python -m pytest tests -m gpu -x -q --timeout 200 --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
     testall) timeout 1500 python -m pytest tests -m gpu -q --durations=12 > $OUT/pytest_gpu.txt 2>&1; tail -15 $OUT/pytest_gpu.txt ;;
-    bench)  timeout 600 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; cut -c1-600 $OUT/bench_cfg2.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg2.json $OUT/profiles/r5_cfg2_bench.json ;;
-    bench3) timeout 900 python bench.py --workload cfg3 --cpu-sample 600 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg3.json $OUT/profiles/r5_cfg3_bench.json ;;
-    bench4) timeout 1500 python bench.py --workload cfg4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; cut -c1-1500 $OUT/bench_cfg4.json; tail -3 $OUT/bench_cfg4.err ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg4.json $OUT/profiles/r5_cfg4_bench.json ;;
-    bench5) timeout 1500 python bench.py --workload cfg5 --cpu-sample 300 --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg5.json $OUT/profiles/r5_cfg5_bench.json ;;
+    bench)  timeout 600 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; cut -c1-600 $OUT/bench_cfg2.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg2.json $OUT/profiles/r6_cfg2_bench.json ;;
+    bench3) timeout 900 python bench.py --workload cfg3 --cpu-sample 600 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; cut -c1-400 $OUT/bench_cfg3.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg3.json $OUT/profiles/r6_cfg3_bench.json ;;
+    bench4) timeout 1500 python bench.py --workload cfg4 --steps 5 --warmup 1 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; cut -c1-1500 $OUT/bench_cfg4.json; tail -3 $OUT/bench_cfg4.err ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg4.json $OUT/profiles/r6_cfg4_bench.json ;;
+    bench5) timeout 1500 python bench.py --workload cfg5 --cpu-sample 300 --steps 20 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; cut -c1-400 $OUT/bench_cfg5.json ; mkdir -p $OUT/profiles; cp $OUT/bench_cfg5.json $OUT/profiles/r6_cfg5_bench.json ;;
     bench2) timeout 600 python bench.py --gpus 2 --no-cpu-baseline > $OUT/bench_cfg2_2ranks.json 2> $OUT/bench_cfg2_2ranks.err; cut -c1-400 $OUT/bench_cfg2_2ranks.json; tail -3 $OUT/bench_cfg2_2ranks.err ;;
     ranks2:*) # ranks2:<workload>:<shard mode>  two ranks on the ONE GPU (gloo): functional check of bench.py --gpus N
             IFS=: read -r _ wl sh <<< "$s"
@@ -30,8 +30,8 @@ except Exception as e:
 PY
             ;;
     prof:*) bash tools/collect_profiles.sh ${s#prof:} > $OUT/collect_${s#prof:}.log 2>&1; tail -3 $OUT/collect_${s#prof:}.log
-            python tools/summarize_profiles.py ${s#prof:} r5_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
-            mkdir -p $OUT/profiles && cp profiles/r5_${s#prof:}_kernel_stats.csv profiles/r5_${s#prof:}_pmc.json profiles/r5_${s#prof:}_bench_under_rocprof.json profiles/traffic.json $OUT/profiles/
+            python tools/summarize_profiles.py ${s#prof:} r6_${s#prof:} > $OUT/summ_${s#prof:}.log 2>&1; tail -4 $OUT/summ_${s#prof:}.log
+            mkdir -p $OUT/profiles && cp profiles/r6_${s#prof:}_kernel_stats.csv profiles/r6_${s#prof:}_pmc.json profiles/r6_${s#prof:}_bench_under_rocprof.json profiles/traffic.json $OUT/profiles/
             rm -rf $R/gpurun_out/prof_${s#prof:} ;;   # (only the summaries travel back: gpurun_out is capped at 64 MiB)
     emul)   bash tools/emulate_scaling.sh cfg2 > $OUT/emulate_cfg2.txt 2>&1; cat $OUT/emulate_cfg2.txt ;;
     emul:*) bash tools/emulate_scaling.sh ${s#emul:} > $OUT/emulate_${s#emul:}.txt 2>&1; cat $OUT/emulate_${s#emul:}.txt ;;
