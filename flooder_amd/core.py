@@ -1676,6 +1676,12 @@ def flood_complex(
                     combos = list(itertools.combinations(range(d + 1), k))
                     results.append(("cells", k - 1, order_np, [combos.index(tuple(int(x) for x in row)) for row in v_idx],
                                     vals_k))
+                elif isinstance(stree, SimplexTree) and k == d + 1 and nf == 1:
+                    # the swept simplices themselves: simp_h is the dimension-d table in queue order
+                    results.append(("rows", d, order_np, vals_k.reshape(-1)))
+                elif isinstance(stree, SimplexTree) and k == 1 and stree._cells is not None:
+                    # vertices of a complex built from cells: row = vertex id (later rows win, as a dict update does)
+                    results.append(("rows", 0, simp_h[:, v_idx].reshape(-1), vals_k.reshape(-1)))
                 else:
                     results.append((simp_h[:, v_idx].reshape(-1, k), vals_k.reshape(-1)))
         else:
@@ -1686,6 +1692,9 @@ def flood_complex(
         for item in results:
             if isinstance(item[0], str) and item[0] == "table":
                 stree._vals[item[1]][:] = item[2]
+                stree._persistence = None
+            elif isinstance(item[0], str) and item[0] == "rows":
+                stree.filtrations_of_dimension(item[1])[item[2]] = item[3]
                 stree._persistence = None
             elif isinstance(item[0], str):
                 stree.assign_cell_faces(item[1], item[2], item[3], item[4])

@@ -173,3 +173,54 @@ extern "C" void flooder_widen_i32(const int32_t* src, int64_t count, int64_t* ds
     for (int64_t i = a; i < b; ++i) dst[i] = src[i];
   });
 }
+
+// One step of the monotone pass (gudhi Simplex_tree::make_filtration_non_decreasing, reference core.py:280) on all
+// cores: every row of the dimension-d table is raised to the largest value among its facets, which are located in the
+// sorted table of dimension d - 1 by binary search on packed keys.  A NaN facet value does not take part, a NaN own
+// value is replaced by the facets' maximum, a row none of whose facets is found (or all are NaN) keeps its value.
+// Returns the number of rows whose value changed, or a code below -(1 << 40) (keys that do not fit 62 bits).
+extern "C" int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k, const int64_t* lower_rows, int64_t n_lo,
+                                           const double* lower_vals, double* vals, int64_t n_points, int n_threads) {
+  if (!rows || !lower_rows || !lower_vals || !vals || n < 0 || n_lo < 0 || k < 2 || k > 16 || n_points < 1) return E_FEW;
+  {
+    long double bits = 0;
+    for (int i = 0; i < k - 1; ++i) bits += std::log2((long double)n_points);
+    if (bits >= 62.0L) return E_RANGE;
+  }
+  const uint64_t base = (uint64_t)n_points;
+  Pool pool(n * k < (1 << 16) ? 1 : host_threads(n_threads));
+  std::vector<uint64_t> keys((size_t)n_lo);
+  pool.parallel_for(n_lo, 1 << 14, [&](int64_t a, int64_t b, int) {
+    for (int64_t i = a; i < b; ++i) {
+      uint64_t key = 0;
+      for (int j = 0; j < k - 1; ++j) key = key * base + (uint64_t)lower_rows[i * (k - 1) + j];
+      keys[(size_t)i] = key;
+    }
+  });
+  std::atomic<int64_t> changed{0};
+  pool.parallel_for(n, 1 << 12, [&](int64_t a, int64_t b, int) {
+    int64_t mine = 0;
+    for (int64_t i = a; i < b; ++i) {
+      const int64_t* r = rows + i * k;
+      double face_max = -HUGE_VAL;
+      for (int omit = 0; omit < k; ++omit) {
+        uint64_t key = 0;
+        for (int j = 0; j < k; ++j)
+          if (j != omit) key = key * base + (uint64_t)r[j];
+        const uint64_t* it = std::lower_bound(keys.data(), keys.data() + n_lo, key);
+        if (it == keys.data() + n_lo || *it != key) continue;
+        const double v = lower_vals[it - keys.data()];
+        if (v == v && v > face_max) face_max = v;
+      }
+      const double own = vals[i];
+      double raised = own != own ? face_max : (face_max > own ? face_max : own);
+      if (raised == -HUGE_VAL) raised = own;
+      if (!(raised == own || (raised != raised && own != own))) {
+        vals[i] = raised;
+        ++mine;
+      }
+    }
+    changed.fetch_add(mine, std::memory_order_relaxed);
+  });
+  return changed.load();
+}

@@ -390,11 +390,12 @@ struct Engine {
 
   // ---- one pivot result per (simplex, open facet)
   struct Contender { int q; double lo, hi; };
-  struct Scan {                       // per thread
+  struct alignas(128) Scan {          // per thread (aligned: the threads' states must not share cache lines)
     std::vector<Contender> cont[D + 1];
     double ustar[D + 1];
-    long flagged = 0;
+    long flagged = 0, pivots = 0;
     ExactCtx cx;
+    char pad[128];
   };
 
   // One block of points against the forms of one simplex: numc = max(0, power - e_pow) (+inf for the simplex's own
@@ -497,7 +498,7 @@ struct Engine {
     if (nk == 0) return;
     Geometry<D> G;
     geometry(vs, G);
-    n_pivots.fetch_add(nk, std::memory_order_relaxed);
+    sc.pivots += nk;
     if (!G.usable) {   // a sliver the double inverse cannot bound: every point is a contender, decided exactly
       for (int a = 0; a < nk; ++a) {
         const int k = ks[a];
@@ -692,7 +693,7 @@ struct Engine {
       const double t0 = now();
       // (a) pivots across the open facets of this level
       apex.assign((size_t)nf * V, -3);
-      pool.parallel_for(nf, 4, [&](int64_t a, int64_t b, int tid) {
+      pool.parallel_for(nf, std::max<int64_t>(1, std::min<int64_t>(16, nf / (8 * (int64_t)pool.nt))), [&](int64_t a, int64_t b, int tid) {
         for (int64_t s = a; s < b; ++s) {
           if (error.load(std::memory_order_relaxed)) return;
           pivots(&verts[(size_t)(lo + s) * V], open_mask[(size_t)(lo + s)], &apex[(size_t)s * V], scans[(size_t)tid]);
@@ -831,7 +832,7 @@ struct Engine {
     }
     if (std::getenv("FLOODER_DELAUNAY_VERBOSE"))
       std::fprintf(stderr, "delaunay_nd<%d>: %ld simplices, %d levels, pivots %.3f s, tables %.3f s, %d threads; %ld pivots, %ld flagged points\n", D,
-                   (long)hi, levels, t_piv, t_rest, pool.nt, n_pivots.load(), [&] { long f = 0; for (auto& s : scans) f += s.flagged; return f; }());
+                   (long)hi, levels, t_piv, t_rest, pool.nt, [&] { long f = 0; for (auto& s : scans) f += s.pivots; return f; }(), [&] { long f = 0; for (auto& s : scans) f += s.flagged; return f; }());
     const int64_t total = hi;
     int32_t* out = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1) * V);
     if (!out) return E_TOO_MANY;

@@ -23,8 +23,9 @@ struct Pool {
   std::mutex m;
   std::condition_variable cv, cv_done;
   const std::function<void(int)>* job = nullptr;
-  long gen = 0;
-  int pending = 0;
+  alignas(128) std::atomic<long> gen{0};        // bumped for every parallel region: idle threads spin on it for a while
+  alignas(128) std::atomic<int> pending{0};
+  alignas(128) std::atomic<int> sleepers{0};
   bool stop = false;
   explicit Pool(int n) : nt(n < 1 ? 1 : n) {
     for (int t = 1; t < nt; ++t) th.emplace_back([this, t] { loop(t); });
@@ -33,25 +34,34 @@ struct Pool {
     {
       std::lock_guard<std::mutex> l(m);
       stop = true;
+      gen.fetch_add(1, std::memory_order_release);
     }
     cv.notify_all();
     for (auto& t : th) t.join();
   }
+  // The regions of one call follow each other within microseconds (level after level): a thread that finds no work
+  // spins on the generation counter for about 100 us before it goes to sleep on the condition variable - waking a
+  // hundred sleepers costs more than most regions last.
   void loop(int tid) {
     long seen = 0;
     for (;;) {
-      const std::function<void(int)>* j;
-      {
+      int spins = 0;
+      while (gen.load(std::memory_order_acquire) == seen) {
+        if (++spins < 4000) {
+          __builtin_ia32_pause();
+          continue;
+        }
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return stop || gen != seen; });
-        if (stop) return;
-        seen = gen;
-        j = job;
+        sleepers.fetch_add(1, std::memory_order_relaxed);
+        cv.wait(l, [&] { return gen.load(std::memory_order_acquire) != seen; });
+        sleepers.fetch_sub(1, std::memory_order_relaxed);
       }
-      (*j)(tid);
-      {
+      seen = gen.load(std::memory_order_acquire);
+      if (stop) return;
+      (*job)(tid);
+      if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         std::lock_guard<std::mutex> l(m);
-        if (--pending == 0) cv_done.notify_one();
+        cv_done.notify_one();
       }
     }
   }
@@ -60,20 +70,27 @@ struct Pool {
     {
       std::lock_guard<std::mutex> l(m);
       job = &f;
-      pending = nt - 1;
-      ++gen;
+      pending.store(nt - 1, std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
     }
-    cv.notify_all();
+    if (sleepers.load(std::memory_order_relaxed) > 0) cv.notify_all();
     f(0);
-    std::unique_lock<std::mutex> l(m);
-    cv_done.wait(l, [&] { return pending == 0; });
+    int spins = 0;
+    while (pending.load(std::memory_order_acquire) != 0) {
+      if (++spins < 20000) {
+        __builtin_ia32_pause();
+        continue;
+      }
+      std::unique_lock<std::mutex> l(m);
+      cv_done.wait(l, [&] { return pending.load(std::memory_order_acquire) == 0; });
+    }
   }
   // f(i0, i1, tid) over [0, n) in chunks; small ranges run on the calling thread
   template <class F>
   void parallel_for(int64_t n, int64_t chunk, F f) {
     if (n <= 0) return;
     if (nt == 1 || n <= chunk) { f((int64_t)0, n, 0); return; }
-    std::atomic<int64_t> next{0};
+    alignas(128) std::atomic<int64_t> next{0};
     const std::function<void(int)> body = [&](int tid) {
       for (;;) {
         const int64_t i0 = next.fetch_add(chunk, std::memory_order_relaxed);

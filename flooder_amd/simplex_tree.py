@@ -120,6 +120,7 @@ def delaunay_cells(points: np.ndarray) -> np.ndarray:
 
 
 NATIVE_DELAUNAY = True   # csrc/delaunay2d.cpp, delaunay3d.cpp, delaunay_nd.cpp (4 .. 8 dimensions, all host cores) in libflooder_host.so instead of Qhull; falls back to Qhull where they decline
+HOST_THREADS_MAX = 32    # measured on the 2 x 64-core host of the MI355X box: 16 - 32 threads are the optimum (345 ms for cfg 4's Delaunay; 8: 690, 64: 510, 128: 890 - the level barriers and the tables' cache lines cost more than the extra cores give)
 DELAUNAY_THREADS = 0     # threads of the 4 .. 8-dimensional routine: 0 = the CPUs of this process's share (see _host_threads)
 LAST_DELAUNAY = {"native": False, "code": 0}
 _HOST_DT = False
@@ -128,7 +129,7 @@ _HOST_DT = False
 def _host_threads() -> int:
     """Threads for the host-parallel Delaunay routine: ``DELAUNAY_THREADS`` / FLOODER_HOST_THREADS if set, else the
     CPUs this process may run on divided by the ranks of this node (LOCAL_WORLD_SIZE: one process per GPU all
-    triangulating the same landmarks at once), at most 128."""
+    triangulating the same landmarks at once), at most ``HOST_THREADS_MAX``."""
     import os
 
     if DELAUNAY_THREADS > 0:
@@ -142,7 +143,7 @@ def _host_threads() -> int:
         cpus = os.cpu_count() or 1
     local = os.environ.get("LOCAL_WORLD_SIZE", "1")
     local = int(local) if local.isdigit() and int(local) > 0 else 1
-    return max(1, min(128, cpus // local))
+    return max(1, min(HOST_THREADS_MAX, cpus // local))
 
 
 def _take_rows(lib, out, count: int, width: int, threads: int) -> np.ndarray:
@@ -180,6 +181,10 @@ def _load_host():
             lib.flooder_delaunay_nd_stat.argtypes = [ctypes.c_int]
             lib.flooder_widen_i32.restype = None
             lib.flooder_widen_i32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+            lib.flooder_raise_dimension.restype = ctypes.c_int64
+            lib.flooder_raise_dimension.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                    ctypes.c_int]
             lib.flooder_cell_faces.restype = ctypes.c_int64
             lib.flooder_cell_faces.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32))]
@@ -248,6 +253,7 @@ def _delaunay_nd(pts: np.ndarray) -> Optional[np.ndarray]:
 _delaunay3d_native = _delaunay_native   # (name of the round-5 3-D entry point, kept for tools and tests)
 
 _C32_CACHE: list = [None, None]
+NATIVE_RAISE_MIN = 1_000_000   # facets (rows x (d + 1)) from which the monotone pass runs in flooder_raise_dimension
 NATIVE_FACES_MIN = 2_000_000   # faces (cells x combinations) from which the table is enumerated by flooder_cell_faces
 
 
@@ -679,8 +685,22 @@ class SimplexTree:
             return False
         vals = self._vals[d]
         lower = self._vals[d - 1]
-        face_max = np.full(rows.shape[0], -np.inf)
         facets = self._facet_rows(d)
+        if facets is None and rows.shape[0] * (d + 1) >= NATIVE_RAISE_MIN and NATIVE_DELAUNAY:
+            lib = _load_host()     # the facets located and compared on all host cores (csrc/cell_faces.cpp)
+            if lib is not None:
+                lo_rows = np.ascontiguousarray(self._rows[d - 1], dtype=np.int64)
+                r64 = np.ascontiguousarray(rows, dtype=np.int64)
+                v64 = np.ascontiguousarray(vals, dtype=np.float64).copy()
+                rc = int(lib.flooder_raise_dimension(r64.ctypes.data, r64.shape[0], d + 1, lo_rows.ctypes.data,
+                                                     lo_rows.shape[0], np.ascontiguousarray(lower, dtype=np.float64).ctypes.data,
+                                                     v64.ctypes.data, max(self._n_points, int(r64.max()) + 1, int(lo_rows.max()) + 1),
+                                                     _host_threads()))
+                if rc >= 0:
+                    if rc > 0:
+                        self._vals[d] = v64
+                    return rc > 0
+        face_max = np.full(rows.shape[0], -np.inf)
         for j in range(d + 1):
             if facets is not None:
                 idx = facets[:, j]

@@ -74,6 +74,16 @@ int flooder_delaunay_nd_isa(int isa);
 int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int k, int64_t n_points, int n_threads,
                            int32_t** out_rows);
 
+/*
+ * One step of gudhi's make_filtration_non_decreasing (reference core.py:280) on all host cores: the values of the
+ * dimension-d table (rows: n x k int64, k = d + 1, ascending ids) raised to the maxima of their facets, which are
+ * located in the sorted dimension-(d-1) table (lower_rows: n_lo x (k-1), lexicographic order; lower_vals).  NaN facet
+ * values do not take part; a NaN own value becomes the facets' maximum.  Returns the number of rows changed, or a code
+ * below -(1 << 40) (n_points^(k-1) >= 2^62: the caller runs the numpy pass).
+ */
+int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k, const int64_t* lower_rows, int64_t n_lo,
+                                const double* lower_vals, double* vals, int64_t n_points, int n_threads);
+
 /* count int32 values widened into a caller-owned int64 array, on all cores (numpy's index dtype). */
 void flooder_widen_i32(const int32_t* src, int64_t count, int64_t* dst, int n_threads);
 

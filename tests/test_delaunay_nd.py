@@ -206,6 +206,33 @@ def test_face_table_declines_keys_that_do_not_fit():
     lib.flooder_host_free(out)
 
 
+def test_parallel_monotone_pass_equals_numpy(monkeypatch):
+    """flooder_raise_dimension (one step of make_filtration_non_decreasing on all cores) against the numpy pass: NaN own
+    values take the facets' maximum, NaN facet values do not take part, values already above their facets stay."""
+    rng = np.random.default_rng(8)
+    cells = qhull(rng.normal(size=(120, 5)))
+
+    def tree():
+        st = stm.SimplexTree.from_cells(cells, 120)
+        r = np.random.default_rng(9)
+        for d in range(6):
+            v = r.random(len(st.simplices_of_dimension(d)))
+            v[r.random(len(v)) < 0.3] = np.nan
+            st._vals[d] = v
+        st._cell_faces = {d: None for d in range(6)}          # (no cell -> face rows: the facets are located by key)
+        return st
+
+    a, b = tree(), tree()
+    monkeypatch.setattr(stm, "NATIVE_RAISE_MIN", 10 ** 15)
+    ca = a.make_filtration_non_decreasing()
+    monkeypatch.setattr(stm, "NATIVE_RAISE_MIN", 1)
+    cb = b.make_filtration_non_decreasing()
+    assert ca == cb is True
+    for d in range(6):
+        assert np.array_equal(a._vals[d], b._vals[d], equal_nan=True)
+    assert not b.make_filtration_non_decreasing()              # idempotent
+
+
 # ------------------------------------------------------------------------------------------------ gudhi's own output
 VIS = ["virus", "coral", "lockwasher"]
 

@@ -933,9 +933,9 @@ def test_the_index_of_generate_landmarks_is_reused_by_flood_complex(dev, monkeyp
         fa.flood_complex(pin, lin, points_per_edge=6)
         assert len(built) == n0 + 1
     import gc
-    tmp = torch.randn(100_000, 3, generator=g).to(dev)                  # the entry dies with its tensor
+    tmp = torch.randn(250_000, 3, generator=g).to(dev)                  # the entry dies with its tensor
     fa.generate_landmarks(tmp, 80, start_idx=0)
-    assert core._LAST_INDEX[2] is not None
+    assert core._LAST_INDEX[2] is not None and core._LAST_INDEX[0]() is tmp
     del tmp
     gc.collect()
     assert core._LAST_INDEX[2] is None
