@@ -15,6 +15,66 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # the product library and selected here - the product file is never overwritten)
 LIB_PATH = os.environ.get("FLOODER_HIP_LIB") or os.path.join(_PKG_DIR, "libflooder_hip.so")
 
+
+
+class _Block(ctypes.Structure):
+    """A parameter block of include/flooder_hip.h: ``size`` and ``abi`` are filled in, fields are set by NAME (a
+    keyword that is not a field of the struct is a TypeError), tensors are passed as their ``data_ptr()``."""
+
+    ABI = 1
+
+    def __init__(self, **fields):
+        super().__init__()
+        self.size = ctypes.sizeof(self)
+        self.abi = self.ABI
+        known = {name for name, _ in self._fields_}
+        for key, value in fields.items():
+            if key not in known:
+                raise TypeError(f"{type(self).__name__} has no field {key!r}")
+            if value is not None and not isinstance(value, (int, float)):
+                value = ptr(value)
+            setattr(self, key, value)
+
+
+def _fields(spec: str):
+    """``"p pts_sorted; i64 n_pts; i32 dim"`` -> ctypes fields (p: pointer, i64 / i32 / u32 / f32)."""
+    kinds = {"p": c_void_p, "i64": c_int64, "i32": c_int32, "u32": c_uint32, "f32": c_float}
+    out = []
+    for item in spec.replace("\n", " ").split(";"):
+        item = item.strip()
+        if item:
+            kind, name = item.split()
+            out.append((name, kinds[kind]))
+    return out
+
+
+class FusedSweep(_Block):
+    """``flooder_fused_sweep_t``: the buffers the three launches of the fused 2-D / 3-D sweep share."""
+
+    _fields_ = _fields("""u32 size; u32 abi; p pts_sorted; i64 n_pts; i32 dim; i32 k1; p nodes; p density_grid; p cloud_box;
+        p verts; p weights; i32 R; i32 n_faces; i64 n_simplices; p memb; f32 alpha; i32 n_coarse; p coarse_rows; p parents;
+        p face_bits; p face_slot; p d2_scratch; p flag_list; p flag_count; p flag_key; p flag_hist; p flag_sorted; p top;
+        p top_list; p top_count; p simplex_weight; p plane_scratch; p wit_queue; p wit_item_list; p wit_stats;
+        p cell_queue; p defer_list; p defer_c; p defer_ctl; p light_list; p heavy_list; p cell_stats; p finish_ctl;
+        p hard_scratch; i32 hard_cap; i32 probed; p finish_stats""")
+
+
+class SortedSweep(_Block):
+    """``flooder_sorted_sweep_t``: the sorted-sample sweep above three dimensions."""
+
+    _fields_ = _fields("""u32 size; u32 abi; p pts_sorted; i64 n_pts; i32 dim; i32 k1; p nodes; p verts; p weights; i32 R;
+        i32 n_faces; i64 n_simplices; p sample_order; p queue; p memb; p face_bits; p face_slot; p stats; p out_d2;
+        i32 shard_rank; i32 shard_world""")
+
+
+class FpsBatched(_Block):
+    """``flooder_fps_batched_t``: the batched landmark selection."""
+
+    _fields_ = _fields("""u32 size; u32 abi; p pts; i64 n_pts; i32 dim; i32 ld; p pts_sorted; p order; i64 start; i32 n_lms;
+        i32 reserved; p out_idx; p minsq; p bucket_box; p bucket_keys; p bucket_coord; p work_best; p work_rec; p work_ctr;
+        p launches_out""")
+
+
 _lib = None
 _load_error: Exception | None = None
 _load_missing = False  # the last failure was "file not found" (worth another look after a build)
@@ -58,14 +118,6 @@ SIGNATURES = {
     "flooder_sample_keys_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "flooder_sample_keys_late_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),
-    "flooder_sweep_bvh_sorted_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                                   c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                                   c_void_p, c_void_p]),
-    "flooder_sweep_bvh_sorted_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "flooder_sweep_bvh_sorted_shard_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                                   c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                                   c_void_p]),
     "flooder_sweep_bvh_items_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
@@ -74,21 +126,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     "flooder_density_grid_words": (c_int64, [c_int]),
     "flooder_density_grid_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
-    "flooder_sweep_cell_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                             c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_wit_max_rows": (c_int, []),
     "flooder_wit_max_coarse": (c_int, []),
-    "flooder_sweep_witness_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
-                                          c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "flooder_finish_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "flooder_face_values_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "flooder_simplex_weight_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -102,11 +141,44 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flooder_fps_batched_max_points": (c_int64, []),
     "flooder_fps_batched_rec_words": (c_int64, [c_int64, c_int, c_int]),
+    "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    # the parameter-block forms of the long entry points (what the default path calls)
+    "flooder_fused_witness": (c_int, [ctypes.POINTER(FusedSweep), c_void_p]),
+    "flooder_fused_cell": (c_int, [ctypes.POINTER(FusedSweep), c_void_p]),
+    "flooder_fused_finish": (c_int, [ctypes.POINTER(FusedSweep), c_void_p]),
+    "flooder_sorted_faces": (c_int, [ctypes.POINTER(SortedSweep), c_void_p]),
+    "flooder_sorted_minima": (c_int, [ctypes.POINTER(SortedSweep), c_void_p]),
+    "flooder_fps_batched": (c_int, [ctypes.POINTER(FpsBatched), c_void_p]),
+}
+
+# The positional forms of the five entry points above: still exported by the library (same symbols as before round 6),
+# typed here so that the symbol test covers them and tests can call them, but nothing in flooder_amd does.
+POSITIONAL_SIGNATURES = {
+    "flooder_sweep_bvh_sorted_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                             c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_sweep_bvh_sorted_shard_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                   c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p]),
+    "flooder_sweep_cell_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                             c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_sweep_witness_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                          c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flooder_finish_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "flooder_sweep_bvh_sorted_faces_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                   c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p]),
     "flooder_fps_batched_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
-    "flooder_fps_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
-                                c_void_p, c_void_p]),
 }
 
 
@@ -128,7 +200,7 @@ def load():
         if _load_missing:
             raise OSError(f"{LIB_PATH} not found")
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **POSITIONAL_SIGNATURES}.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

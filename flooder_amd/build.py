@@ -29,7 +29,7 @@ def _tmp(path: str) -> str:
     must never publish another process's half-written file."""
     return f"{path}.{os.getpid()}.tmp"
 
-HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip"]
+HIP_SOURCES = ["flood_kernels.hip", "flood_bvh.hip", "flood_cell.hip", "flood_finish.hip", "flood_fps.hip", "flood_fps2.hip", "flood_index.hip", "flood_f64.hip", "flood_sorted.hip", "flood_wit.hip", "flood_params.hip"]
 HOST_SOURCES = ["persistence.cpp", "delaunay3d.cpp", "delaunay2d.cpp", "delaunay_nd.cpp", "cell_faces.cpp"]
 HOST_HEADERS = ["exact_int.hpp", "host_parallel.hpp"]
 

@@ -29,6 +29,7 @@ The (S, R, dim) tensor of sample points the reference materialises (``core.py:18
 
 from __future__ import annotations
 
+import ctypes
 import itertools
 import os
 import weakref
@@ -181,7 +182,6 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
                 return _fps_bucket_one_per_launch(lib, pts, n, dim, n_lms, start_idx, index, out_idx, points)
         if method == "bucket" and (FPS_BATCHED or dim > 3):
             global LAST_FPS_LAUNCHES
-            import ctypes
             if index is None:
                 index = _recall_index(points)
                 if index is None:
@@ -203,11 +203,11 @@ def fps_indices(points: torch.Tensor, n_lms: int, start_idx: int = 0, method: Op
             launches = ctypes.c_int32(0)
             with torch.cuda.device(pts.device):
                 st = _native.current_stream_ptr(pts.device)
-                _native.check(lib.flooder_fps_batched_f32(
-                    _native.ptr(pts), n, dim, dim, _native.ptr(index.pts), _native.ptr(index.order32), n_lms,
-                    int(start_idx), _native.ptr(out_idx), _native.ptr(minsq), _native.ptr(box), _native.ptr(keys),
-                    _native.ptr(bcoord), _native.ptr(work_best), _native.ptr(rec), _native.ptr(work_ctr),
-                    ctypes.addressof(launches), st), "flooder_fps_batched_f32")
+                blk = _native.FpsBatched(pts=pts, n_pts=n, dim=dim, ld=dim, pts_sorted=index.pts, order=index.order32,
+                                         start=int(start_idx), n_lms=int(n_lms), out_idx=out_idx, minsq=minsq,
+                                         bucket_box=box, bucket_keys=keys, bucket_coord=bcoord, work_best=work_best,
+                                         work_rec=rec, work_ctr=work_ctr, launches_out=ctypes.addressof(launches))
+                _native.check(lib.flooder_fps_batched(ctypes.byref(blk), st), "flooder_fps_batched")
             LAST_FPS_LAUNCHES = int(launches.value)
             if FPS_KEEP_DIAG:
                 LAST_FPS_DIAG.update(ctr=work_ctr, rec=rec, blocks=rec.numel() // ((n_lms + 4) * (12 + max(dp, 4))),
@@ -1107,10 +1107,10 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
                                                            _native.ptr(keys), st), "flooder_sample_keys_late_f32")
             _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, 32, _native.ptr(keys_sorted), _native.ptr(order),
                                                  _native.ptr(tmp), tmp_bytes, st), "flooder_index_sort (samples)")
-            _native.check(lib.flooder_sweep_bvh_sorted_faces_f32(
-                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, R, S, _native.ptr(order), _native.ptr(queue), _native.ptr(plan.memb_all), F,
-                _native.ptr(face_bits), None, _native.ptr(stats), st), "flooder_sweep_bvh_sorted_faces_f32")
+            blk = _native.SortedSweep(pts_sorted=index.pts, n_pts=index.n, dim=index.dim, k1=k1, nodes=index.nodes, verts=verts,
+                                      weights=w_perm, R=R, n_faces=F, n_simplices=S, sample_order=order, queue=queue,
+                                      memb=plan.memb_all, face_bits=face_bits, stats=stats)
+            _native.check(lib.flooder_sorted_faces(ctypes.byref(blk), st), "flooder_sorted_faces")
         del keys, keys_sorted, tmp
         out_face = torch.empty((S, F), dtype=torch.float32, device=dev)
         with _span(timer, "face_max"):
@@ -1137,17 +1137,13 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
             _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, int(lib.flooder_sample_key_bits(index.dim)),
                                                  _native.ptr(keys_sorted), _native.ptr(order), _native.ptr(tmp),
                                                  tmp_bytes, st), "flooder_index_sort (samples)")
-            if tile_shard is not None:
-                # every rank sorts ALL samples (the same order everywhere) and takes a contiguous world-th of the tiles
-                _native.check(lib.flooder_sweep_bvh_sorted_shard_f32(
-                    _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                    _native.ptr(w_perm), k1, R, S, _native.ptr(order), int(tile_shard[0]), int(tile_shard[1]),
-                    _native.ptr(queue), _native.ptr(d2), _native.ptr(stats), st), "flooder_sweep_bvh_sorted_shard_f32")
-            else:
-                _native.check(lib.flooder_sweep_bvh_sorted_f32(
-                    _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                    _native.ptr(w_perm), k1, R, S, _native.ptr(order), _native.ptr(queue), _native.ptr(d2),
-                    _native.ptr(stats), st), "flooder_sweep_bvh_sorted_f32")
+            # (a tile shard: every rank sorts ALL samples - the same order everywhere - and takes a contiguous world-th of
+            # the tiles)
+            blk = _native.SortedSweep(pts_sorted=index.pts, n_pts=index.n, dim=index.dim, k1=k1, nodes=index.nodes, verts=verts,
+                                      weights=w_perm, R=R, n_simplices=S, sample_order=order, queue=queue, out_d2=d2,
+                                      stats=stats, shard_rank=0 if tile_shard is None else int(tile_shard[0]),
+                                      shard_world=0 if tile_shard is None else int(tile_shard[1]))
+            _native.check(lib.flooder_sorted_minima(ctypes.byref(blk), st), "flooder_sorted_minima")
             del keys, keys_sorted, tmp
         else:
             _native.check(lib.flooder_sweep_bvh_f32(
@@ -1270,37 +1266,31 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             wgt = torch.empty(S, dtype=torch.float32, device=dev)
             _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
                                                          k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
+        # ONE parameter block for the three launches (include/flooder_hip.h: flooder_fused_sweep_t): they share the cloud,
+        # the lattice, the result words and most of the scratch
+        wst = stats[16:40] if use_wit and stats is not None and stats.numel() >= 40 else None
+        blk = _native.FusedSweep(
+            pts_sorted=index.pts, n_pts=index.n, dim=index.dim, k1=k1, nodes=index.nodes, density_grid=index.dens,
+            cloud_box=index.box, verts=verts, weights=w_perm, R=R, n_faces=F, n_simplices=S, memb=plan.memb_all,
+            alpha=float(CELL_ALPHA), face_bits=face_bits, face_slot=slot_t, d2_scratch=d2, flag_list=flags[0],
+            flag_count=ctl[1:].data_ptr(), simplex_weight=wgt, plane_scratch=planes,
+            cell_queue=qbuf.data_ptr(), defer_list=defer_list, defer_c=defer_c, cell_stats=sub(0, 9),
+            finish_ctl=fctl.data_ptr(), hard_scratch=hard, hard_cap=FINISH_HARD_CAP, probed=1 if CELL_PROBE else 0,
+            finish_stats=sub(9, 16))
+        if CELL_PROBE:
+            blk.flag_key, blk.flag_hist, blk.flag_sorted = flags[1].data_ptr(), ctl[48:].data_ptr(), flags[2].data_ptr()
+            blk.top, blk.top_list, blk.top_count = top.data_ptr(), top_list.data_ptr(), fctl[3:].data_ptr()
+        if CELL_SUPER:
+            blk.defer_ctl, blk.light_list, blk.heavy_list = ctl[12:].data_ptr(), split[0].data_ptr(), split[1].data_ptr()
+        if use_wit:   # (split[0]: the witness sweep's item list - scratch until the cell sweep's entry fills it)
+            blk.n_coarse, blk.coarse_rows, blk.parents = plan.wit[2], plan.wit[0].data_ptr(), plan.wit[1].data_ptr()
+            blk.wit_queue, blk.wit_item_list, blk.wit_stats = qwit.data_ptr(), split[0].data_ptr(), _native.ptr(wst) or None
         with _span(timer, "sweep"):
             if use_wit:
-                wst = stats[16:40] if stats is not None and stats.numel() >= 40 else None
-                _native.check(lib.flooder_sweep_witness_f32(
-                    _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                    _native.ptr(w_perm), k1, R, S, _native.ptr(plan.wit[0]), plan.wit[2], _native.ptr(plan.wit[1]),
-                    qwit.data_ptr(), _native.ptr(d2), _native.ptr(plan.memb_all), F, _native.ptr(face_bits),
-                    _native.ptr(slot_t), _native.ptr(flags[0]), ctl[1:].data_ptr(), _native.ptr(flags[1]),
-                    ctl[48:].data_ptr(), _native.ptr(top), _native.ptr(top_list), fctl[3:].data_ptr(),
-                    _native.ptr(wgt), _native.ptr(split[0]), _native.ptr(planes), _native.ptr(wst), st),
-                    "flooder_sweep_witness_f32")   # (split[0]: scratch until the cell sweep's entry fills it)
-            _native.check(lib.flooder_sweep_cell_faces_f32(
-                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, R, S, float(CELL_ALPHA), qbuf.data_ptr(), _native.ptr(d2),
-                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(flags[0]),
-                ctl[1:].data_ptr(), _native.ptr(flags[1]) if CELL_PROBE else None,
-                ctl[48:].data_ptr() if CELL_PROBE else None, _native.ptr(top) if CELL_PROBE else None, _native.ptr(top_list) if CELL_PROBE else None,
-                fctl[3:].data_ptr() if CELL_PROBE else None, _native.ptr(defer_list), _native.ptr(defer_c),
-                ctl[12:].data_ptr() if CELL_SUPER else None, _native.ptr(wgt), _native.ptr(split[0]) if CELL_SUPER else None,
-                _native.ptr(split[1]) if CELL_SUPER else None, _native.ptr(planes), _native.ptr(index.dens),
-                _native.ptr(index.box), _native.ptr(sub(0, 9)), st),
-                "flooder_sweep_cell_faces_f32")
+                _native.check(lib.flooder_fused_witness(ctypes.byref(blk), st), "flooder_fused_witness")
+            _native.check(lib.flooder_fused_cell(ctypes.byref(blk), st), "flooder_fused_cell")
         with _span(timer, "fallback"):
-            _native.check(lib.flooder_finish_faces_f32(
-                _native.ptr(index.pts), index.n, index.dim, _native.ptr(index.nodes), _native.ptr(verts),
-                _native.ptr(w_perm), k1, R, S, _native.ptr(flags[0]), ctl[1:].data_ptr(),
-                _native.ptr(flags[1]) if CELL_PROBE else None, ctl[48:].data_ptr() if CELL_PROBE else None,
-                _native.ptr(flags[2]) if CELL_PROBE else None, fctl.data_ptr(),
-                _native.ptr(top), _native.ptr(top_list), 1 if CELL_PROBE else 0, _native.ptr(d2),
-                _native.ptr(plan.memb_all), F, _native.ptr(face_bits), _native.ptr(slot_t), _native.ptr(hard),
-                FINISH_HARD_CAP, _native.ptr(sub(9, 16)), st), "flooder_finish_faces_f32")
+            _native.check(lib.flooder_fused_finish(ctypes.byref(blk), st), "flooder_fused_finish")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)
             LAST_STATS.deferred_chunks = int(ctl[12].item())
             LAST_STATS.light_heavy = (int(ctl[14].item()), int(ctl[15].item()))

@@ -522,6 +522,131 @@ int flooder_fps_batched_f32(const float* pts, int64_t n_pts, int dim, int ld, co
                             float* bucket_box, uint64_t* bucket_keys, float* bucket_coord, uint64_t* work_best,
                             uint32_t* work_rec, int32_t* work_ctr, int32_t* launches_out, void* stream);
 
+/*
+ * ---- parameter blocks ----------------------------------------------------------------------------------------------
+ * The entry points of the DEFAULT path that take more than a dozen arguments also exist in a form that takes ONE
+ * struct: the three launches of the fused 2-D / 3-D sweep share almost all of their buffers (flooder_fused_sweep_t,
+ * filled once, passed three times), the sorted-sample sweep above 3-D and the batched landmark selection have a block
+ * each.  A maintainer binds a struct field by NAME (cgo / ctypes.Structure / JNA) - a transposed pointer in a run of
+ * thirty positional void* is a silently wrong answer, a misspelt field is a compile error.  Every block opens with
+ * `size` (sizeof of the struct as the caller compiled it) and `abi` (FLOODER_PARAMS_ABI): a library that knows a longer
+ * struct reads the fields the caller has and takes the documented default (NULL / 0) for the rest; a caller newer than
+ * the library is refused (FLOODER_E_ARG).  Pointers are device pointers unless said otherwise; what every field
+ * means, and which may be NULL, is documented at the positional function it is forwarded to - those stay exported as
+ * they were (same symbols, same behaviour; flooder_amd's own default path no longer calls them).
+ */
+#define FLOODER_PARAMS_ABI 1
+
+typedef struct flooder_fused_sweep_s {
+  uint32_t size, abi;
+  /* the cloud and its index (flooder_index_rows_f32 / flooder_bvh_build_f32 / flooder_density_grid_f32) */
+  const float* pts_sorted;
+  int64_t n_pts;
+  int32_t dim;
+  int32_t k1;                 /* vertices per simplex */
+  const float* nodes;
+  const int32_t* density_grid;
+  const float* cloud_box;
+  /* simplices and sample lattice */
+  const float* verts;
+  const float* weights;
+  int32_t R;
+  int32_t n_faces;
+  int64_t n_simplices;
+  const uint32_t* memb;
+  float alpha;
+  int32_t n_coarse;           /* witness plan: flooder_sweep_witness_f32 */
+  const int32_t* coarse_rows;
+  const uint32_t* parents;
+  /* result */
+  uint32_t* face_bits;
+  const int32_t* face_slot;
+  /* scratch shared by the three launches */
+  uint32_t* d2_scratch;
+  int32_t* flag_list;
+  int32_t* flag_count;
+  uint32_t* flag_key;
+  int32_t* flag_hist;
+  int32_t* flag_sorted;
+  uint64_t* top;
+  int32_t* top_list;
+  int32_t* top_count;
+  float* simplex_weight;
+  float* plane_scratch;
+  /* witness sweep */
+  int32_t* wit_queue;
+  int32_t* wit_item_list;
+  uint64_t* wit_stats;
+  /* cell sweep */
+  int32_t* cell_queue;
+  int32_t* defer_list;
+  float* defer_c;
+  int32_t* defer_ctl;
+  int32_t* light_list;
+  int32_t* heavy_list;
+  uint64_t* cell_stats;
+  /* finish */
+  int32_t* finish_ctl;
+  uint64_t* hard_scratch;
+  int32_t hard_cap;
+  int32_t probed;
+  uint64_t* finish_stats;
+} flooder_fused_sweep_t;
+
+/* flooder_sweep_witness_f32, flooder_sweep_cell_faces_f32, flooder_finish_faces_f32 on the fields of *p (host memory;
+ * read during the call only). */
+int flooder_fused_witness(const flooder_fused_sweep_t* p, void* stream);
+int flooder_fused_cell(const flooder_fused_sweep_t* p, void* stream);
+int flooder_fused_finish(const flooder_fused_sweep_t* p, void* stream);
+
+typedef struct flooder_sorted_sweep_s {   /* flooder_sweep_bvh_sorted_faces_f32 / _sorted_f32 / _sorted_shard_f32 */
+  uint32_t size, abi;
+  const float* pts_sorted;
+  int64_t n_pts;
+  int32_t dim;
+  int32_t k1;
+  const float* nodes;
+  const float* verts;
+  const float* weights;
+  int32_t R;
+  int32_t n_faces;
+  int64_t n_simplices;
+  const int32_t* sample_order;
+  int32_t* queue;
+  const uint32_t* memb;
+  uint32_t* face_bits;
+  const int32_t* face_slot;
+  uint64_t* stats;
+  uint32_t* out_d2;           /* flooder_sorted_minima only: the (S, R) minima */
+  int32_t shard_rank;         /* flooder_sorted_minima: this rank's run of the tiles when shard_world > 1 */
+  int32_t shard_world;        /* 0 or 1: all tiles */
+} flooder_sorted_sweep_t;
+int flooder_sorted_faces(const flooder_sorted_sweep_t* p, void* stream);    /* fused with the face maxima */
+int flooder_sorted_minima(const flooder_sorted_sweep_t* p, void* stream);   /* minima into out_d2 (all tiles / a shard) */
+
+typedef struct flooder_fps_batched_s {    /* flooder_fps_batched_f32 */
+  uint32_t size, abi;
+  const float* pts;
+  int64_t n_pts;
+  int32_t dim;
+  int32_t ld;
+  const float* pts_sorted;
+  const int32_t* order;
+  int64_t start;
+  int32_t n_lms;
+  int32_t reserved;
+  int64_t* out_idx;
+  float* minsq;
+  float* bucket_box;
+  uint64_t* bucket_keys;
+  float* bucket_coord;
+  uint64_t* work_best;
+  uint32_t* work_rec;
+  int32_t* work_ctr;
+  int32_t* launches_out;      /* host */
+} flooder_fps_batched_t;
+int flooder_fps_batched(const flooder_fps_batched_t* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

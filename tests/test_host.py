@@ -1,5 +1,6 @@
 """Host logic of flooder_amd on CPU: API surface, error behaviour, the CPU branch against the
 reference's golden outputs, the simplex tree, and the C-ABI library's symbols."""
+import ctypes
 import os
 import re
 
@@ -126,9 +127,54 @@ def test_native_library_loads_and_exports_header_symbols():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert declared == set(_native.SIGNATURES), "ctypes binding and header disagree"
+    assert declared == set(_native.SIGNATURES) | set(_native.POSITIONAL_SIGNATURES), "ctypes binding and header disagree"
+    # what flooder_amd itself calls takes at most a dozen arguments on the default path (2-D / 3-D fused sweep, the
+    # sorted-sample sweep above 3-D, the batched landmark selection: parameter blocks bound by field name); the longer
+    # positional signatures left in SIGNATURES belong to method="ball", mode="blocks", the unfused sweeps and the
+    # one-per-launch selection
+    long_ones = {k for k, (_, a) in _native.SIGNATURES.items() if len(a) > 12}
+    assert long_ones == {"flooder_ball_fill_f32", "flooder_sweep_f32", "flooder_box_select_f32", "flooder_sweep_bvh_f32",
+                         "flooder_sweep_bvh_items_f32", "flooder_sweep_cell_f32", "flooder_fps_indexed_f32"}
     assert lib.flooder_abi_version() == 1
     assert [lib.flooder_padded_dim(d) for d in (1, 2, 3, 4, 5, 8)] == [2, 2, 4, 4, 8, 8]
+
+
+def test_parameter_blocks_have_the_layout_of_the_header(tmp_path):
+    """The ctypes Structures of ``_native`` against the C structs of include/flooder_hip.h: same size, every field at
+    the same offset (compiled with the host C compiler; a maintainer's cgo / JNA binding is checked the same way)."""
+    import shutil
+    import subprocess
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    blocks = {"flooder_fused_sweep_t": _native.FusedSweep, "flooder_sorted_sweep_t": _native.SortedSweep,
+              "flooder_fps_batched_t": _native.FpsBatched}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "flooder_hip.h")}"',
+             'int main(void) {']
+    for cname, cls in blocks.items():
+        lines.append(f'printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        if not line:
+            continue
+        cname, what, val = line.split()
+        cls = blocks[cname]
+        assert int(val) == (ctypes.sizeof(cls) if what == "sizeof" else getattr(cls, what).offset), line
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in blocks.values())
+    blk = _native.FusedSweep(n_pts=5, alpha=0.5)
+    assert blk.size == ctypes.sizeof(_native.FusedSweep) and blk.abi == 1 and blk.n_pts == 5 and not blk.top
+    with pytest.raises(TypeError):
+        _native.FusedSweep(no_such_field=1)
 
 
 def test_host_libraries_export_header_symbols():
