@@ -224,3 +224,43 @@ extern "C" int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k
   });
   return changed.load();
 }
+
+// Row of `table` (m x k int64, ascending ids per row, rows in lexicographic order) that equals each query row
+// (n x k, ascending ids), -1 if there is none: binary search on packed keys, on all cores.  What numpy's searchsorted
+// does on one thread for the three million (triangle, edge) pairs of cfg 4's hand-off (core.py:258-263: the dict
+// update by simplex tuple).  Returns 0, or a code below -(1 << 40) (keys that do not fit 62 bits).
+extern "C" int64_t flooder_locate_rows(const int64_t* query, int64_t n, int k, const int64_t* table, int64_t m,
+                                       int64_t n_points, int64_t* out, int n_threads) {
+  if (!query || !table || !out || n < 0 || m < 0 || k < 1 || k > 16 || n_points < 1) return E_FEW;
+  {
+    long double bits = 0;
+    for (int i = 0; i < k; ++i) bits += std::log2((long double)n_points);
+    if (bits >= 62.0L) return E_RANGE;
+  }
+  const uint64_t base = (uint64_t)n_points;
+  Pool pool((n + m) * k < (1 << 17) ? 1 : host_threads(n_threads));
+  std::vector<uint64_t> keys((size_t)m);
+  auto pack = [&](const int64_t* r) {
+    uint64_t key = 0;
+    for (int j = 0; j < k; ++j) key = key * base + (uint64_t)r[j];
+    return key;
+  };
+  pool.parallel_for(m, 1 << 14, [&](int64_t a, int64_t b, int) {
+    for (int64_t i = a; i < b; ++i) keys[(size_t)i] = pack(table + i * k);
+  });
+  pool.parallel_for(n, 1 << 13, [&](int64_t a, int64_t b, int) {
+    for (int64_t i = a; i < b; ++i) {
+      const int64_t* r = query + i * k;
+      bool in_range = true;
+      for (int j = 0; j < k; ++j) in_range &= r[j] >= 0 && r[j] < n_points;
+      int64_t at = -1;
+      if (in_range) {
+        const uint64_t key = pack(r);
+        const uint64_t* it = std::lower_bound(keys.data(), keys.data() + m, key);
+        if (it != keys.data() + m && *it == key) at = it - keys.data();
+      }
+      out[i] = at;
+    }
+  });
+  return 0;
+}

@@ -181,6 +181,9 @@ def _load_host():
             lib.flooder_delaunay_nd_stat.argtypes = [ctypes.c_int]
             lib.flooder_widen_i32.restype = None
             lib.flooder_widen_i32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+            lib.flooder_locate_rows.restype = ctypes.c_int64
+            lib.flooder_locate_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
             lib.flooder_raise_dimension.restype = ctypes.c_int64
             lib.flooder_raise_dimension.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -253,6 +256,7 @@ def _delaunay_nd(pts: np.ndarray) -> Optional[np.ndarray]:
 _delaunay3d_native = _delaunay_native   # (name of the round-5 3-D entry point, kept for tools and tests)
 
 _C32_CACHE: list = [None, None]
+NATIVE_LOCATE_MIN = 500_000    # query entries from which SimplexTree._locate runs in flooder_locate_rows
 NATIVE_RAISE_MIN = 1_000_000   # facets (rows x (d + 1)) from which the monotone pass runs in flooder_raise_dimension
 NATIVE_FACES_MIN = 2_000_000   # faces (cells x combinations) from which the table is enumerated by flooder_cell_faces
 
@@ -443,6 +447,16 @@ class SimplexTree:
         query = np.asarray(query, dtype=np.int64).reshape(-1, d + 1)
         if table is None or table.shape[0] == 0 or query.shape[0] == 0:
             return np.full(query.shape[0], -1, dtype=np.int64)
+        if query.shape[0] * (d + 1) >= NATIVE_LOCATE_MIN and NATIVE_DELAUNAY:
+            lib = _load_host()        # binary search on packed keys, all host cores (csrc/cell_faces.cpp)
+            if lib is not None:
+                q64 = np.ascontiguousarray(query, dtype=np.int64)
+                t64 = np.ascontiguousarray(table, dtype=np.int64)
+                out = np.empty(q64.shape[0], dtype=np.int64)
+                n_pts = max(self._n_points, int(t64[:, -1].max()) + 1)   # (ascending rows: the last column holds the maxima)
+                if int(lib.flooder_locate_rows(q64.ctypes.data, q64.shape[0], d + 1, t64.ctypes.data, t64.shape[0], n_pts,
+                                               out.ctypes.data, _host_threads())) == 0:
+                    return out
         base = int(max(table.max(), query.max())) + 1
         if base ** (d + 1) < 2 ** 62:
             mult = base ** np.arange(d, -1, -1, dtype=np.int64)

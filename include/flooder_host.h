@@ -84,6 +84,14 @@ int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int
 int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k, const int64_t* lower_rows, int64_t n_lo,
                                 const double* lower_vals, double* vals, int64_t n_points, int n_threads);
 
+/*
+ * out[i] = the row of `table` (m x k int64, ascending ids, lexicographic order) equal to query row i (n x k), or -1:
+ * binary search on packed keys on all host cores - the hand-off's lookup of simplices by their vertex tuple
+ * (core.py:258-263, 278-280).  0, or a code below -(1 << 40) when n_points^k >= 2^62 (numpy path then).
+ */
+int64_t flooder_locate_rows(const int64_t* query, int64_t n, int k, const int64_t* table, int64_t m, int64_t n_points,
+                            int64_t* out, int n_threads);
+
 /* count int32 values widened into a caller-owned int64 array, on all cores (numpy's index dtype). */
 void flooder_widen_i32(const int32_t* src, int64_t count, int64_t* dst, int n_threads);
 

@@ -206,6 +206,24 @@ def test_face_table_declines_keys_that_do_not_fit():
     lib.flooder_host_free(out)
 
 
+def test_parallel_row_lookup_equals_numpy(monkeypatch):
+    """flooder_locate_rows against the searchsorted path of SimplexTree._locate: present rows, absent rows, ids outside
+    the table's range."""
+    rng = np.random.default_rng(4)
+    cells = qhull(rng.normal(size=(150, 4)))
+    st = stm.SimplexTree.from_cells(cells, 150)
+    for d in (1, 2, 4):
+        rows = st.simplices_of_dimension(d)
+        q = np.concatenate([rows[rng.permutation(len(rows))[:400]],
+                            np.sort(rng.integers(0, 150, size=(300, d + 1)), axis=1),
+                            np.sort(rng.integers(140, 170, size=(20, d + 1)), axis=1)])
+        monkeypatch.setattr(stm, "NATIVE_LOCATE_MIN", 10 ** 15)
+        want = st._locate(d, q)
+        monkeypatch.setattr(stm, "NATIVE_LOCATE_MIN", 1)
+        got = st._locate(d, q)
+        assert np.array_equal(got, want) and (got[:400] >= 0).all() and (got < 0).any()
+
+
 def test_parallel_monotone_pass_equals_numpy(monkeypatch):
     """flooder_raise_dimension (one step of make_filtration_non_decreasing on all cores) against the numpy pass: NaN own
     values take the facets' maximum, NaN facet values do not take part, values already above their facets stay."""

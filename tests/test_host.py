@@ -188,7 +188,7 @@ def test_host_libraries_export_header_symbols():
     declared = set(re.findall(r"\b(flooder_[a-z0-9_]+)\s*\(", header))
     assert declared == {"flooder_delaunay3d", "flooder_delaunay2d", "flooder_delaunay3d_local_edges", "flooder_persistence_z2",
                         "flooder_filtration_order", "flooder_dict_update", "flooder_delaunay_nd", "flooder_host_free",
-                        "flooder_delaunay_nd_stat", "flooder_delaunay_nd_isa", "flooder_cell_faces", "flooder_widen_i32", "flooder_raise_dimension"}
+                        "flooder_delaunay_nd_stat", "flooder_delaunay_nd_isa", "flooder_cell_faces", "flooder_widen_i32", "flooder_raise_dimension", "flooder_locate_rows"}
     build.build_host()
     host = ctypes.CDLL(build.HOST_LIB)
     assert all(hasattr(host, f) for f in declared - {"flooder_dict_update"})
