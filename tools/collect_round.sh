@@ -6,7 +6,7 @@
 # landmark-selection times, the reference's end-to-end protocol.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
-TAG=${1:-r5}
+TAG=${1:-r6}
 bash tools/gpu_session.sh final_$TAG test bench bench3 bench5 bench4 prof:cfg2 prof:cfg3 prof:cfg5 prof:cfg4 emul:cfg2 emul:cfg3 emul:cfg5 emul:cfg4 tfps
 OUT=$R/gpurun_out/final_$TAG
 cp $OUT/pytest_gpu.txt $OUT/profiles/${TAG}_pytest_gpu.txt
