@@ -12,6 +12,7 @@
 #include "host_parallel.hpp"
 
 #include <cstdlib>
+#include <exception>
 #include <memory>
 
 namespace {
@@ -35,7 +36,7 @@ std::vector<std::vector<int>> combos(int w, int k) {
 }  // namespace
 
 extern "C" int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int k, int64_t n_points,
-                                      int n_threads, int32_t** out_rows) {
+                                      int n_threads, int32_t** out_rows) try {
   if (!cells || !out_rows || n_cells < 0 || width < 1 || width > 16 || k < 1 || k > width || n_points < 1) return E_FEW;
   *out_rows = nullptr;
   // keys: the face's vertex ids as digits to the base n_points, first vertex most significant
@@ -162,6 +163,8 @@ extern "C" int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int
   });
   *out_rows = out;
   return nd;
+} catch (const std::exception&) {   // (out of memory: nothing may cross the C ABI)
+  return E_FEW;
 }
 
 // int32 rows widened into a caller-owned int64 array on all cores (the tables above are handed over as int32; numpy

@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <functional>
 #include <cstdlib>
+#include <exception>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -917,6 +918,7 @@ extern "C" int64_t flooder_delaunay_nd(const double* pts, int64_t n, int dim, in
   *out_cells = nullptr;
   if (dim < 2 || dim > 8) return E_DIM;
   if (n < dim + 2 || n > 0x3fffffff) return E_FEW;
+  try {
   switch (dim) {
     case 2: return delaunay_nd<2>(pts, n, n_threads, out_cells);
     case 3: return delaunay_nd<3>(pts, n, n_threads, out_cells);
@@ -925,6 +927,9 @@ extern "C" int64_t flooder_delaunay_nd(const double* pts, int64_t n, int dim, in
     case 6: return delaunay_nd<6>(pts, n, n_threads, out_cells);
     case 7: return delaunay_nd<7>(pts, n, n_threads, out_cells);
     default: return delaunay_nd<8>(pts, n, n_threads, out_cells);
+  }
+  } catch (const std::exception&) {   // (out of memory: a complex too large for this host - nothing may cross the C ABI)
+    return E_TOO_MANY;
   }
 }
 
