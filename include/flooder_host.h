@@ -68,8 +68,8 @@ int flooder_delaunay_nd_isa(int isa);
  * 51 million keys for the triangles of the 6-D complex of BASELINE cfg 4).
  *   cells: n_cells x width int32, ascending vertex ids < n_points per row (host).  *out_rows: malloc'ed (count, k) int32,
  *   ascending ids per row, rows in lexicographic order - release with flooder_host_free.
- *   returns the number of distinct faces, or a code below -(1 << 40): bad arguments, or n_points^k >= 2^62 (the packed
- *   keys would not fit: the caller enumerates with numpy then).
+ *   returns the number of distinct faces, or a code below -(1 << 40): bad arguments, or n_points^k >= 2^126 (the packed
+ *   keys fit neither 64 nor 128 bits: the caller enumerates with numpy then).
  */
 int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int k, int64_t n_points, int n_threads,
                            int32_t** out_rows);
@@ -79,7 +79,7 @@ int64_t flooder_cell_faces(const int32_t* cells, int64_t n_cells, int width, int
  * dimension-d table (rows: n x k int64, k = d + 1, ascending ids) raised to the maxima of their facets, which are
  * located in the sorted dimension-(d-1) table (lower_rows: n_lo x (k-1), lexicographic order; lower_vals).  NaN facet
  * values do not take part; a NaN own value becomes the facets' maximum.  Returns the number of rows changed, or a code
- * below -(1 << 40) (n_points^(k-1) >= 2^62: the caller runs the numpy pass).
+ * below -(1 << 40) (n_points^(k-1) >= 2^126: the caller runs the numpy pass).
  */
 int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k, const int64_t* lower_rows, int64_t n_lo,
                                 const double* lower_vals, double* vals, int64_t n_points, int n_threads);
@@ -87,7 +87,7 @@ int64_t flooder_raise_dimension(const int64_t* rows, int64_t n, int k, const int
 /*
  * out[i] = the row of `table` (m x k int64, ascending ids, lexicographic order) equal to query row i (n x k), or -1:
  * binary search on packed keys on all host cores - the hand-off's lookup of simplices by their vertex tuple
- * (core.py:258-263, 278-280).  0, or a code below -(1 << 40) when n_points^k >= 2^62 (numpy path then).
+ * (core.py:258-263, 278-280).  0, or a code below -(1 << 40) when n_points^k >= 2^126 (numpy path then).
  */
 int64_t flooder_locate_rows(const int64_t* query, int64_t n, int k, const int64_t* table, int64_t m, int64_t n_points,
                             int64_t* out, int n_threads);

@@ -196,11 +196,48 @@ def test_parallel_face_table_equals_numpy(dim, n, k, monkeypatch):
     assert got.tolist() == [list(map(int, r)) for r in brute]
 
 
+def test_wide_keys_give_the_same_tables():
+    """Where n_points^k >= 2^62 (the 6- and 7-vertex faces of a 6-D complex over 2000 landmarks) the packed keys are 128
+    bits wide: written out, sorted, made distinct; lookups and the monotone pass search them the same way.  Forced here
+    by passing a large base for a small complex: the tables must not depend on it."""
+    lib = host()
+    rng = np.random.default_rng(12)
+    cells = qhull(rng.normal(size=(90, 5)))
+    for k in (3, 5, 6):
+        narrow = stm._faces_native(cells, k - 1, 90)
+        wide = stm._faces_native(cells, k - 1, 1 << 20)                # 60 / 100 / 120 bits: wide keys from k = 5
+        assert narrow is not None and wide is not None and np.array_equal(narrow, wide)
+    table = stm._faces_native(cells, 3, 90)
+    lower = stm._faces_native(cells, 2, 90)
+    q = np.concatenate([table[::3], np.sort(rng.integers(0, 90, size=(200, 4)), axis=1)])
+    out = {}
+    for base in (90, 1 << 24):
+        o = np.empty(len(q), dtype=np.int64)
+        assert lib.flooder_locate_rows(q.ctypes.data, len(q), 4, table.ctypes.data, len(table), base, o.ctypes.data, 2) == 0
+        out[base] = o
+    assert np.array_equal(out[90], out[1 << 24]) and (out[90][: len(table[::3])] >= 0).all()
+    lv = rng.random(len(lower))
+    lv[::7] = np.nan
+    res = {}
+    for base in (90, 1 << 24):
+        v = rng.random(len(table)) * 0.5
+        v[::5] = np.nan
+        v0 = np.random.default_rng(1).random(len(table)) * 0.5
+        v0[::5] = np.nan
+        rc = lib.flooder_raise_dimension(table.ctypes.data, len(table), 4, lower.ctypes.data, len(lower), lv.ctypes.data,
+                                         v0.ctypes.data, base, 2)
+        assert rc > 0
+        res[base] = v0
+    assert np.array_equal(res[90], res[1 << 24], equal_nan=True)
+
+
 def test_face_table_declines_keys_that_do_not_fit():
     lib = host()
     cells = np.array([[0, 1, 2, 3, 4, 5, 6]], dtype=np.int32)
     out = ctypes.POINTER(ctypes.c_int32)()
-    assert lib.flooder_cell_faces(cells.ctypes.data, 1, 7, 7, 1 << 20, 1, ctypes.byref(out)) < E_BASE   # (2^20)^7 keys
+    assert lib.flooder_cell_faces(cells.ctypes.data, 1, 7, 7, 1 << 20, 1, ctypes.byref(out)) < E_BASE   # (2^20)^7: 140 bits
+    assert lib.flooder_cell_faces(cells.ctypes.data, 1, 7, 7, 1 << 17, 1, ctypes.byref(out)) == 1      # 119 bits: wide keys
+    lib.flooder_host_free(out)
     rc = lib.flooder_cell_faces(cells.ctypes.data, 1, 7, 3, 7, 1, ctypes.byref(out))
     assert rc == 35
     lib.flooder_host_free(out)
