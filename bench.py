@@ -112,6 +112,8 @@ def parse_args():
     ap.add_argument("--shard", default="simplices", choices=["simplices", "points", "blocks"],
                     help="multi-GPU decomposition: simplices (full cloud per rank, every W-th simplex; default) "
                          "or points (interleaved rows of the cloud, all_reduce(MIN) on the (S,R) minima)")
+    ap.add_argument("--deal", default=None, choices=["size", "stride"],
+                    help="--shard simplices: how the queue is cut (core.simplex_share; default core.SHARD_DEAL)")
     ap.add_argument("--emulate-shard", default=None, metavar="r/W",
                     help="diagnostic (N=1 only): time rank r's share of a W-rank simplex-sharded step, no collective")
     ap.add_argument("--alpha", type=float, default=None, help="cell size of the cell sweep in units of the local spacing")
@@ -387,13 +389,13 @@ def main():
         if args.shard == "blocks":   # contiguous block of the axis-ordered queue; index over the block's sub-cloud only
             mine = torch.arange(S_all * rank // world, S_all * (rank + 1) // world, device=dev) if world > 1 else None
         else:
-            mine = torch.arange(rank, S_all, world, device=dev) if world > 1 else None
+            mine = torch.as_tensor(core.simplex_share(verts, rank, world, args.deal), device=dev) if world > 1 else None
         hook = None
     face_hook = min_reduce_hook() if (world > 1 and mine is not None) else None
     if args.emulate_shard and world == 1:
         er, ew = (int(v) for v in args.emulate_shard.split("/"))
         mine = (torch.arange(S_all * er // ew, S_all * (er + 1) // ew, device=dev) if args.shard == "blocks"
-                else torch.arange(er, S_all, ew, device=dev))
+                else torch.as_tensor(core.simplex_share(verts, er, ew, args.deal), device=dev))
         face_hook = lambda t: t  # noqa: E731  (the 360 KB all_reduce is not emulated)
     # a simplex-sharded run through the sorted-sample sweep (above 3D) shards the TILES of the sorted order instead
     # (core.shards_sorted_tiles): every rank keeps all simplices and combines its partial face maxima with MAX

@@ -769,6 +769,30 @@ def block_subcloud(points32: torch.Tensor, verts: torch.Tensor, d: int, box: Opt
     return out[:int(count.item())]
 
 
+SHARD_DEAL = "size"   # how mode="simplices" cuts the queue: "size" (largest simplices first, dealt round-robin), "stride"
+
+
+def simplex_share(verts, rank: int, world: int, deal: Optional[str] = None) -> np.ndarray:
+    """Rows of the simplex queue (``verts``: (S, k1, dim) vertex coordinates in queue order, array or tensor) that rank
+    ``rank`` of ``world`` sweeps, ascending.  ``"stride"``: every ``world``-th row (round 5).  ``"size"`` (default): the
+    simplices sorted by the squared diagonal of their bounding box, largest first, and dealt round-robin - the work of
+    a simplex is heavy-tailed and its tail are the LARGE simplices (they span the voids of the cloud: their samples lie
+    far from every point, their tiles are the finish's long searches), so each rank gets its share of them instead of
+    what the stride happens to hit.  Computed from the landmark coordinates alone, in float64 with a stable sort:
+    the same on every rank; any partition gives the same values."""
+    deal = SHARD_DEAL if deal is None else deal
+    n = int(verts.shape[0])
+    if deal == "stride" or world <= 1 or n == 0:
+        return np.arange(rank, n, max(world, 1), dtype=np.int64)
+    if deal != "size":
+        raise ValueError("deal must be 'size' or 'stride'")
+    v = verts.detach().cpu().numpy() if isinstance(verts, torch.Tensor) else np.asarray(verts)
+    v = v.astype(np.float64, copy=False)
+    key = ((v.max(axis=1) - v.min(axis=1)) ** 2).sum(axis=1)
+    order = np.argsort(-key, kind="stable")
+    return np.sort(order[rank::world]).astype(np.int64)
+
+
 def shared_face_slots(stree, d: int, order_np: np.ndarray, v_idx_np: List[np.ndarray], device):
     """Slots of the fused face maxima with ONE word per distinct face of the complex: for the top cells of a
     ``SimplexTree.from_cells`` complex (in the order ``order_np`` of the sweep) and the face numbering of
@@ -1583,7 +1607,7 @@ def flood_complex(
                 mine = None          # all simplices, a contiguous run of the TILES of the sorted sample order
                 tile_shard = (sh_rank, sh_world)
             else:
-                mine = torch.arange(sh_rank, num_simplices, sh_world, device=device)
+                mine = torch.as_tensor(simplex_share(simplex_vertices, sh_rank, sh_world), device=device)
         else:
             mine = None
         sv = simplex_vertices if mine is None else simplex_vertices[mine]
