@@ -769,12 +769,12 @@ def block_subcloud(points32: torch.Tensor, verts: torch.Tensor, d: int, box: Opt
     return out[:int(count.item())]
 
 
-SHARD_DEAL = "size"   # how mode="simplices" cuts the queue: "size" (largest simplices first, dealt round-robin), "stride"
+SHARD_DEAL = "stride"   # how mode="simplices" cuts the queue: "stride" (every world-th row), "size" (largest simplices first, dealt round-robin: measured, round 6 - an eighth of cfg 3 1.48 -> 1.42 ms, of cfg 5 2.97 -> 2.93, of cfg 2 0.59 -> 0.62: the slow rank is the one that holds THE hardest tile, whichever deal hands it over)
 
 
 def simplex_share(verts, rank: int, world: int, deal: Optional[str] = None) -> np.ndarray:
     """Rows of the simplex queue (``verts``: (S, k1, dim) vertex coordinates in queue order, array or tensor) that rank
-    ``rank`` of ``world`` sweeps, ascending.  ``"stride"``: every ``world``-th row (round 5).  ``"size"`` (default): the
+    ``rank`` of ``world`` sweeps, ascending.  ``"stride"`` (default): every ``world``-th row.  ``"size"``: the
     simplices sorted by the squared diagonal of their bounding box, largest first, and dealt round-robin - the work of
     a simplex is heavy-tailed and its tail are the LARGE simplices (they span the voids of the cloud: their samples lie
     far from every point, their tiles are the finish's long searches), so each rank gets its share of them instead of
