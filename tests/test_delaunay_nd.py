@@ -142,6 +142,18 @@ def test_exact_stage_is_reached_and_decides_like_qhull():
     assert total > 0, "no case reached the exact predicates"
 
 
+def test_large_low_dimensional_inputs_go_to_qhull(monkeypatch):
+    """The scan per pivot is O(n): above ``ND_MAX_POINTS[dim]`` points (2 - 5 dimensions) Qhull's n log n wins and is
+    asked instead."""
+    rng = np.random.default_rng(3)
+    P = rng.normal(size=(300, 4))
+    monkeypatch.setitem(stm.ND_MAX_POINTS, 4, 100)
+    cells = stm.delaunay_cells(P)
+    assert not stm.LAST_DELAUNAY["native"] and np.array_equal(cells, qhull(P))
+    monkeypatch.setitem(stm.ND_MAX_POINTS, 4, 1000)
+    assert np.array_equal(stm.delaunay_cells(P), cells) and stm.LAST_DELAUNAY["native"]
+
+
 def test_declines_what_it_cannot_triangulate_and_delaunay_cells_falls_back():
     rng = np.random.default_rng(2)
     P = rng.normal(size=(100, 4))
