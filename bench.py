@@ -655,7 +655,11 @@ def main():
                             "points_staged": wit[4], "coarse_certified": wit[5], "samples_live_after_bound": wit[6],
                             "rounds": wit[7], "samples_open_after_stage": wit[8], "tiles_flagged": wit[9],
                             "pairs_stage": wit[10], "pairs_bound": 4 * wit[0] * R, "focus_rounds": wit[22],
-                            "focus_gather_overflow": wit[23], "enabled": bool(core.CELL_WITNESS)},
+                            "focus_gather_overflow": wit[23],
+                            "enabled": bool(core.CELL_WITNESS and S >= core.WIT_MIN_SIMPLICES
+                                            and w["n"] <= core.WIT_MAX_POINTS_PER_SIMPLEX * S),
+                            "enabled_note": "off on queues shorter than core.WIT_MIN_SIMPLICES and on clouds with more than "
+                                            "core.WIT_MAX_POINTS_PER_SIMPLEX points per simplex (cfg 5: it would handle none)"},
                 "cell_pairs": sh[0], "points_staged": sh[1], "tiles_flagged": sh[2],
                 "restage_rounds": sh[3], "tiles_total": tiles_total,
                 "chunks_total": S * ((R + 255) // 256),

@@ -1206,6 +1206,12 @@ FINISH_HARD_CAP = 32768  # entries per hard list of the finish (a tile that does
 CELL_DENSITY_GRID = True   # PointIndex carries a density grid; the cell sweep reads its first cell size from it
 CELL_SUPER = True    # runs of four chunks share one gather / classification / stage (two launches: runs, deferred chunks)
 WIT_MIN_SIMPLICES = 1536   # fewer simplices than this in a sweep: no witness sweep (1024 persistent workgroups, one simplex each)
+# ... and none on a cloud with more than this many points per simplex: the witness sweep takes simplices with at most
+# "wit_weight" (800) points in their bounding box - about six times the simplex's own share - and at 634 points per
+# simplex (cfg 5) it finds 2000 candidates among 25 000, abandons every one after the gather (too dense for one stage)
+# and costs 148 us + 43 us for its item list: 2.2 % of the step for nothing (cfg 2: 165 points per simplex, 4327 of
+# 6052 handled; cfg 3: 181).  Results do not depend on it (witness on / off: bit-identical, tested).
+WIT_MAX_POINTS_PER_SIMPLEX = 400
 CELL_WITNESS = True  # sparse simplices go to the witness sweep first (whole simplex per wave, coarse samples + bounds)
 
 
@@ -1264,7 +1270,7 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # launch then lasts as long as its longest item, 250 - 300 us, where the cell sweep balances chunk by chunk;
         # measured on an eighth of cfg 2: 0.65 ms per rank with it, 0.55 without)
         use_wit = (CELL_WITNESS and CELL_SUPER and CELL_PROBE and index.dim in (2, 3) and S >= WIT_MIN_SIMPLICES
-                   and plan.wit is not None)
+                   and index.n <= WIT_MAX_POINTS_PER_SIMPLEX * S and plan.wit is not None)
         zeroed = torch.zeros((1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots,
                              dtype=torch.int32, device=dev)
         if use_wit:

@@ -23,10 +23,11 @@ def dev():
 
 @pytest.fixture(autouse=True)
 def restore_options():
-    keep = core.WIT_MIN_SIMPLICES
+    keep = core.WIT_MIN_SIMPLICES, core.WIT_MAX_POINTS_PER_SIMPLEX
     core.WIT_MIN_SIMPLICES = 0    # (the product skips the witness sweep on short queues: the tests here want it run)
+    core.WIT_MAX_POINTS_PER_SIMPLEX = 1 << 40   # (... and on clouds with many points per simplex)
     yield
-    core.WIT_MIN_SIMPLICES = keep
+    core.WIT_MIN_SIMPLICES, core.WIT_MAX_POINTS_PER_SIMPLEX = keep
     lib = _native.load()
     for k, v in WIT_DEFAULTS.items():
         assert lib.flooder_set_option(k.encode(), v) == 0
