@@ -1420,7 +1420,12 @@ def flood_complex(
     reference's CPU path.  ``index`` (keyword-only): a ``PointIndex`` built from these very ``points`` (ROCm
     tensors, methods ``"cell"``/``"bvh"``) - the curve-sorted copy and box tree are reused instead of rebuilt
     (callers that sweep one cloud several times, and every rank of a multi-GPU run; the caller vouches that
-    ``points`` has not changed since: only the shape is checked).  ``simplex_shard=(rank, world)`` sweeps this rank's
+    ``points`` has not changed since: the shape is checked, and an in-place write that moved torch's version counter is
+    refused).  The handle comes from ``generate_landmarks(points, n, return_index=True)``; with integer ``landmarks``
+    the function builds one index for the selection and the sweep itself.  No index is remembered between calls
+    unless ``core.INDEX_CACHE`` (FLOODER_INDEX_CACHE=1) is switched on - and then by tensor identity and version
+    counter only, which does NOT see writes through ``.data``, raw-pointer kernels or DLPack / cupy aliases: with the
+    cache on, such a write before the next call sweeps a stale copy of the cloud.  ``simplex_shard=(rank, world)`` sweeps this rank's
     share of the simplices only (the other rows of the (S, F) values are +inf until ``face_reduce_hook`` combines
     them; on the default cell-sweep path the ranks share ONE word per distinct face of the complex as a single GPU
     does, and what ``face_reduce_hook`` receives is that (n_slots,) vector, +inf for the faces none of this rank's
