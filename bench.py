@@ -538,12 +538,14 @@ def main():
                     "step_ms": round(float(step_ms.mean()), 4), "step_ms_index_ready": round(float(step_ms_ci.mean()), 4),
                     "spans": spans_of(timer), "spans_index_ready": spans_of(timer_ready),
                     "top_simplices": int(verts.shape[0])}
+        per_rank = [mine_rec]
         if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine_rec)
-            per_rank = gathered
-        else:
-            per_rank = [mine_rec]
+            try:   # (a diagnostic: it must never cost the line)
+                gathered = [None] * world
+                dist.all_gather_object(gathered, mine_rec)
+                per_rank = gathered
+            except Exception as e:  # noqa: BLE001
+                per_rank = [dict(mine_rec, note=f"all_gather_object failed: {e!r}"[:200])]
 
     # cold steps: 512 MB written to another buffer before every step (L2 + the 256 MB Infinity Cache hold none of
     # the cloud, the tree or the tables: what one flood_complex call on a fresh cloud sees)
