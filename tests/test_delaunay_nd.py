@@ -300,6 +300,34 @@ def test_parallel_monotone_pass_equals_numpy(monkeypatch):
     assert not b.make_filtration_non_decreasing()              # idempotent
 
 
+def test_host_abi_from_plain_c(tmp_path):
+    """examples/host_abi_example.c: the host entry points called from C, linked against libflooder_host.so - the same
+    cell count as the Python binding gives for the same cloud."""
+    import shutil
+    import subprocess
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_abi_example"
+    lib = build.build_host()
+    subprocess.run([cc, "-O2", f"-I{os.path.join(root, 'include')}", os.path.join(root, "examples", "host_abi_example.c"),
+                    "-o", str(exe), lib, f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
+    out = subprocess.run([str(exe), "5", "160"], check=True, capture_output=True, text=True).stdout
+    assert "dim 5, 160 points" in out and "faces of cell 0 found 20" in out
+    n_cells = int(out.split(":")[1].split()[0])
+    # the same xorshift cloud in numpy
+    s, vals = 88172645463325252, []
+    for _ in range(160 * 5):
+        s ^= (s << 13) & 0xFFFFFFFFFFFFFFFF
+        s ^= s >> 7
+        s ^= (s << 17) & 0xFFFFFFFFFFFFFFFF
+        vals.append(np.float32((s >> 11) / 9007199254740992.0 - 0.5))
+    P = np.array(vals, dtype=np.float32).reshape(160, 5)
+    assert len(qhull(P)) == n_cells
+
+
 # ------------------------------------------------------------------------------------------------ gudhi's own output
 VIS = ["virus", "coral", "lockwasher"]
 
