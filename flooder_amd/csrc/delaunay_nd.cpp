@@ -660,180 +660,247 @@ struct Engine {
     int64_t lo = 0, hi = 1;
     const int64_t max_simplices = (int64_t)1 << 28;
 
-    std::vector<int> apex;
-    std::vector<int64_t> cand_base;
-    std::vector<int32_t> cverts;
-    std::vector<uint8_t> cpos;
-    std::vector<int32_t> cslot;
-    std::unique_ptr<std::atomic<int32_t>[]> tab_idx;
-    std::unique_ptr<std::atomic<uint32_t>[]> tab_mask;
-    size_t tab_cap = 0;
-    auto need_table = [&](size_t items) {
+    // Two lock-free open-addressing tables (one word per slot, claimed by CAS):
+    //   A, per sub-round: the candidate simplices by their vertices - the same simplex is reached through several
+    //      facets; the smallest candidate index represents it;
+    //   T, per level: facets by their vertices - the still-open facets of the level's simplices ("old") and every facet
+    //      of the simplices the level has produced so far ("new").  The second owner of a facet closes it for both.
+    // (a slot holds the upper half of the key's hash beside the entry: a probe that passes over another key's slot
+    // compares one word and never touches that key's vertices - a cache miss each in tables of millions of slots)
+    struct Table {
+      std::unique_ptr<std::atomic<uint64_t>[]> idx;   // hash tag << 32 | entry (0: empty)
+      size_t cap = 0, mask = 0;
+    } A, T;
+    auto need_table = [&](Table& t, size_t items) {
       size_t cap = 1024;
       while (cap < 2 * items + 16) cap <<= 1;
-      if (cap > tab_cap) {
-        tab_idx.reset(new std::atomic<int32_t>[cap]);
-        tab_mask.reset(new std::atomic<uint32_t>[cap]);
-        tab_cap = cap;
+      if (cap > t.cap) {
+        t.idx.reset(new std::atomic<uint64_t>[cap]);
+        t.cap = cap;
       }
+      t.mask = cap - 1;
       pool.parallel_for((int64_t)cap, 1 << 16, [&](int64_t a, int64_t b, int) {
-        for (int64_t i = a; i < b; ++i) {
-          tab_idx[(size_t)i].store(0, std::memory_order_relaxed);
-          tab_mask[(size_t)i].store(0, std::memory_order_relaxed);
-        }
+        for (int64_t i = a; i < b; ++i) t.idx[(size_t)i].store(0, std::memory_order_relaxed);
       });
-      return cap;
     };
+    std::vector<int> apex;
+    std::vector<int64_t> task, cand_base;
+    std::vector<int32_t> cverts;
+    std::vector<int32_t> cslot;
+    std::vector<uint8_t> cpos;
 
     int levels = 0;
-    double t_piv = 0, t_rest = 0;
+    long rounds = 0;
+    double t_piv = 0, t_rest = 0, t_ph[6] = {0, 0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const char* env_r = std::getenv("FLOODER_DELAUNAY_ROUNDS");
     while (lo < hi) {
       const int64_t nf = hi - lo;
       ++levels;
-      const double t0 = now();
-      // (a) pivots across the open facets of this level
-      apex.assign((size_t)nf * V, -3);
-      pool.parallel_for(nf, std::max<int64_t>(1, std::min<int64_t>(16, nf / (8 * (int64_t)pool.nt))), [&](int64_t a, int64_t b, int tid) {
-        for (int64_t s = a; s < b; ++s) {
-          if (error.load(std::memory_order_relaxed)) return;
-          pivots(&verts[(size_t)(lo + s) * V], open_mask[(size_t)(lo + s)], &apex[(size_t)s * V], scans[(size_t)tid]);
+      double t0 = now();
+      // A level is worked off in R sub-rounds: the simplices a sub-round produces close facets of the level's other
+      // simplices BEFORE those are pivoted (one sweep of the level reaches a new simplex from two sides on average:
+      // twice the pivots).  R grows with the width of the level; a narrow level keeps all threads busy only in one go.
+      int64_t n_open = 0;
+      for (int64_t s = 0; s < nf; ++s) n_open += __builtin_popcount(open_mask[(size_t)(lo + s)]);
+      if (n_open == 0) break;
+      if (nf >= ((int64_t)1 << 24) || n_open >= ((int64_t)1 << 24)) return E_TOO_MANY;   // (table entries are 31-bit)
+      int R = env_r ? std::atoi(env_r) : (int)std::min<int64_t>(8, nf / ((int64_t)pool.nt * 48));
+      R = std::max(1, std::min(R, 64));
+      // facets closed during this level: of the level's own simplices, and of the new ones (at most one per open facet)
+      std::unique_ptr<std::atomic<uint32_t>[]> fclosed(new std::atomic<uint32_t>[(size_t)nf]);
+      std::unique_ptr<std::atomic<uint32_t>[]> nclosed(new std::atomic<uint32_t>[(size_t)n_open]);
+      pool.parallel_for(std::max(nf, n_open), 1 << 15, [&](int64_t a, int64_t b, int) {
+        for (int64_t i = a; i < b; ++i) {
+          if (i < nf) fclosed[(size_t)i].store(0, std::memory_order_relaxed);
+          if (i < n_open) nclosed[(size_t)i].store(0, std::memory_order_relaxed);
         }
       });
-      if (error.load()) return E_DEGENERATE;
-      const double t1 = now();
-      t_piv += t1 - t0;
-      // (b) candidates: the simplex beyond every pivoted facet
-      cand_base.assign((size_t)nf + 1, 0);
-      for (int64_t s = 0; s < nf; ++s) {
-        int c = 0;
-        for (int k = 0; k < V; ++k) c += apex[(size_t)s * V + k] >= 0;
-        cand_base[(size_t)s + 1] = cand_base[(size_t)s] + c;
-      }
-      const int64_t nc = cand_base[(size_t)nf];
-      if (nc == 0) { t_rest += now() - t1; break; }
-      if (hi + nc > max_simplices) return E_TOO_MANY;
-      cverts.resize((size_t)nc * V);
-      cpos.resize((size_t)nc);
-      cslot.resize((size_t)nc);
-      pool.parallel_for(nf, 256, [&](int64_t a, int64_t b, int) {
-        for (int64_t s = a; s < b; ++s) {
-          int64_t c = cand_base[(size_t)s];
-          const int32_t* vs = &verts[(size_t)(lo + s) * V];
-          for (int k = 0; k < V; ++k) {
-            const int q = apex[(size_t)s * V + k];
-            if (q < 0) continue;
-            int32_t* o = &cverts[(size_t)c * V];
-            int m = 0, pos = -1;
-            for (int i = 0; i < V; ++i) {
-              if (i == k) continue;
-              if (pos < 0 && q < vs[i]) { pos = m; o[m++] = q; }
-              o[m++] = vs[i];
-            }
-            if (pos < 0) { pos = m; o[m++] = q; }
-            cpos[(size_t)c] = (uint8_t)pos;
-            ++c;
-          }
-        }
-      });
-      // (c) the same simplex reached through several facets: one representative (the smallest candidate index), the
-      // facets it was reached through are closed
-      const size_t capA = need_table((size_t)nc);
-      pool.parallel_for(nc, 1024, [&](int64_t a, int64_t b, int) {
-        for (int64_t c = a; c < b; ++c) {
-          const int32_t* v = &cverts[(size_t)c * V];
-          uint64_t h = 0x9E3779B97F4A7C15ull;
-          for (int i = 0; i < V; ++i) h = mix64(h ^ (uint64_t)(uint32_t)v[i]);
-          size_t slot = (size_t)h & (capA - 1);
-          for (;;) {
-            int32_t cur = tab_idx[slot].load(std::memory_order_acquire);
-            if (cur == 0) {
-              if (tab_idx[slot].compare_exchange_strong(cur, (int32_t)c + 1, std::memory_order_acq_rel)) break;
-            }
-            const int32_t* u = &cverts[(size_t)(cur - 1) * V];
-            bool same = true;
-            for (int i = 0; i < V; ++i) same &= u[i] == v[i];
-            if (same) {
-              while (cur - 1 > c && !tab_idx[slot].compare_exchange_weak(cur, (int32_t)c + 1, std::memory_order_acq_rel)) {
-              }
-              break;
-            }
-            slot = (slot + 1) & (capA - 1);
-          }
-          tab_mask[slot].fetch_or(1u << cpos[(size_t)c], std::memory_order_relaxed);
-          cslot[(size_t)c] = (int32_t)slot;
-        }
-      });
-      // (d) the new simplices, in candidate order
-      std::vector<int64_t> new_of((size_t)nc + 1, 0);
-      for (int64_t c = 0; c < nc; ++c)
-        new_of[(size_t)c + 1] = new_of[(size_t)c] + (tab_idx[(size_t)cslot[(size_t)c]].load(std::memory_order_relaxed) == (int32_t)c + 1);
-      const int64_t nn = new_of[(size_t)nc];
-      verts.resize((size_t)(hi + nn) * V);
-      open_mask.resize((size_t)(hi + nn));
-      std::unique_ptr<std::atomic<uint32_t>[]> closed(new std::atomic<uint32_t>[(size_t)nn]);
-      pool.parallel_for(nc, 4096, [&](int64_t a, int64_t b, int) {
-        for (int64_t c = a; c < b; ++c) {
-          const size_t slot = (size_t)cslot[(size_t)c];
-          if (tab_idx[slot].load(std::memory_order_relaxed) != (int32_t)c + 1) continue;
-          const int64_t id = new_of[(size_t)c];
-          std::memcpy(&verts[(size_t)(hi + id) * V], &cverts[(size_t)c * V], sizeof(int32_t) * V);
-          closed[(size_t)id].store(tab_mask[slot].load(std::memory_order_relaxed), std::memory_order_relaxed);
-        }
-      });
-      // (e) facets shared by two of the new simplices
-      const size_t capB = need_table((size_t)nn * V);
+      need_table(T, (size_t)n_open * (size_t)(V + 1));
       std::atomic<int> bad{0};
-      pool.parallel_for(nn, 512, [&](int64_t a, int64_t b, int) {
-        for (int64_t s = a; s < b; ++s) {
-          const int32_t* v = &verts[(size_t)(hi + s) * V];
-          const uint32_t origin = closed[(size_t)s].load(std::memory_order_relaxed);   // (set in (d): stable)
-          for (int k = 0; k < V; ++k) {
-            if (origin >> k & 1) continue;
-            uint64_t h = 0xD6E8FEB86659FD93ull;
-            for (int i = 0; i < V; ++i)
-              if (i != k) h = mix64(h ^ (uint64_t)(uint32_t)v[i]);
-            size_t slot = (size_t)h & (capB - 1);
-            const int32_t me = (int32_t)(s * 16 + k) + 1;
-            for (;;) {
-              int32_t cur = tab_idx[slot].load(std::memory_order_acquire);
-              if (cur == 0) {
-                if (tab_idx[slot].compare_exchange_strong(cur, me, std::memory_order_acq_rel)) break;
-              }
-              const int64_t s2 = (cur - 1) / 16;
-              const int k2 = (cur - 1) % 16;
-              const int32_t* u = &verts[(size_t)(hi + s2) * V];
-              bool same = true;
-              for (int i = 0, i2 = 0; i < V && same; ++i) {
-                if (i == k) continue;
-                if (i2 == k2) ++i2;
-                same = u[i2] == v[i];
-                ++i2;
-              }
-              if (same) {
-                // second owner: both facets are closed; a third owner means the pivots were inconsistent
-                if (tab_mask[slot].fetch_add(1, std::memory_order_relaxed) != 0) bad.store(1);
-                closed[(size_t)s].fetch_or(1u << (16 + k), std::memory_order_relaxed);
-                closed[(size_t)s2].fetch_or(1u << (16 + k2), std::memory_order_relaxed);
-                break;
-              }
-              slot = (slot + 1) & (capB - 1);
-            }
+      // insert facet k of a simplex (old: index into the level, new: index among the level's new simplices) into T; the
+      // second owner closes the facet for both, a third means the pivots were inconsistent
+      auto facet_insert = [&](const int32_t* v, int k, int32_t me) {
+        uint64_t h = 0xD6E8FEB86659FD93ull;
+        for (int i = 0; i < V; ++i)
+          if (i != k) h = mix64(h ^ (uint64_t)(uint32_t)v[i]);
+        size_t slot = (size_t)h & T.mask;
+        const uint64_t tag = h & 0xFFFFFFFF00000000ull, mine = tag | (uint32_t)me;
+        for (;;) {
+          uint64_t word = T.idx[slot].load(std::memory_order_acquire);
+          if (word == 0) {
+            if (T.idx[slot].compare_exchange_strong(word, mine, std::memory_order_acq_rel)) return;
           }
+          if ((word & 0xFFFFFFFF00000000ull) != tag) {
+            slot = (slot + 1) & T.mask;
+            continue;
+          }
+          const int32_t cur = (int32_t)((uint32_t)word & 0x7FFFFFFFu);
+          const bool cur_new = (cur - 1) & 1;
+          const int64_t s2 = (cur - 1) >> 5;
+          const int k2 = ((cur - 1) >> 1) & 15;
+          const int32_t* u = &verts[(size_t)((cur_new ? hi : lo) + s2) * V];
+          bool same = true;
+          for (int i = 0, i2 = 0; i < V && same; ++i) {
+            if (i == k) continue;
+            if (i2 == k2) ++i2;
+            same = u[i2] == v[i];
+            ++i2;
+          }
+          if (same) {
+            // (bit 31 of the entry: the facet has its second owner - a third means the pivots were inconsistent)
+            if (T.idx[slot].fetch_or(0x80000000ull, std::memory_order_relaxed) & 0x80000000ull) bad.store(1);
+            const bool me_new = (me - 1) & 1;
+            const int64_t s1 = (me - 1) >> 5;
+            (me_new ? nclosed : fclosed)[(size_t)s1].fetch_or(1u << k, std::memory_order_relaxed);
+            (cur_new ? nclosed : fclosed)[(size_t)s2].fetch_or(1u << k2, std::memory_order_relaxed);
+            return;
+          }
+          slot = (slot + 1) & T.mask;
+        }
+      };
+      auto entry = [](int64_t s, int k, bool is_new) { return (int32_t)(((s << 4 | k) << 1 | (is_new ? 1 : 0)) + 1); };
+      pool.parallel_for(nf, 1024, [&](int64_t a, int64_t b, int) {
+        for (int64_t s = a; s < b; ++s) {
+          const unsigned m = open_mask[(size_t)(lo + s)];
+          for (int k = 0; k < V; ++k)
+            if (m >> k & 1) facet_insert(&verts[(size_t)(lo + s) * V], k, entry(s, k, false));
         }
       });
       if (bad.load()) return E_INCONSISTENT;
-      for (int64_t s = 0; s < nn; ++s) {
-        const uint32_t c = closed[(size_t)s].load(std::memory_order_relaxed);
-        open_mask[(size_t)(hi + s)] = (uint16_t)(((1u << V) - 1) & ~(c | (c >> 16)));
+      t_rest += now() - t0;
+      t_ph[0] += now() - t0;
+      int64_t nn_level = 0;
+      for (int r = 0; r < R; ++r) {
+        t0 = now();
+        ++rounds;
+        // (a) pivots across the facets of this sub-round's simplices that are still open
+        task.clear();
+        for (int64_t s = r; s < nf; s += R)
+          if (open_mask[(size_t)(lo + s)] & ~fclosed[(size_t)s].load(std::memory_order_relaxed)) task.push_back(s);
+        const int64_t nt_ = (int64_t)task.size();
+        if (nt_ == 0) { t_rest += now() - t0; continue; }
+        apex.assign((size_t)nt_ * V, -3);
+        pool.parallel_for(nt_, std::max<int64_t>(1, std::min<int64_t>(16, nt_ / (8 * (int64_t)pool.nt))), [&](int64_t a, int64_t b, int tid) {
+          for (int64_t i = a; i < b; ++i) {
+            if (error.load(std::memory_order_relaxed)) return;
+            const int64_t s = task[(size_t)i];
+            const unsigned m = open_mask[(size_t)(lo + s)] & ~fclosed[(size_t)s].load(std::memory_order_relaxed);
+            pivots(&verts[(size_t)(lo + s) * V], m, &apex[(size_t)i * V], scans[(size_t)tid]);
+          }
+        });
+        if (error.load()) return E_DEGENERATE;
+        const double t1 = now();
+        t_piv += t1 - t0;
+        // (b) candidates: the simplex beyond every pivoted facet
+        cand_base.assign((size_t)nt_ + 1, 0);
+        for (int64_t i = 0; i < nt_; ++i) {
+          int c = 0;
+          for (int k = 0; k < V; ++k) c += apex[(size_t)i * V + k] >= 0;
+          cand_base[(size_t)i + 1] = cand_base[(size_t)i] + c;
+        }
+        const int64_t nc = cand_base[(size_t)nt_];
+        if (nc == 0) { t_rest += now() - t1; continue; }
+        if (hi + nn_level + nc > max_simplices) return E_TOO_MANY;
+        cverts.resize((size_t)nc * V);
+        cslot.resize((size_t)nc);
+        cpos.resize((size_t)nc);
+        pool.parallel_for(nt_, 256, [&](int64_t a, int64_t b, int) {
+          for (int64_t i = a; i < b; ++i) {
+            int64_t c = cand_base[(size_t)i];
+            const int32_t* vs = &verts[(size_t)(lo + task[(size_t)i]) * V];
+            for (int k = 0; k < V; ++k) {
+              const int q = apex[(size_t)i * V + k];
+              if (q < 0) continue;
+              int32_t* o = &cverts[(size_t)c * V];
+              int m = 0, pos = -1;
+              for (int j = 0; j < V; ++j) {
+                if (j == k) continue;
+                if (pos < 0 && q < vs[j]) { pos = m; o[m++] = q; }
+                o[m++] = vs[j];
+              }
+              if (pos < 0) { pos = m; o[m++] = q; }
+              cpos[(size_t)c] = (uint8_t)pos;     // the facet opposite the apex is the parent's: closed
+              ++c;
+            }
+          }
+        });
+        double tp = now();
+        t_ph[1] += tp - t1;
+        // (c) the same simplex reached through several facets: the smallest candidate index represents it
+        need_table(A, (size_t)nc);
+        pool.parallel_for(nc, 1024, [&](int64_t a, int64_t b, int) {
+          for (int64_t c = a; c < b; ++c) {
+            const int32_t* v = &cverts[(size_t)c * V];
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+            for (int i = 0; i < V; ++i) h = mix64(h ^ (uint64_t)(uint32_t)v[i]);
+            size_t slot = (size_t)h & A.mask;
+            const uint64_t tag = h & 0xFFFFFFFF00000000ull, mine = tag | (uint32_t)((int32_t)c + 1);
+            for (;;) {
+              uint64_t word = A.idx[slot].load(std::memory_order_acquire);
+              if (word == 0) {
+                if (A.idx[slot].compare_exchange_strong(word, mine, std::memory_order_acq_rel)) break;
+              }
+              bool same = (word & 0xFFFFFFFF00000000ull) == tag;
+              if (same) {
+                const int32_t* u = &cverts[(size_t)((int32_t)(uint32_t)word - 1) * V];
+                for (int i = 0; i < V; ++i) same &= u[i] == v[i];
+              }
+              if (same) {   // (the smallest candidate index stays in the slot)
+                while ((int32_t)(uint32_t)word - 1 > c && !A.idx[slot].compare_exchange_weak(word, mine, std::memory_order_acq_rel)) {
+                }
+                break;
+              }
+              slot = (slot + 1) & A.mask;
+            }
+            cslot[(size_t)c] = (int32_t)slot;
+          }
+        });
+        t_ph[2] += now() - tp;
+        tp = now();
+        // (d) the new simplices, in candidate order, behind the ones the level has produced so far
+        std::vector<int64_t> new_of((size_t)nc + 1, 0);
+        for (int64_t c = 0; c < nc; ++c)
+          new_of[(size_t)c + 1] = new_of[(size_t)c] + ((int32_t)(uint32_t)A.idx[(size_t)cslot[(size_t)c]].load(std::memory_order_relaxed) == (int32_t)c + 1);
+        const int64_t nn = new_of[(size_t)nc];
+        if (nn_level + nn > n_open) return E_INCONSISTENT;     // (more simplices than open facets: impossible)
+        verts.resize((size_t)(hi + nn_level + nn) * V);
+        pool.parallel_for(nc, 4096, [&](int64_t a, int64_t b, int) {
+          for (int64_t c = a; c < b; ++c) {
+            if ((int32_t)(uint32_t)A.idx[(size_t)cslot[(size_t)c]].load(std::memory_order_relaxed) != (int32_t)c + 1) continue;
+            std::memcpy(&verts[(size_t)(hi + nn_level + new_of[(size_t)c]) * V], &cverts[(size_t)c * V], sizeof(int32_t) * V);
+            nclosed[(size_t)(nn_level + new_of[(size_t)c])].store(1u << cpos[(size_t)c], std::memory_order_relaxed);
+          }
+        });
+        t_ph[3] += now() - tp;
+        tp = now();
+        // (e) the facets of the new simplices into the level's table (not the one a simplex was reached through: its
+        // parent's, pivoted and done): they meet still-open facets of the level - no pivot needed there any more -,
+        // facets of other new simplices, or nobody yet
+        pool.parallel_for(nn, 512, [&](int64_t a, int64_t b, int) {
+          for (int64_t s = a; s < b; ++s) {
+            const int64_t id = nn_level + s;
+            const uint32_t origin = nclosed[(size_t)id].load(std::memory_order_relaxed) & ((1u << V) - 1);
+            for (int k = 0; k < V; ++k)
+              if (!((origin >> k) & 1)) facet_insert(&verts[(size_t)(hi + id) * V], k, entry(id, k, true));
+          }
+        });
+        if (bad.load()) return E_INCONSISTENT;
+        nn_level += nn;
+        t_ph[4] += now() - tp;
+        t_rest += now() - t1;
       }
+      open_mask.resize((size_t)(hi + nn_level));
+      for (int64_t s = 0; s < nn_level; ++s)
+        open_mask[(size_t)(hi + s)] = (uint16_t)(((1u << V) - 1) & ~nclosed[(size_t)s].load(std::memory_order_relaxed));
       lo = hi;
-      hi += nn;
-      t_rest += now() - t1;
+      hi += nn_level;
     }
     if (std::getenv("FLOODER_DELAUNAY_VERBOSE"))
-      std::fprintf(stderr, "delaunay_nd<%d>: %ld simplices, %d levels, pivots %.3f s, tables %.3f s, %d threads; %ld pivots, %ld flagged points\n", D,
-                   (long)hi, levels, t_piv, t_rest, pool.nt, [&] { long f = 0; for (auto& s : scans) f += s.pivots; return f; }(), [&] { long f = 0; for (auto& s : scans) f += s.flagged; return f; }());
+      std::fprintf(stderr, "  tables: level set-up %.3f, candidates %.3f, dedupe %.3f, new simplices %.3f, facets %.3f s\n", t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4]);
+    if (std::getenv("FLOODER_DELAUNAY_VERBOSE"))
+      std::fprintf(stderr, "delaunay_nd<%d>: %ld simplices, %d levels (%ld sub-rounds), pivots %.3f s, tables %.3f s, %d threads; %ld pivots, %ld flagged points\n", D,
+                   (long)hi, levels, rounds, t_piv, t_rest, pool.nt, [&] { long f = 0; for (auto& s : scans) f += s.pivots; return f; }(), [&] { long f = 0; for (auto& s : scans) f += s.flagged; return f; }());
     const int64_t total = hi;
     int32_t* out = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1) * V);
     if (!out) return E_TOO_MANY;
