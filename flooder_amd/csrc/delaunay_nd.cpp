@@ -700,12 +700,14 @@ struct Engine {
       double t0 = now();
       // A level is worked off in R sub-rounds: the simplices a sub-round produces close facets of the level's other
       // simplices BEFORE those are pivoted (one sweep of the level reaches a new simplex from two sides on average:
-      // twice the pivots).  R grows with the width of the level; a narrow level keeps all threads busy only in one go.
+      // twice the pivots).  R grows with the width of the level, up to 4 (8 on at most 8 threads; measured on 32 threads of the GPU box's host at
+      // cfg 4: R = 1 438 ms, 4 354, 8 387, 16 443 - every sub-round is six more barriers); a narrow level keeps all
+      // threads busy only in one go.
       int64_t n_open = 0;
       for (int64_t s = 0; s < nf; ++s) n_open += __builtin_popcount(open_mask[(size_t)(lo + s)]);
       if (n_open == 0) break;
       if (nf >= ((int64_t)1 << 24) || n_open >= ((int64_t)1 << 24)) return E_TOO_MANY;   // (table entries are 31-bit)
-      int R = env_r ? std::atoi(env_r) : (int)std::min<int64_t>(8, nf / ((int64_t)pool.nt * 48));
+      int R = env_r ? std::atoi(env_r) : (int)std::min<int64_t>(pool.nt <= 8 ? 8 : 4, nf / ((int64_t)pool.nt * 48));
       R = std::max(1, std::min(R, 64));
       // facets closed during this level: of the level's own simplices, and of the new ones (at most one per open facet)
       std::unique_ptr<std::atomic<uint32_t>[]> fclosed(new std::atomic<uint32_t>[(size_t)nf]);

@@ -120,7 +120,7 @@ def delaunay_cells(points: np.ndarray) -> np.ndarray:
 
 
 NATIVE_DELAUNAY = True   # csrc/delaunay2d.cpp, delaunay3d.cpp, delaunay_nd.cpp (4 .. 8 dimensions, all host cores) in libflooder_host.so instead of Qhull; falls back to Qhull where they decline
-HOST_THREADS_MAX = 32    # measured on the 2 x 64-core host of the MI355X box: 16 - 32 threads are the optimum (345 ms for cfg 4's Delaunay; 8: 690, 64: 510, 128: 890 - the level barriers and the tables' cache lines cost more than the extra cores give)
+HOST_THREADS_MAX = 24    # measured on the 2 x 64-core host of the MI355X box: 16 - 32 threads are the optimum (345 - 390 ms for cfg 4's Delaunay; 8: 660, 48: 480, 64: 580, 128: 890 - the barriers of the sub-rounds and the tables' cache lines cost more than the extra cores give)
 DELAUNAY_THREADS = 0     # threads of the 4 .. 8-dimensional routine: 0 = the CPUs of this process's share (see _host_threads)
 LAST_DELAUNAY = {"native": False, "code": 0}
 _HOST_DT = False
