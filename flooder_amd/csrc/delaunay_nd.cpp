@@ -14,8 +14,8 @@
 // independent of every other one: the open facets of a level are spread over the threads, the simplices they produce
 // are deduplicated and their facets matched in lock-free hash tables, what stays unmatched is the next level.  (An
 // incremental insertion does a tenth of the arithmetic and all of it in sequence; this does ten times the arithmetic
-// in perfectly parallel dot products - 5 core-seconds at cfg 4, half a second on 8 cores, less on the 256 of the GPU
-// box.)
+// in perfectly parallel dot products - 7 core-seconds at cfg 4: 1.2 s on the 8 CPUs of the build container, 0.35 s on
+// 16 - 24 threads of the GPU box's host; Qhull: 21 s / 8 s on one.)
 //
 // Exactness: the linear forms come from a floating-point inverse of the simplex's edge matrix with RIGOROUS error
 // bounds (a-posteriori: the residual I - U X bounds |U^-1 - X|); a point whose interval may beat the best upper bound
@@ -23,7 +23,7 @@
 // facet - the comparison is decided EXACTLY: the coordinates are dyadic rationals, scaled once to integers (at most 121
 // bits), the determinants behind power and lambda are evaluated over multi-word integers.  Points in general position
 // have a unique Delaunay triangulation: the result equals Qhull's and CGAL's as a set of simplices
-// (tests/test_delaunay.py).  An exact tie (d + 2 cospherical points, d + 1 points on a hyperplane) is declined - the
+// (tests/test_delaunay_nd.py; pinned to gudhi's own output on the reference's committed clouds).  An exact tie (d + 2 cospherical points, d + 1 points on a hyperplane) is declined - the
 // caller then uses Qhull, as with the 2-D / 3-D routines.
 //
 // C ABI (include/flooder_host.h):  flooder_delaunay_nd, flooder_host_free.
@@ -191,7 +191,7 @@ struct Engine {
   double amax[D];                        // upper bound of |pc_ij|
   std::vector<int32_t> verts;            // simplices: V ascending vertex ids each
   std::atomic<int> error{0};
-  std::atomic<long> exact_calls{0}, contenders_total{0}, n_pivots{0};
+  std::atomic<long> exact_calls{0}, contenders_total{0};
 
   const double* P(int i) const { return pc.data() + (size_t)i * D; }
 
