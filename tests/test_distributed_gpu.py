@@ -290,3 +290,19 @@ def test_block_shards_refuse_landmarks_off_the_cloud():
     fa.flood_complex(pts, lms, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True)
     with pytest.raises(ValueError, match="rows of `points`"):
         fa.flood_complex(pts, lms + 1e-3, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True)
+    # landmarks_in_cloud: the caller vouches (True: the O(n log n) membership test and its host synchronisation are
+    # skipped - same values), or says they are not (False: refused without looking)
+    from flooder_amd import core
+
+    calls = []
+    orig = core._rows_are_subset
+    core._rows_are_subset = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    try:
+        a = fa.flood_complex(pts, lms, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True)
+        n_checked = len(calls)
+        b = fa.flood_complex(pts, lms, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True, landmarks_in_cloud=True)
+        assert n_checked >= 1 and len(calls) == n_checked and a == b
+    finally:
+        core._rows_are_subset = orig
+    with pytest.raises(ValueError, match="rows of `points`"):
+        fa.flood_complex(pts, lms, points_per_edge=6, simplex_shard=(0, 2), shard_blocks=True, landmarks_in_cloud=False)
