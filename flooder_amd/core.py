@@ -769,6 +769,7 @@ def block_subcloud(points32: torch.Tensor, verts: torch.Tensor, d: int, box: Opt
     return out[:int(count.item())]
 
 
+CPU_WORKERS = -1      # threads of the CPU branch's kd-tree query (scipy: -1 = all cores; the reference's call uses 1)
 SHARD_DEAL = "stride"   # how mode="simplices" cuts the queue: "stride" (every world-th row), "size" (largest simplices first, dealt round-robin: measured, round 6 - an eighth of cfg 3 1.48 -> 1.42 ms, of cfg 5 2.97 -> 2.93, of cfg 2 0.59 -> 0.62: the slow rank is the one that holds THE hardest tile, whichever deal hands it over)
 
 
@@ -1651,7 +1652,9 @@ def flood_complex(
                 face_dev, _ = _sweep_dimension_bvh(index, sv, weights, faces, reduce_hook, plan=plan, tile_shard=tile_shard)
         else:
             samples = weights.unsqueeze(0) @ sv
-            dist, _ = kdtree.query(np.asarray(samples))
+            # (the reference queries with scipy's default of ONE worker, core.py:198; the distances do not depend on
+            # the number of workers)
+            dist, _ = kdtree.query(np.asarray(samples), workers=CPU_WORKERS)
             dist = torch.as_tensor(dist)
             if reduce_hook is not None:
                 reduce_hook(dist)
