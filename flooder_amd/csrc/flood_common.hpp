@@ -49,6 +49,7 @@ extern int g_cell_retry_keep;  // ... and the attempt may have kept at most this
 extern int g_cell_retry_pct;  // share (percent) of a chunk's open samples that must have a point within twice the cell size for a second try (0: always)
 extern int g_finish_items_cap;
 extern int g_finish_budget_min;  // leaves a tile of a SHORT list may evaluate before it counts as hard
+extern int g_finish_wide_points;  // clouds of at least this many points run the finish's per-wave passes with 8 waves per workgroup (0: never)
 extern int g_finish_budget;  // scale of the leaf budget beyond which a tile of the finish counts as hard (0: off)
 extern int g_finish_top;     // 1: the finish settles one sample per simplex (its largest bound) before everything else
 extern int g_finish_order;   // 1: the finish works the flagged tiles off by descending probe bound

@@ -72,8 +72,13 @@ struct HardLists {
 
 constexpr int TEAM_WAVES = 16;
 
-template <int DIM, bool TEAM>
-__global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FINISH_WAVES) void finish_faces_kernel(
+// WAVES: waves per workgroup of the per-wave passes.  4 (default): four workgroups per CU, 4 waves per SIMD.  8: eight
+// waves share ONE staged tree top - three workgroups per CU, 6 waves per SIMD at an 80-register cap (a dozen spills) -
+// for clouds whose tree is deep: a search there is a longer chain of dependent steps and more waves hide more of it
+// (cfg 5, 16 M points: finish 1.68 -> 1.47 ms, step 8.71 -> 8.49; cfg 3, 1 M points: 1.580 -> 1.564; cfg 2: 0.077 ->
+// 0.082 - chosen by cloud size, option "finish_wide_points").
+template <int DIM, bool TEAM, int WAVES = 4>
+__global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 64 * WAVES, TEAM ? 4 : (WAVES == 8 ? 6 : FLOODER_FINISH_WAVES)) void finish_faces_kernel(
     const float* __restrict__ pts, const float* __restrict__ nodes, Levels lv,
     const float* __restrict__ verts, const float* __restrict__ weights, int k1, int R,
     int64_t n_simplices, const int32_t* __restrict__ flag_list, const int32_t* __restrict__ flag_sorted,
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
     int32_t* __restrict__ top_list, int32_t* __restrict__ top_count, HardLists hl,
     unsigned long long* __restrict__ stats) {
   constexpr int DP = padded_dim(DIM);
-  constexpr int NW = TEAM ? TEAM_WAVES : 4;  // waves of the workgroup
+  constexpr int NW = TEAM ? TEAM_WAVES : WAVES;  // waves of the workgroup
   __shared__ float s_lb[NW][MAXL][FAN];
   __shared__ int64_t s_grp[NW][MAXL];
   // TEAM: the tile being worked on, wave 0's reading of the face maxima, the combined minima of a round
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
   if (mode == 2) {
     subs = subs_max;
     while (subs > 1 && n_base * subs > items_cap) subs >>= 1;
-    if (subs_max > 1 && n_base * 64 <= (int64_t)gridDim.x * 4) subs = 64;
+    if (subs_max > 1 && n_base * 64 <= (int64_t)gridDim.x * NW) subs = 64;
   }
   if (n_base == 0) return;
   // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
   // simplices) lowers it with the share
   // (top pass: one point query per simplex and about one query per wave - the pass lasts as long as its longest
   // query, so the budget is a fixed few dozen leaves)
-  const int64_t budget_raw = mode == 1 ? (int64_t)hl.budget * 4 : (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * 4);
+  const int64_t budget_raw = mode == 1 ? (int64_t)hl.budget * 4 : (int64_t)hl.budget * n_list / ((int64_t)gridDim.x * NW);
   // (a short list - cfg 2's 200 tiles, a rank's share - used to get min(budget, 64) = 14 leaves: every dense tile went
   // to the team launch, 50 us of launch for work the first pass does in 20; cfg 2 finish 0.115 -> 0.082 ms)
   const int budget_min = hl.budget_min;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 256, TEAM ? 4 : FLOODER_FI
   long long g_prev = -1;
   unsigned long long m_prev = 0;
 #endif
-  const bool static_deal = !TEAM && n_items <= (int64_t)gridDim.x * 4;
+  const bool static_deal = !TEAM && n_items <= (int64_t)gridDim.x * NW;
   bool dealt = false;
   int q_shard = (int)(wave_id % QSHARDS), q_tried = 0;
   for (;;) {
@@ -691,6 +696,7 @@ struct FinishOp {
       return fail(FLOODER_E_ARG, "flooder_finish_faces_f32: only dim 2 and 3");
     } else {
     const int grid = g_bvh_grid;
+    const bool wide = g_finish_wide_points > 0 && lv.count[0] * (int64_t)FLOODER_BVH_LEAF >= (int64_t)g_finish_wide_points;
     // ctl[0..2]: work-queue heads of the three passes, ctl[3]: simplices with a top tile (filled by the probe -
     // the cell sweep's when `probed`, else pass 0 here); the hard-entry launches' words: below
     const bool hard_on = hard != nullptr && hard_cap > 0 && g_finish_budget > 0;
@@ -717,6 +723,11 @@ struct FinishOp {
                            nodes, lv, verts, weights, k1, R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count,
                            mode, g_bvh_subs, g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f,
                            g_finish_refresh, queue, d2, acc, top, top_list, ctl + 3, hl, stats);
+      else if (wide)   // (deep tree: eight waves per workgroup, three workgroups per CU)
+        hipLaunchKernelGGL((finish_faces_kernel<DIM, false, 8>), dim3(grid * 3 / 4), dim3(512), 0, st, pts, nodes, lv, verts,
+                           weights, k1, R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count, mode, g_bvh_subs,
+                           g_finish_items_cap, g_bvh_refine_pct, (float)g_finish_focus_pct * 0.01f, g_finish_refresh,
+                           queue, d2, acc, top, top_list, ctl + 3, hl, stats);
       else
         hipLaunchKernelGGL((finish_faces_kernel<DIM, false>), dim3(grid), dim3(256), 0, st, pts, nodes, lv, verts,
                            weights, k1, R, ns, flag_list, ordered ? flag_sorted : nullptr, flag_count, mode, g_bvh_subs,

@@ -69,7 +69,11 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *                     twice the cell size (50 %; 0: whatever they are) - else its open tiles go to the finish;
  *   "cell_tries" / "cell_exh_tries": cell sizes tried per chunk (2) / attempts that may fall back to the exhaustive
  *                     evaluation (3); "finish_focus_pct", "finish_items_cap", "finish_budget", "finish_order", "finish_top":
- *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
+ *                     focus rounds, tile splitting and hard tiles of flooder_finish_faces_f32; "finish_wide_points"
+ *                     (4194304; 0 = never): clouds of at least this many points - a box tree of four levels and more -
+ *                     run its per-wave passes with eight waves per workgroup sharing one staged tree top (6 waves per
+ *                     SIMD at an 80-register cap instead of 4: a search in a deep tree is a longer chain of dependent
+ *                     steps; cfg 5 finish 1.68 -> 1.47 ms, no gain at a million points); "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
  *                     handed to the tree sweep (default 32768). */
 int flooder_set_option(const char* name, int value);
