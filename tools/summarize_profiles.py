@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from bench import kernel_source_sha
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-name = sys.argv[2] if len(sys.argv) > 2 else f"r5_{tag}"
+name = sys.argv[2] if len(sys.argv) > 2 else f"r6_{tag}"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 FROM_PMC = "--from-pmc" in sys.argv   # recompute traffic.json from the committed summaries (no raw profiler output)
@@ -53,8 +53,10 @@ SPANS = (("cell", "sweep", (("wit_sweep_kernel<3>", 1), ("wit_list_kernel", 1), 
                             ("cell_sweep_kernel<3, false, 4>", 1))),
          # the pass over the flagged tiles, its hard tiles (one workgroup each), the ordering of the flagged tiles:
          # one launch each per step (the "top pass" that doubled the first two is off by default since round 2)
+         # (round 6: a third template argument - waves per workgroup: 8 on clouds of 4 M points and more)
          ("cell", "fallback", (("finish_faces_kernel<3, false>", 1), ("finish_faces_kernel<3, true>", 1),
-                               ("order_flags_kernel", 1))),
+                               ("finish_faces_kernel<3, false, 4>", 1), ("finish_faces_kernel<3, false, 8>", 1),
+                               ("finish_faces_kernel<3, true, 4>", 1), ("order_flags_kernel", 1))),
          ("bvh", "sweep_bvh", (("sweep_bvh_kernel<3, 2, 1>", 1),)),
          # tree sweep over sorted samples: keys, the radix sort's launches (rocprim kernels are not listed by name:
          # their share is in kernel_stats.csv), the sweep
