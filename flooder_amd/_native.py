@@ -98,6 +98,7 @@ SIGNATURES = {
     "flooder_bbox_chunk_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "flooder_bbox_reduce_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "flooder_morton_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_morton_zero_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_curve_key_bits": (c_int, [c_int]),
     "flooder_index_sort_bytes": (c_int64, [c_int64]),
     "flooder_index_sort": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -126,6 +127,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     "flooder_density_grid_words": (c_int64, [c_int]),
     "flooder_density_grid_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "flooder_cloud_kind": (c_int, [c_void_p, c_int, c_void_p]),
     "flooder_wit_max_rows": (c_int, []),
     "flooder_wit_max_coarse": (c_int, []),
     "flooder_face_values_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

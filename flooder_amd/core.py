@@ -623,6 +623,7 @@ class PointIndex:
         self.box = box if box is not None else cloud_box(pts32)  # device: [0:dim] min, [8:8+dim] max
         # sorted row -> original index (int32)
         self.order32 = torch.empty(n, dtype=torch.int32, device=dev)
+        dens = None
         self.kd = dim > KD_ORDER_ABOVE_DIM and n > BVH_LEAF
         if self.kd:
             # above 3D: the order of a balanced k-d tree aligned with the box tree's groups (flood_index.hip) - a curve
@@ -636,9 +637,12 @@ class PointIndex:
                                                        _native.ptr(tmp), tmp_bytes, st), "flooder_kd_order_f32")
         else:
             codes = torch.empty(n, dtype=torch.int64, device=dev)
+            if dim in (2, 3) and CELL_DENSITY_GRID:   # (zeroed by the curve-code kernel on its way: no fill launch)
+                dens = torch.empty(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
             with _span(timer, "morton"):
-                _native.check(lib.flooder_morton_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
-                                                     _native.ptr(codes), st), "flooder_morton_f32")
+                _native.check(lib.flooder_morton_zero_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
+                                                          _native.ptr(codes), _native.ptr(dens),
+                                                          0 if dens is None else dens.numel(), st), "flooder_morton_zero_f32")
             # radix sort over the bits the codes use
             codes_sorted = torch.empty(n, dtype=torch.int64, device=dev)
             tmp_bytes = int(lib.flooder_index_sort_bytes(n))
@@ -654,8 +658,8 @@ class PointIndex:
         n_nodes = int(lib.flooder_bvh_node_count(n))
         self.nodes = torch.empty((n_nodes, 2 * self.dp), dtype=torch.float32, device=dev)
         # density grid for the cell sweep (2D / 3D): point counts per cell, accumulated from the leaf boxes in the same pass
-        self.dens = None
-        if dim in (2, 3) and CELL_DENSITY_GRID:
+        self.dens = dens
+        if self.dens is None and dim in (2, 3) and CELL_DENSITY_GRID:
             self.dens = torch.zeros(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
         with _span(timer, "bvh_build"):  # rows in curve order + leaf boxes in one pass, then the inner levels
             _native.check(lib.flooder_index_rows_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.order32),

@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 4; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 99; int g_finish_refresh = 16; int g_curve_bits = 0; int g_cell_super_weight = 2000; int g_cell_super_n0 = 480; int g_cell_super_sparse = 600; int g_cell_super_min_chunks = 49152; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; int g_finish_budget = 14; int g_finish_budget_min = 64; int g_finish_wide_points = 4 << 20; int g_finish_order = 1; int g_cell_retry_pct = 50; int g_cell_retry_keep = 200; int g_finish_top = 0; int g_cell_tiles = 0; int g_cell_density_grid = 16; int g_cell_chunks_per_block = 12; int g_cell_min_grid = 384; int g_cell_weight_classes = 1; int g_cell_listed_first = 1; int g_cell_tail_waves = 200; int g_cell_one_pass = 125; int g_cell_chunk_major = 1; int g_cell_chunk_major_max = 262144; int g_cell_drop = 1; int g_cell_queue_block = 5; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 4; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 99; int g_finish_refresh = 16; int g_curve_bits = 0; int g_cell_super_weight = 2000; int g_cell_super_n0 = 480; int g_cell_super_sparse = 600; int g_cell_super_min_chunks = 49152; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; int g_finish_budget = 14; int g_finish_budget_min = 64; int g_finish_wide_points = 4 << 20; int g_cell_surface_pct = 60; int g_finish_order = 1; int g_cell_retry_pct = 50; int g_cell_retry_keep = 200; int g_finish_top = 0; int g_cell_tiles = 0; int g_cell_density_grid = 16; int g_cell_chunks_per_block = 12; int g_cell_min_grid = 384; int g_cell_weight_classes = 1; int g_cell_listed_first = 1; int g_cell_tail_waves = 200; int g_cell_one_pass = 125; int g_cell_chunk_major = 1; int g_cell_chunk_major_max = 262144; int g_cell_drop = 1; int g_cell_queue_block = 5; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton
@@ -120,7 +120,13 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict
 template <int DIM>
 __global__ __launch_bounds__(256) void morton_kernel(const float* __restrict__ pts, int64_t n, int ld,
                                                      const float* __restrict__ dbox, int64_t* __restrict__ codes,
-                                                     int curve, int BITS, int narrow) {
+                                                     int curve, int BITS, int narrow, int32_t* __restrict__ zero_buf = nullptr,
+                                                     int64_t zero_words = 0) {
+  // (rides along: a buffer the NEXT kernels of the index build add into - the density grid - is zeroed here instead of
+  // by a fill launch of its own, 5 us on the critical path of a 157 us build)
+  if (zero_buf != nullptr)
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < zero_words; j += (int64_t)gridDim.x * blockDim.x)
+      zero_buf[j] = 0;
   // curve 0: Morton (Z-order) codes; 1: Hilbert codes (Skilling's axes-to-transpose transform, then the same
   // bit interleave) - consecutive codes are neighbours in space, so 16 consecutive points make tighter leaves.
   // BITS per axis (flooder_curve_key_bits(dim) / dim): the radix sort of the codes costs one pass per 8 key bits
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256) void gather_leaf_kernel(const float* __restric
         }
         const int64_t left = n - j;
         atomicAdd(&dens[cell], (int)(left < LEAF ? left : LEAF));
+
       }
     }
   }
@@ -278,9 +285,22 @@ __global__ __launch_bounds__(256) void gather_leaf_kernel(const float* __restric
 
 template <int DIM>
 __global__ __launch_bounds__(256) void bvh_inner_kernel(const float* __restrict__ child, int64_t n_child,
-                                                        int64_t n_nodes_pad, float* __restrict__ nodes) {
+                                                        int64_t n_nodes_pad, float* __restrict__ nodes,
+                                                        int32_t* __restrict__ dens = nullptr, int kind_phase = 0,
+                                                        int kind_block0 = 0) {
   // one WAVE per node: lane = child box, 2 x DIM wave reductions (the 64 child boxes are one coalesced read)
   constexpr int DP = padded_dim(DIM);
+  if constexpr (DIM == 2 || DIM == 3) {
+    // sixteen spare workgroups behind the node builders of the level-1 launch: the cloud-kind statistic of the density
+    // grid (flood_common.hpp) - no launch of its own
+    if (kind_phase != 0 && (int)blockIdx.x >= kind_block0) {
+      __shared__ int s_own[256];
+      __shared__ int s_red[8];
+      cloud_kind_block<DIM>(dens, dens + (DIM == 2 ? 256 * 256 : 64 * 64 * 64), (int)blockIdx.x - kind_block0, threadIdx.x, s_own,
+                            s_red);
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= n_nodes_pad) return;
@@ -718,11 +738,12 @@ __global__ __launch_bounds__(256) void sweep_bvh_kernel(
 // ------------------------------------------------------------------------------------ host ops
 template <int DIM>
 struct MortonOp {
-  static int run(const float* pts, int64_t n, int ld, const float* box, int64_t* codes, hipStream_t st) {
+  static int run(const float* pts, int64_t n, int ld, const float* box, int64_t* codes, int32_t* zero_buf,
+                 int64_t zero_words, hipStream_t st) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((morton_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, box, codes, g_curve,
-                       curve_bits_per_axis(DIM), curve_bits_per_axis(DIM) * DIM <= 32 ? 1 : 0);
+                       curve_bits_per_axis(DIM), curve_bits_per_axis(DIM) * DIM <= 32 ? 1 : 0, zero_buf, zero_words);
     return check_launch("morton");
   }
 };
@@ -788,8 +809,11 @@ struct IndexRowsOp {
                        n_rows_all, nodes + lv.off[0] * 2 * DP, dens, cbox, dens_g);
     for (int l = 1; l < lv.n_levels; ++l) {
       int64_t pad = (lv.count[l] + FAN - 1) / FAN * FAN;
-      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3((unsigned)((pad + 3) / 4)), dim3(256), 0, st,
-                         nodes + lv.off[l - 1] * 2 * DP, lv.count[l - 1], pad, nodes + lv.off[l] * 2 * DP);
+      const unsigned nb = (unsigned)((pad + 3) / 4);
+      // (the cloud-kind statistic rides in sixteen spare workgroups of the first of these launches: flood_common.hpp)
+      const int phase = (dens != nullptr && l == 1) ? 1 : 0;
+      hipLaunchKernelGGL((bvh_inner_kernel<DIM>), dim3(nb + (phase == 1 ? 16u : 0u)), dim3(256), 0, st,
+                         nodes + lv.off[l - 1] * 2 * DP, lv.count[l - 1], pad, nodes + lv.off[l] * 2 * DP, dens, phase, (int)nb);
     }
     return check_launch("index_rows");
   }
@@ -871,7 +895,16 @@ int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const f
   if (n_pts == 0) return FLOODER_OK;
   if (!pts || !box || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM)
     return fail(FLOODER_E_ARG, "flooder_morton_f32: bad argument");
-  return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, (hipStream_t)stream);
+  return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, (int32_t*)nullptr, (int64_t)0, (hipStream_t)stream);
+}
+
+int flooder_morton_zero_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
+                            int32_t* zero_buf, int64_t zero_words, void* stream) {
+  if (n_pts == 0) return FLOODER_OK;
+  if (!pts || !box || !codes || n_pts < 0 || ld < dim || dim < 1 || dim > FLOODER_MAX_DIM || zero_words < 0 ||
+      (zero_words > 0 && !zero_buf))
+    return fail(FLOODER_E_ARG, "flooder_morton_zero_f32: bad argument");
+  return dispatch_dim<MortonOp>(dim, pts, n_pts, ld, box, codes, zero_buf, zero_words, (hipStream_t)stream);
 }
 
 int flooder_curve_key_bits(int dim) {

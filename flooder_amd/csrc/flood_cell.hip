@@ -61,6 +61,8 @@ struct DensGrid {
   int min_count = 16;             // the grid is used where every probed cell holds at least this many points
   int one_pass = 125;             // (rides along: single-pass exhaustive evaluation of dense chunks, see the kernel;
                                   // percent of the give-up cap the extrapolated kept set may reach, 0 = off)
+  int surface_pct = 0;            // (rides along: one cell size per chunk when fewer than this percentage of the cloud's
+                                  // points sit in interior cells of the grid - the words behind it, cloud_kind_kernel)
 };
 template <int DIM>
 struct DensCfg {
@@ -976,7 +978,15 @@ __global__ __launch_bounds__(256, FLOODER_CELL_WAVES) void cell_sweep_kernel(Cel
       // its chunks would try on their own - leave those to the per-chunk pass)
       if (give_up || n0 == 0 || (float)n0 * grow > (float)ARG(dl.n0_limit)) { defer_all_fresh(); continue; }
     }
-    const int max_tries = SUPER ? 1 : ARG(max_tries);
+    int max_tries = SUPER ? 1 : ARG(max_tries);
+    if constexpr (!SUPER) {
+      const int spct = ARG(dg.surface_pct);
+      if (spct > 0 && dg.grid != nullptr) {   // a cloud on a surface: the doubled cell size does not pay (flood_common.hpp)
+        const int32_t* kind = dg.grid + DensCfg<DIM>::NF;
+        const int inner = __builtin_amdgcn_readfirstlane(kind[2]), all = __builtin_amdgcn_readfirstlane(kind[3]);
+        if (all > 0 && (long long)inner * 100 < (long long)all * spct) max_tries = 1;
+      }
+    }
     for (int attempt = seeded ? 1 : 0; attempt < max_tries && !give_up; ++attempt) {
       c = __builtin_fmaxf(c, ext / (float)(G - 3));
       const float inv_c = 1.f / c;
@@ -1692,6 +1702,7 @@ struct CellOp {
       if (!g_cell_density_grid) dg = DensGrid{};
       dg.min_count = g_cell_density_grid;
       dg.one_pass = g_cell_one_pass;
+      dg.surface_pct = g_cell_surface_pct;
       // persistent blocks of 4 independent waves: 3 per CU fit, but a short queue is swept faster by fewer
       // waves (its longest chunks then share their SIMD with fewer others): about 48 chunks per block,
       // measured on 1/4 and 1/8 shares of cfg 2
@@ -2104,9 +2115,9 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
 }
 
 
-int64_t flooder_density_grid_words(int dim) {
-  if (dim == 2) return DensCfg<2>::NF;
-  if (dim == 3) return DensCfg<3>::NF;
+int64_t flooder_density_grid_words(int dim) {   // (the grid, then four words about it: cloud_kind_kernel)
+  if (dim == 2) return DensCfg<2>::NF + KIND_WORDS;
+  if (dim == 3) return DensCfg<3>::NF + KIND_WORDS;
   return 0;
 }
 
@@ -2124,6 +2135,13 @@ int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const f
                        n_leaves, cloud_box, grid);
   }
   return check_launch("density_grid");
+}
+
+
+int flooder_cloud_kind(int32_t* density_grid, int dim, void* stream) {
+  if (!density_grid || (dim != 2 && dim != 3)) return fail(FLOODER_E_ARG, "flooder_cloud_kind: bad argument (dim 2 and 3 only)");
+  launch_cloud_kind(dim, density_grid, (hipStream_t)stream);
+  return check_launch("cloud_kind");
 }
 
 }  // extern "C"

@@ -49,6 +49,7 @@ extern int g_cell_retry_keep;  // ... and the attempt may have kept at most this
 extern int g_cell_retry_pct;  // share (percent) of a chunk's open samples that must have a point within twice the cell size for a second try (0: always)
 extern int g_finish_items_cap;
 extern int g_finish_budget_min;  // leaves a tile of a SHORT list may evaluate before it counts as hard
+extern int g_cell_surface_pct;    // cell sweep: one cell size per chunk on clouds with less than this percentage of their points in interior cells of the density grid (0: never)
 extern int g_finish_wide_points;  // clouds of at least this many points run the finish's per-wave passes with 8 waves per workgroup (0: never)
 extern int g_finish_budget;  // scale of the leaf budget beyond which a tile of the finish counts as hard (0: off)
 extern int g_finish_top;     // 1: the finish settles one sample per simplex (its largest bound) before everything else
@@ -317,6 +318,94 @@ int dispatch_dim(int dim, Args&&... args) {
     case 8: return F<8>::run(args...);
     default: return fail(FLOODER_E_ARG, "dim must be in 1..8");
   }
+}
+
+
+// ---- what kind of cloud is this?  Four words behind the density grid (flooder_density_grid_words counts them): [2] =
+// points in INTERIOR cells of a COARSE grid (16^3 / 64^2: four fine cells per axis pooled) - occupied cells whose axis
+// neighbours inside the grid are all occupied -, [3] = all points.  A cloud that fills a volume (Gaussian, swiss
+// cheese; 20 k to 16 M points) has 91 - 99 % of its points in interior cells, one that lies on a surface (the noisy
+// torus) 7 - 21 %: there a second, doubled cell size per chunk of the cell sweep keeps thousands of points for samples
+// the finish settles sooner (cfg 3 3.88 -> 3.75 ms with one try; cfg 2 1.18 -> 1.20) - the sweep reads the two words
+// and decides (option "cell_surface_pct").  Results do not depend on it.  (The fine grid itself will not do: at a
+// million points it holds a quarter of a leaf per cell, and a uniform cloud looks as hollow as a surface.)
+// 16 workgroups of 256 threads, no communication between them: workgroup b owns the coarse slab z = b (3-D; in the
+// plane: rows 4b .. 4b+3), a thread pools its own cell AND its two neighbours along z (y) - 48 (12) vector loads in
+// flight together, one memory round trip -, the neighbours along the other axes come from the workgroup's LDS; two
+// atomics per workgroup.  flooder_index_rows_f32 lets them ride in spare workgroups of the launch that builds the
+// first inner tree level (a launch of their own after the index: +17 us; on a side stream: +40 us of cross-stream
+// dependencies; coarse counts added atomically by the leaf pass: +46 us on the Gaussian, whose dense core hits a few
+// hundred addresses: all measured); flooder_cloud_kind is the stand-alone form.
+constexpr int KIND_WORDS = 4;
+template <int DIM>
+__device__ __forceinline__ void cloud_kind_block(const int32_t* __restrict__ fine, int32_t* __restrict__ kind, int block, int tid,
+                                                 int* s_own, int* s_red) {
+  constexpr int G = DIM == 2 ? 64 : 16;      // coarse cells per axis
+  constexpr int GF = 4 * G;                  // fine cells per axis
+  // coarse cell of this thread: (cx, cy [, cz]); the axis handled through the thread's own extra sums is the LAST one
+  // in 3-D (z = block) and y in the plane (y = 4 * block + tid / 64)
+  const int cx = DIM == 3 ? (tid & 15) : (tid & 63);
+  const int cy = DIM == 3 ? (tid >> 4) : (4 * block + (tid >> 6));
+  const int cz = DIM == 3 ? block : 0;
+  const int own_axis = DIM == 3 ? cz : cy;
+  int4 r[3][DIM == 3 ? 16 : 4];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int a = own_axis + d - 1;          // the pooled cell along the own axis: below, own, above
+    const bool ok = a >= 0 && a < G;
+    if constexpr (DIM == 3) {
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          r[d][4 * z + y] = ok ? *reinterpret_cast<const int4*>(fine + ((4 * a + z) * GF + (4 * cy + y)) * GF + 4 * cx)
+                               : int4{0, 0, 0, 0};
+    } else {
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+        r[d][y] = ok ? *reinterpret_cast<const int4*>(fine + (4 * a + y) * GF + 4 * cx) : int4{0, 0, 0, 0};
+    }
+  }
+  int sum[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < (DIM == 3 ? 16 : 4); ++q) t += r[d][q].x + r[d][q].y + r[d][q].z + r[d][q].w;
+    sum[d] = t;
+  }
+  s_own[tid] = sum[1];
+  __syncthreads();
+  const int c = sum[1];
+  bool in = c > 0;
+  in = in && (own_axis == 0 || sum[0] > 0) && (own_axis == G - 1 || sum[2] > 0);
+  in = in && (cx == 0 || s_own[tid - 1] > 0) && (cx == G - 1 || s_own[tid + 1] > 0);
+  if constexpr (DIM == 3) in = in && (cy == 0 || s_own[tid - 16] > 0) && (cy == 15 || s_own[tid + 16] > 0);
+  int inner = in ? c : 0, all = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    inner += __shfl_xor(inner, o);
+    all += __shfl_xor(all, o);
+  }
+  if ((tid & 63) == 0) { s_red[tid >> 6] = inner; s_red[4 + (tid >> 6)] = all; }
+  __syncthreads();
+  if (tid == 0) {
+    const int a = s_red[0] + s_red[1] + s_red[2] + s_red[3], b = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    if (b != 0) {
+      atomicAdd(&kind[2], a);
+      atomicAdd(&kind[3], b);
+    }
+  }
+}
+template <int DIM>
+__global__ __launch_bounds__(256) void cloud_kind_kernel(const int32_t* __restrict__ fine, int32_t* __restrict__ kind) {
+  __shared__ int s_own[256];
+  __shared__ int s_red[8];
+  cloud_kind_block<DIM>(fine, kind, blockIdx.x, threadIdx.x, s_own, s_red);
+}
+inline void launch_cloud_kind(int dim, int32_t* grid, hipStream_t st) {   // grid: the fine grid; the words sit behind it
+  if (dim == 2) hipLaunchKernelGGL((cloud_kind_kernel<2>), dim3(16), dim3(256), 0, st, grid, grid + 256 * 256);
+  else if (dim == 3) hipLaunchKernelGGL((cloud_kind_kernel<3>), dim3(16), dim3(256), 0, st, grid, grid + 64 * 64 * 64);
 }
 
 }  // namespace flooder

@@ -663,6 +663,10 @@ int flooder_set_option(const char* name, int value) {
     g_finish_budget_min = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "cell_surface_pct") == 0 && value >= 0 && value <= 100) {
+    g_cell_surface_pct = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "finish_wide_points") == 0 && value >= 0) {
     g_finish_wide_points = value;
     return FLOODER_OK;

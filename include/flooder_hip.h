@@ -172,6 +172,10 @@ int flooder_bbox_reduce_f32(const float* partial, int n_partial, int dim, float*
  * 16-point leaves of the box tree are tight - the tree sweep of cfg 2 takes 3.3 ms instead of 6.5 ms. */
 int flooder_morton_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
                        void* stream);
+/* The same, and `zero_words` int32 words at `zero_buf` are set to zero on the way: the density grid that the kernels of
+ * flooder_index_rows_f32 - enqueued behind this one - add into, without a fill launch of its own. */
+int flooder_morton_zero_f32(const float* pts, int64_t n_pts, int dim, int ld, const float* box, int64_t* codes,
+                            int32_t* zero_buf, int64_t zero_words, void* stream);
 
 /* Number of low bits a curve code of flooder_morton_f32 occupies for ambient dimension dim (bits per axis x dim;
  * option "curve_bits": bits per axis, default 8 in 3D, 12 elsewhere, at most floor(63 / dim) and 21).  When
@@ -296,10 +300,18 @@ int flooder_sweep_bvh_items_f32(const float* pts_sorted, int64_t n_pts, int dim,
 
 /* Density grid of the cloud for the cell sweep (dim 2 and 3): point counts in 64^3 (256^2) cells over the cloud's
  * box, accumulated from the leaves of the box tree (nodes: the array of flooder_index_rows_f32, leaves first).
- * grid: flooder_density_grid_words(dim) int32, ZEROED. */
+ * grid: flooder_density_grid_words(dim) int32, ZEROED - the fine grid, then four words that flooder_cloud_kind fills. */
 int64_t flooder_density_grid_words(int dim);
 int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const float* cloud_box, int32_t* grid,
                              void* stream);
+/* What kind of cloud is it?  Pools the filled density grid into 16^3 (64^2) coarse cells and counts the points in
+ * INTERIOR cells - occupied cells whose axis neighbours are all occupied: 91 - 99 % of a cloud that fills a volume
+ * (Gaussian, swiss cheese, annulus in the plane), 7 - 21 % of one that lies on a surface (the noisy torus); words [2]
+ * and [3] behind the fine grid.  The cell sweep reads them and tries ONE cell size per chunk instead of two on surface
+ * clouds (option "cell_surface_pct", 60; 0 = never): cfg 3 3.88 -> 3.75 ms.  flooder_index_rows_f32 computes the
+ * statistic itself (in spare workgroups of the launch that builds the first inner tree level); this entry point is for grids filled by flooder_density_grid_f32 (one launch; the four words must be zero).
+ * Without it the words stay zero and the sweep tries two sizes, as before round 6.  No result depends on it. */
+int flooder_cloud_kind(int32_t* density_grid, int dim, void* stream);
 
 /*
  * Cell sweep (dim 2 and 3; the default device path there).  One wave per chunk of 256 consecutive

@@ -945,3 +945,35 @@ def test_the_index_of_generate_landmarks_is_reused_by_flood_complex(dev, monkeyp
     n1 = len(built)
     fa.flood_complex(pts, lms, points_per_edge=8)
     assert len(built) == n1 + 1
+
+
+def test_cloud_kind_words_tell_a_surface_from_a_volume(dev):
+    """The statistic behind the density grid (flooder_cloud_kind / the index build): share of the points in interior
+    cells of the coarse grid - high for clouds that fill a volume, low for the torus surface; the cell sweep tries one
+    cell size per chunk on the latter (option cell_surface_pct) and the values are the same bits either way."""
+    lib = _native.load()
+    torch.manual_seed(3)
+    clouds = {"gauss": torch.randn(300_000, 3), "torus": fa.generate_noisy_torus_points_3d(300_000, seed=2),
+              "cheese": fa.generate_swiss_cheese_points(300_000, k=6, seed=5)[0]}
+    pct = {}
+    for name, p in clouds.items():
+        idx = core.PointIndex(p.to(dev))
+        k = idx.dens[64 ** 3:64 ** 3 + 4].cpu().tolist()
+        assert k[3] == 300_000
+        pct[name] = 100.0 * k[2] / k[3]
+        # the stand-alone entry point on a grid of its own gives the same words
+        grid = torch.zeros(int(lib.flooder_density_grid_words(3)), dtype=torch.int32, device=dev)
+        st = _native.current_stream_ptr(dev)
+        _native.check(lib.flooder_density_grid_f32(_native.ptr(idx.nodes), idx.n, 3, _native.ptr(idx.box), _native.ptr(grid), st), "grid")
+        _native.check(lib.flooder_cloud_kind(_native.ptr(grid), 3, st), "kind")
+        assert grid[64 ** 3 + 2:64 ** 3 + 4].cpu().tolist() == k[2:]
+    assert pct["gauss"] > 85 and pct["cheese"] > 85 and pct["torus"] < 35, pct
+    tp = clouds["torus"].to(dev)
+    lms = fa.generate_landmarks(tp, 300, start_idx=0)
+    a = fa.flood_complex(tp, lms, points_per_edge=20)
+    assert lib.flooder_set_option(b"cell_surface_pct", 0) == 0
+    try:
+        b = fa.flood_complex(tp, lms, points_per_edge=20)
+    finally:
+        assert lib.flooder_set_option(b"cell_surface_pct", 60) == 0
+    assert a == b
