@@ -54,6 +54,10 @@ WORKLOADS = {
                       "of the Delaunay triangles (BASELINE.json configs[3])",
                  gen="gauss", n=2_000_000, dim=6, n_lms=2000, ppe=8, max_dim=2, method="bvh", p_sample=2048,
                  cpu_sample=1500),
+    "torus300k": dict(desc="300k-point 3D noisy torus, 1k landmarks, points_per_edge 30 (debug: a sparser surface cloud)",
+                      gen="torus", n=300_000, dim=3, n_lms=1000, ppe=30),
+    "torus100k": dict(desc="100k-point 3D noisy torus, 1k landmarks, points_per_edge 30 (debug)",
+                      gen="torus", n=100_000, dim=3, n_lms=1000, ppe=30),
     "small": dict(desc="100k-point 3D Gaussian, 300 landmarks, points_per_edge 12 (debug)",
                   gen="gauss", n=100_000, dim=3, n_lms=300, ppe=12),
     "small6d": dict(desc="100k-point 6D Gaussian, 150 landmarks, max_dimension 2, points_per_edge 8 (debug)",

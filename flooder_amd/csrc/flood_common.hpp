@@ -71,6 +71,7 @@ extern int g_wit_max_leaves;
 extern int g_wit_max_in_pct;
 extern int g_wit_max_live_pct;
 extern int g_wit_min_bins;  // ... excess bins (of 64) the stage must hold at least
+extern int g_wit_surface_pct;  // ... and no attempt on a cloud with less than this percentage of its points in interior cells (0: always)
 // face planes of every simplex (flood_cell.hip: simplex_planes_kernel), 24 floats per simplex
 int launch_simplex_planes(int dim, const float* verts, int k1, int64_t n_simplices, float* tab, hipStream_t st);
 // the witness sweep's entry has just filled `tab` for these simplices on this stream: the cell sweep's entry, called
@@ -407,5 +408,14 @@ inline void launch_cloud_kind(int dim, int32_t* grid, hipStream_t st) {   // gri
   if (dim == 2) hipLaunchKernelGGL((cloud_kind_kernel<2>), dim3(16), dim3(256), 0, st, grid, grid + 256 * 256);
   else if (dim == 3) hipLaunchKernelGGL((cloud_kind_kernel<3>), dim3(16), dim3(256), 0, st, grid, grid + 64 * 64 * 64);
 }
+
+// flood_wit.hip: flooder_sweep_witness_f32 with the index's density grid (what flooder_fused_witness calls)
+int sweep_witness(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
+                  const float* weights, int k1, int R, int64_t n_simplices, const int32_t* coarse_rows, int n_coarse,
+                  const uint32_t* parents, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb, int n_faces,
+                  uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list, int32_t* flag_count,
+                  uint32_t* flag_key, int32_t* flag_hist, uint64_t* top, int32_t* top_list, int32_t* top_count,
+                  float* simplex_weight, int32_t* item_list, float* plane_scratch, uint64_t* stats,
+                  const int32_t* density_grid, void* stream);
 
 }  // namespace flooder

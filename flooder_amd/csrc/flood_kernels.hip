@@ -811,6 +811,10 @@ int flooder_set_option(const char* name, int value) {
     g_wit_grid = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "wit_surface_pct") == 0 && value >= 0 && value <= 100) {
+    g_wit_surface_pct = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "wit_min_bins") == 0 && value >= 1 && value <= 64) {
     g_wit_min_bins = value;
     return FLOODER_OK;

@@ -25,11 +25,11 @@ int take(const T* p, T& out, const char* who) {
 extern "C" int flooder_fused_witness(const flooder_fused_sweep_t* p, void* stream) {
   flooder_fused_sweep_t a;
   if (int rc = take(p, a, "flooder_fused_witness: bad parameter block (abi / size)")) return rc;
-  return flooder_sweep_witness_f32(a.pts_sorted, a.n_pts, a.dim, a.nodes, a.verts, a.weights, a.k1, a.R, a.n_simplices,
-                                   a.coarse_rows, a.n_coarse, a.parents, a.wit_queue, a.d2_scratch, a.memb, a.n_faces,
-                                   a.face_bits, a.face_slot, a.flag_list, a.flag_count, a.flag_key, a.flag_hist, a.top,
-                                   a.top_list, a.top_count, a.simplex_weight, a.wit_item_list, a.plane_scratch,
-                                   a.wit_stats, stream);
+  return flooder::sweep_witness(a.pts_sorted, a.n_pts, a.dim, a.nodes, a.verts, a.weights, a.k1, a.R, a.n_simplices,
+                                a.coarse_rows, a.n_coarse, a.parents, a.wit_queue, a.d2_scratch, a.memb, a.n_faces,
+                                a.face_bits, a.face_slot, a.flag_list, a.flag_count, a.flag_key, a.flag_hist, a.top,
+                                a.top_list, a.top_count, a.simplex_weight, a.wit_item_list, a.plane_scratch, a.wit_stats,
+                                a.density_grid, stream);
 }
 
 extern "C" int flooder_fused_cell(const flooder_fused_sweep_t* p, void* stream) {

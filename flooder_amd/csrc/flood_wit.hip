@@ -46,6 +46,9 @@ int g_wit_max_live_pct = 12; // ... and the share of all samples that may surviv
 int g_wit_adaptive = 0;     // 1: once half of the simplices tried had to be abandoned, only every 16th is still tried
 int g_wit_flags = 0;        // test switches: 1 = no exact pass for the open samples, 2 = rounds not shared between waves
 int g_wit_cmax_ext_pct = 60;  // ... and at most this share of the simplex's extent
+int g_wit_surface_pct = 60;   // no attempt at all on a cloud that lies on a surface (the statistic of flood_common.hpp's cloud_kind_block,
+//    // same threshold as the cell sweep's "cell_surface_pct"): every box that meets the sheet is too dense for one stage
+//    // (cfg 3: 5581 simplices tried, none handled, 52 us); 0 = always try
 }  // namespace flooder
 
 namespace {
@@ -1056,10 +1059,18 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
 constexpr int WCLASSES = 4;
 constexpr int WLIST_PER = 32;  // simplices per thread whose class is held in registers, 4 bits each (n <= 32768: one global round trip in all)
 __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict__ weight, int n, float limit,
-                                                        int32_t* __restrict__ list, int32_t* __restrict__ count) {
+                                                        int32_t* __restrict__ list, int32_t* __restrict__ count,
+                                                        const int32_t* __restrict__ kind, int surface_pct) {
   __shared__ int s_cnt[WCLASSES][16];
   __shared__ int s_base[WCLASSES + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (kind != nullptr) {   // a cloud on a surface: an empty list, the sweep's workgroups leave at once
+    const int inner = kind[2], all = kind[3];
+    if (all > 0 && (long long)inner * 100 < (long long)all * surface_pct) {
+      if (threadIdx.x == 0) count[0] = 0;
+      return;
+    }
+  }
   auto cls = [&](float w) -> int {  // 0 = heaviest; -1: not for this sweep
     if (!(w >= 0.f) || !(w <= limit)) return -1;
     return w > 0.5f * limit ? 0 : (w > 0.25f * limit ? 1 : (w > 0.125f * limit ? 2 : 3));
@@ -1146,13 +1157,14 @@ template <int DIM>
 struct WitOp {
   static int run(const float* pts, const float* nodes, const Levels& lv, const float* verts, float* plane_tab,
                  const float* weights, int k1, int R, int64_t ns, WitPlan plan, int32_t* queue, int32_t* item_list,
-                 int32_t* item_count, WitOut out, FaceAcc acc, unsigned long long* stats, hipStream_t st) {
+                 int32_t* item_count, WitOut out, FaceAcc acc, unsigned long long* stats, const int32_t* kind,
+                 hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
       const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
       if (rc != FLOODER_OK) return rc;
       planes_done_for(verts, plane_tab, ns, st);   // (the cell sweep's entry, next on this stream, need not repeat it)
       hipLaunchKernelGGL(wit_list_kernel, dim3(1), dim3(1024), 0, st, out.weight, (int)ns, (float)g_wit_weight, item_list,
-                         item_count);
+                         item_count, g_wit_surface_pct > 0 ? kind : nullptr, g_wit_surface_pct);
       const int grid = (int)(ns < g_wit_grid ? ns : g_wit_grid);
       hipLaunchKernelGGL((wit_sweep_kernel<DIM>), dim3(grid), dim3(WTHREADS), 0, st, pts, nodes, lv, verts, plane_tab, weights, k1,
                          R, ns, (float)g_wit_weight, 0.01f * (float)g_wit_cmax_pct, 0.01f * (float)g_wit_cmax_ext_pct, g_wit_min_bins, g_wit_flags, g_wit_max_open, (int)((int64_t)R * g_wit_max_live_pct / 100), (int)((int64_t)R * g_wit_max_in_pct / 100), g_wit_adaptive, g_wit_max_leaves < WLEAF ? g_wit_max_leaves : WLEAF, g_wit_max_eval, item_list, item_count, plan, queue, out, acc,
@@ -1166,18 +1178,17 @@ struct WitOp {
 
 }  // namespace
 
-extern "C" {
+namespace flooder {
 
-int flooder_wit_max_rows(void) { return WROWS; }
-int flooder_wit_max_coarse(void) { return WCOARSE; }
-
-int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
-                              const float* weights, int k1, int R, int64_t n_simplices, const int32_t* coarse_rows,
-                              int n_coarse, const uint32_t* parents, int32_t* queue, uint32_t* d2_scratch,
-                              const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
-                              int32_t* flag_list, int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist,
-                              uint64_t* top, int32_t* top_list, int32_t* top_count, float* simplex_weight,
-                              int32_t* item_list, float* plane_scratch, uint64_t* stats, void* stream) {
+// flooder_sweep_witness_f32 plus the density grid of the index (NULL: none): with it the sweep stands back on a cloud
+// that lies on a surface ("wit_surface_pct").  The parameter-block form passes the grid it holds anyway.
+int sweep_witness(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
+                  const float* weights, int k1, int R, int64_t n_simplices, const int32_t* coarse_rows, int n_coarse,
+                  const uint32_t* parents, int32_t* queue, uint32_t* d2_scratch, const uint32_t* memb, int n_faces,
+                  uint32_t* face_bits, const int32_t* face_slot, int32_t* flag_list, int32_t* flag_count,
+                  uint32_t* flag_key, int32_t* flag_hist, uint64_t* top, int32_t* top_list, int32_t* top_count,
+                  float* simplex_weight, int32_t* item_list, float* plane_scratch, uint64_t* stats,
+                  const int32_t* density_grid, void* stream) {
   if (n_simplices == 0 || R == 0) return FLOODER_OK;
   if (!pts_sorted || !nodes || !verts || !weights || !coarse_rows || !parents || !queue || !d2_scratch || !memb ||
       !face_bits || !flag_list || !flag_count || !simplex_weight || !item_list || !plane_scratch || n_pts < 1 || k1 < 1 ||
@@ -1196,7 +1207,28 @@ int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, c
   return dispatch_dim<WitOp>(dim, pts_sorted, nodes, lv, verts, plane_scratch, weights, k1, R, n_simplices,
                              WitPlan{coarse_rows, parents, n_coarse}, queue, item_list, queue + FLOODER_QUEUE_WORDS - 1,
                              WitOut{d2_scratch, flag_list, flag_count, simplex_weight}, acc,
-                             reinterpret_cast<unsigned long long*>(stats), (hipStream_t)stream);
+                             reinterpret_cast<unsigned long long*>(stats),
+                             density_grid ? density_grid + (flooder_density_grid_words(dim) - KIND_WORDS) : nullptr,
+                             (hipStream_t)stream);
+}
+
+}  // namespace flooder
+
+extern "C" {
+
+int flooder_wit_max_rows(void) { return WROWS; }
+int flooder_wit_max_coarse(void) { return WCOARSE; }
+
+int flooder_sweep_witness_f32(const float* pts_sorted, int64_t n_pts, int dim, const float* nodes, const float* verts,
+                              const float* weights, int k1, int R, int64_t n_simplices, const int32_t* coarse_rows,
+                              int n_coarse, const uint32_t* parents, int32_t* queue, uint32_t* d2_scratch,
+                              const uint32_t* memb, int n_faces, uint32_t* face_bits, const int32_t* face_slot,
+                              int32_t* flag_list, int32_t* flag_count, uint32_t* flag_key, int32_t* flag_hist,
+                              uint64_t* top, int32_t* top_list, int32_t* top_count, float* simplex_weight,
+                              int32_t* item_list, float* plane_scratch, uint64_t* stats, void* stream) {
+  return sweep_witness(pts_sorted, n_pts, dim, nodes, verts, weights, k1, R, n_simplices, coarse_rows, n_coarse, parents,
+                       queue, d2_scratch, memb, n_faces, face_bits, face_slot, flag_list, flag_count, flag_key, flag_hist,
+                       top, top_list, top_count, simplex_weight, item_list, plane_scratch, stats, nullptr, stream);
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 WIT_DEFAULTS = {"wit_max_eval": 768, "wit_max_leaves": 400, "wit_adaptive": 0, "wit_weight": 800, "wit_cmax_pct": 250, "wit_cmax_ext_pct": 60, "wit_min_bins": 48, "wit_flags": 0,
                 "wit_max_open": 48, "wit_max_live_pct": 12, "wit_max_in_pct": 8}
+WIT_SURFACE_PCT = 60   # the product's default: the witness sweep stands back on clouds that lie on a surface
 
 
 @pytest.fixture(scope="module")
@@ -26,9 +27,11 @@ def restore_options():
     keep = core.WIT_MIN_SIMPLICES, core.WIT_MAX_POINTS_PER_SIMPLEX
     core.WIT_MIN_SIMPLICES = 0    # (the product skips the witness sweep on short queues: the tests here want it run)
     core.WIT_MAX_POINTS_PER_SIMPLEX = 1 << 40   # (... and on clouds with many points per simplex)
+    assert _native.load().flooder_set_option(b"wit_surface_pct", 0) == 0   # (... and on clouds that lie on a surface)
     yield
     core.WIT_MIN_SIMPLICES, core.WIT_MAX_POINTS_PER_SIMPLEX = keep
     lib = _native.load()
+    assert lib.flooder_set_option(b"wit_surface_pct", WIT_SURFACE_PCT) == 0
     for k, v in WIT_DEFAULTS.items():
         assert lib.flooder_set_option(k.encode(), v) == 0
     core.CELL_WITNESS = True
@@ -108,6 +111,23 @@ def test_witness_sweep_takes_the_sparse_simplices_and_leaves_the_dense_ones(dev)
     lms_d = fa.generate_landmarks(dense, 300, start_idx=0)
     st_d = sweep_stats(dense, lms_d)
     assert int(st_d[0]) == 0, "a dense uniform cloud has nothing for the witness sweep"
+
+
+def test_witness_sweep_stands_back_on_a_surface_cloud(dev):
+    """Decided on the device from the density grid's cloud-kind words (flood_common.hpp): on the noisy torus no simplex
+    is tried at all with the default option, every simplex is looked at with the gate off - and the values are the same."""
+    tor = clouds("torus", 400_000).to(dev)
+    lms = fa.generate_landmarks(tor, 400, start_idx=0)
+    st_open = sweep_stats(tor, lms)
+    assert int(st_open[:4].sum()) > 0, "gate off: the sweep looks at the simplices (handled / heavy / over / dense)"
+    off = run(tor, lms, True)
+    set_options(wit_surface_pct=WIT_SURFACE_PCT)
+    st_gate = sweep_stats(tor, lms)
+    assert int(st_gate[:12].sum()) == 0, st_gate[:12]
+    assert_same(run(tor, lms, True), off, "torus: surface gate on / off")
+    gau = clouds("gauss", 300_000).to(dev)   # a volume cloud is not touched by the gate
+    lms_g = fa.generate_landmarks(gau, 500, start_idx=0)
+    assert int(sweep_stats(gau, lms_g)[0]) > 0
 
 
 def test_witness_sweep_random_weights_and_off_cloud_landmarks(dev):
