@@ -308,7 +308,8 @@ int flooder_density_grid_f32(const float* nodes, int64_t n_pts, int dim, const f
  * INTERIOR cells - occupied cells whose axis neighbours are all occupied: 91 - 99 % of a cloud that fills a volume
  * (Gaussian, swiss cheese, annulus in the plane), 7 - 21 % of one that lies on a surface (the noisy torus); words [2]
  * and [3] behind the fine grid.  The cell sweep reads them and tries ONE cell size per chunk instead of two on surface
- * clouds (option "cell_surface_pct", 60; 0 = never): cfg 3 3.88 -> 3.75 ms.  flooder_index_rows_f32 computes the
+ * clouds (option "cell_surface_pct", 60; 0 = never): cfg 3 3.88 -> 3.75 ms; flooder_fused_witness reads them too and
+ * tries no simplex at all on such a cloud (option "wit_surface_pct", 60; 0 = always try): 3.75 -> 3.70 ms.  flooder_index_rows_f32 computes the
  * statistic itself (in spare workgroups of the launch that builds the first inner tree level); this entry point is for grids filled by flooder_density_grid_f32 (one launch; the four words must be zero).
  * Without it the words stay zero and the sweep tries two sizes, as before round 6.  No result depends on it. */
 int flooder_cloud_kind(int32_t* density_grid, int dim, void* stream);
@@ -610,7 +611,9 @@ typedef struct flooder_fused_sweep_s {
 } flooder_fused_sweep_t;
 
 /* flooder_sweep_witness_f32, flooder_sweep_cell_faces_f32, flooder_finish_faces_f32 on the fields of *p (host memory;
- * read during the call only). */
+ * read during the call only).  flooder_fused_witness also hands `density_grid` (may be NULL) to the witness sweep, which
+ * then stands back on a cloud that lies on a surface (option "wit_surface_pct"); the positional function has no such
+ * argument and always tries. */
 int flooder_fused_witness(const flooder_fused_sweep_t* p, void* stream);
 int flooder_fused_cell(const flooder_fused_sweep_t* p, void* stream);
 int flooder_fused_finish(const flooder_fused_sweep_t* p, void* stream);
