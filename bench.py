@@ -531,6 +531,21 @@ def main():
     elapsed_ci, step_ms_ci, _ = timed_loop(args.steps, timer_ready, index=ready_index)
     ms_cached = elapsed_ci / args.steps * 1e3
 
+    # the host's side of the step: wall time until the LAST launch of n steps is enqueued (no synchronize inside), and the
+    # same steps without the per-span HIP events of the timed loop above (8 event records per step) - how far ahead of
+    # the GPU the Python loop runs, and what the instrumentation the roofline needs costs the headline
+    host_rec = None
+    if world == 1 and not args.emulate_shard:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        t_enq = time.perf_counter() - t0
+        sync_all()
+        t_all = time.perf_counter() - t0
+        host_rec = {"host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+                    "ms_per_step_no_span_events": round(t_all / args.steps * 1e3, 4)}
+
     # what every rank spent where (HIP events on its own stream, ms per step): index / sweep / finish / reduce spans of
     # the step with the index rebuilt and with a ready index, and its own step (the line's ms_per_step is the MAX) -
     # the first thing to read when a scaling curve disappoints
@@ -726,6 +741,7 @@ def main():
         "ms_index_build": round(ms_index, 4),
         "value_sweep_only": round(w["n"] * S_all / (ms_sweep_only * 1e-3) / 1e6, 3),
         "ms_per_step_index_ready": round(ms_cached, 4),
+        "host": host_rec,
         "value_index_ready": round(w["n"] * S_all / (ms_cached * 1e-3) / 1e6, 3),
         "cold_step_ms": None if cold_ms is None else round(cold_ms, 4),
         "step_definition": "raw cloud + simplices in HBM -> index build (Hilbert sort + box tree) -> sweep -> exact "

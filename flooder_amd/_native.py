@@ -102,6 +102,9 @@ SIGNATURES = {
     "flooder_curve_key_bits": (c_int, [c_int]),
     "flooder_index_sort_bytes": (c_int64, [c_int64]),
     "flooder_index_sort": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "flooder_index_sort_state_words": (c_int64, [c_int64, c_int]),
+    "flooder_index_sort_zeroed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                          c_void_p]),
     "flooder_kd_order_bytes": (c_int64, [c_int64]),
     "flooder_kd_order_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "flooder_select_grid_bytes": (c_int64, [c_int]),
@@ -132,6 +135,8 @@ SIGNATURES = {
     "flooder_wit_max_coarse": (c_int, []),
     "flooder_face_values_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "flooder_simplex_weight_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "flooder_simplex_prepare_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_int64, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flooder_fill_u32": (c_int, [c_void_p, c_int64, c_uint32, c_void_p]),
     "flooder_gather_rows_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -63,7 +63,7 @@ def _build_hip_to(HIP_LIB: str, force: bool, verbose: bool) -> str:
 
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     hdrs = [os.path.join(ROOT, "include", "flooder_hip.h"), os.path.join(CSRC, "flood_common.hpp"),
-            os.path.join(CSRC, "flood_bvh.hpp")]
+            os.path.join(CSRC, "flood_bvh.hpp"), os.path.join(CSRC, "flood_planes.hpp")]
     if not force and _newer(HIP_LIB, srcs + hdrs):
         return HIP_LIB
     extra = os.environ.get("FLOODER_HIPCC_FLAGS", "").split()

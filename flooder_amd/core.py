@@ -599,6 +599,10 @@ def forget_index() -> None:
     _LAST_INDEX[:] = [None, None, None]
 
 
+SWEEP_PREPARE_FUSED = True    # fused 2-D / 3-D sweep: zero fill + simplex weights + plane rows in one launch
+SORT_STATE_BY_CALLER = True   # the index's radix sort on state zeroed by the curve-code kernel (no fill launches)
+
+
 class PointIndex:
     """Copy of a point set sorted along a space-filling curve (Hilbert by default) plus its implicit box tree
     (HBM resident).
@@ -637,12 +641,18 @@ class PointIndex:
                                                        _native.ptr(tmp), tmp_bytes, st), "flooder_kd_order_f32")
         else:
             codes = torch.empty(n, dtype=torch.int64, device=dev)
-            if dim in (2, 3) and CELL_DENSITY_GRID:   # (zeroed by the curve-code kernel on its way: no fill launch)
-                dens = torch.empty(int(lib.flooder_density_grid_words(dim)), dtype=torch.int32, device=dev)
+            key_bits = int(lib.flooder_curve_key_bits(dim))
+            # one buffer the curve-code kernel zeroes on its way (no fill launch): the density grid of the cell sweep
+            # and the state of the radix sort (its histograms, look-back arrays, block tickets: flooder_index_sort_zeroed)
+            n_dens = int(lib.flooder_density_grid_words(dim)) if dim in (2, 3) and CELL_DENSITY_GRID else 0
+            n_state = int(lib.flooder_index_sort_state_words(n, key_bits)) if SORT_STATE_BY_CALLER else 0
+            zeroed = torch.empty(n_dens + n_state, dtype=torch.int32, device=dev) if n_dens + n_state else None
+            dens = zeroed[:n_dens] if n_dens else None
+            sort_state = zeroed[n_dens:] if n_state else None
             with _span(timer, "morton"):
                 _native.check(lib.flooder_morton_zero_f32(_native.ptr(pts32), n, dim, dim, _native.ptr(self.box),
-                                                          _native.ptr(codes), _native.ptr(dens),
-                                                          0 if dens is None else dens.numel(), st), "flooder_morton_zero_f32")
+                                                          _native.ptr(codes), _native.ptr(zeroed),
+                                                          0 if zeroed is None else zeroed.numel(), st), "flooder_morton_zero_f32")
             # radix sort over the bits the codes use
             codes_sorted = torch.empty(n, dtype=torch.int64, device=dev)
             tmp_bytes = int(lib.flooder_index_sort_bytes(n))
@@ -650,9 +660,14 @@ class PointIndex:
                 raise RuntimeError("flooder_index_sort_bytes failed")
             tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
             with _span(timer, "sort"):
-                _native.check(lib.flooder_index_sort(_native.ptr(codes), n, int(lib.flooder_curve_key_bits(dim)),
-                                                     _native.ptr(codes_sorted), _native.ptr(self.order32), _native.ptr(tmp),
-                                                     tmp_bytes, st), "flooder_index_sort")
+                if sort_state is not None:
+                    _native.check(lib.flooder_index_sort_zeroed(_native.ptr(codes), n, key_bits, _native.ptr(codes_sorted),
+                                                                _native.ptr(self.order32), _native.ptr(tmp), tmp_bytes,
+                                                                _native.ptr(sort_state), st), "flooder_index_sort_zeroed")
+                else:
+                    _native.check(lib.flooder_index_sort(_native.ptr(codes), n, key_bits, _native.ptr(codes_sorted),
+                                                         _native.ptr(self.order32), _native.ptr(tmp), tmp_bytes, st),
+                                  "flooder_index_sort")
         n_pad = (n + BVH_LEAF - 1) // BVH_LEAF * BVH_LEAF
         self.pts = torch.empty((n_pad, self.dp), dtype=torch.float32, device=dev)
         n_nodes = int(lib.flooder_bvh_node_count(n))
@@ -1276,8 +1291,11 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         # measured on an eighth of cfg 2: 0.65 ms per rank with it, 0.55 without)
         use_wit = (CELL_WITNESS and CELL_SUPER and CELL_PROBE and index.dim in (2, 3) and S >= WIT_MIN_SIMPLICES
                    and index.n <= WIT_MAX_POINTS_PER_SIMPLEX * S and plan.wit is not None)
-        zeroed = torch.zeros((1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots,
-                             dtype=torch.int32, device=dev)
+        # (with the simplex weights wanted, the launch that computes them clears these words and writes the plane rows on
+        # its way - flooder_simplex_prepare_f32 below -: one launch instead of three)
+        n_zeroed = (1 if use_wit else 0) * QUEUE_WORDS + 6 * QUEUE_WORDS + 24 + 2 * S + 48 + 8192 + n_slots
+        zeroed = (torch.empty if CELL_SUPER and SWEEP_PREPARE_FUSED else torch.zeros)(n_zeroed, dtype=torch.int32, device=dev)
+        zeroed_all = zeroed
         if use_wit:
             qwit = zeroed[:QUEUE_WORDS]
             zeroed = zeroed[QUEUE_WORDS:]
@@ -1299,8 +1317,14 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
         split = torch.empty((2, S), dtype=torch.int32, device=dev) if CELL_SUPER else None  # light / heavy simplices
         if CELL_SUPER:  # rough point count per simplex box: dense simplices skip the run-of-four launch
             wgt = torch.empty(S, dtype=torch.float32, device=dev)
-            _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
-                                                         k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
+            if SWEEP_PREPARE_FUSED:
+                _native.check(lib.flooder_simplex_prepare_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
+                                                              k1, S, _native.ptr(wgt), _native.ptr(planes),
+                                                              _native.ptr(zeroed_all), n_zeroed, st),
+                              "flooder_simplex_prepare_f32")
+            else:
+                _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, index.dim, _native.ptr(verts),
+                                                             k1, S, _native.ptr(wgt), st), "flooder_simplex_weight_f32")
         # ONE parameter block for the three launches (include/flooder_hip.h: flooder_fused_sweep_t): they share the cloud,
         # the lattice, the result words and most of the scratch
         wst = stats[16:40] if use_wit and stats is not None and stats.numel() >= 40 else None

@@ -20,6 +20,7 @@
 
 #include "flood_common.hpp"
 #include "flood_bvh.hpp"
+#include "flood_planes.hpp"
 
 using namespace flooder;
 
@@ -809,16 +810,31 @@ namespace {
 
 constexpr int WFRONT = 256;
 
+// The same launch PREPARES a fused sweep (flooder_simplex_prepare_f32): every thread clears its share of `zero_buf` (the
+// control words, queue heads and face words the three launches of the sweep start from - torch.zeros was a launch of
+// its own), and the blocks behind the first `weight_blocks` write the face-plane rows (flood_planes.hpp - a launch of
+// its own in front of the witness / cell sweep).  Three launches in one: ~8 us of cfg 2's step.
 template <int DIM>
 __global__ __launch_bounds__(256) void simplex_weight_kernel(const float* __restrict__ nodes, Levels lv,
                                                              const float* __restrict__ verts, int k1,
-                                                             int64_t n_simplices, float* __restrict__ weight) {
+                                                             int64_t n_simplices, float* __restrict__ weight,
+                                                             int weight_blocks, float* __restrict__ plane_tab,
+                                                             int32_t* __restrict__ zero_buf, int64_t zero_words) {
   constexpr int DP = padded_dim(DIM);
   __shared__ int s_front[4][2][WFRONT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int topl = lv.n_levels - 1;
   const int stop = topl >= 1 ? 1 : 0;
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wv; s < n_simplices; s += (int64_t)gridDim.x * 4) {
+  if (zero_buf != nullptr)
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < zero_words; j += (int64_t)gridDim.x * 256) zero_buf[j] = 0;
+  if ((int)blockIdx.x >= weight_blocks) {   // (plane rows: one simplex per thread)
+    if constexpr (DIM == 2 || DIM == 3) {
+      const int64_t s = (int64_t)((int)blockIdx.x - weight_blocks) * 256 + threadIdx.x;
+      if (s < n_simplices) simplex_planes_row<DIM>(verts, k1, s, plane_tab);
+    }
+    return;
+  }
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wv; s < n_simplices; s += (int64_t)weight_blocks * 4) {
     float blo[DIM], bhi[DIM];
     const float* vs = verts + s * (int64_t)k1 * DIM;
 #pragma unroll
@@ -886,10 +902,15 @@ __global__ __launch_bounds__(256) void simplex_weight_kernel(const float* __rest
 template <int DIM>
 struct WeightOp {
   static int run(const float* nodes, const Levels& lv, const float* verts, int k1, int64_t ns, float* weight,
-                 hipStream_t st) {
+                 float* plane_tab, int32_t* zero_buf, int64_t zero_words, hipStream_t st) {
     int64_t blocks = (ns + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((simplex_weight_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, nodes, lv, verts, k1, ns, weight);
+    int64_t plane_blocks = 0;
+    if constexpr (DIM == 2 || DIM == 3) plane_blocks = plane_tab ? (ns + 255) / 256 : 0;
+    else if (plane_tab) return fail(FLOODER_E_ARG, "flooder_simplex_prepare_f32: plane rows only in dim 2 and 3");
+    hipLaunchKernelGGL((simplex_weight_kernel<DIM>), dim3((int)(blocks + plane_blocks)), dim3(256), 0, st, nodes, lv, verts,
+                       k1, ns, weight, (int)blocks, plane_tab, zero_buf, zero_words);
+    if (plane_blocks) planes_done_for(verts, plane_tab, ns, st);   // (the sweep's entries need not launch theirs)
     return check_launch("simplex_weight");
   }
 };
@@ -902,5 +923,18 @@ extern "C" int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int
   if (!nodes || !verts || !weight || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS)
     return fail(FLOODER_E_ARG, "flooder_simplex_weight_f32: bad argument");
   const Levels lv = make_levels(n_pts);
-  return dispatch_dim<WeightOp>(dim, nodes, lv, verts, k1, n_simplices, weight, (hipStream_t)stream);
+  return dispatch_dim<WeightOp>(dim, nodes, lv, verts, k1, n_simplices, weight, (float*)nullptr, (int32_t*)nullptr,
+                                (int64_t)0, (hipStream_t)stream);
+}
+
+extern "C" int flooder_simplex_prepare_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
+                                           int64_t n_simplices, float* weight, float* plane_scratch, int32_t* zero_buf,
+                                           int64_t zero_words, void* stream) {
+  if (n_simplices == 0 && zero_words == 0) return FLOODER_OK;
+  if (!nodes || !verts || !weight || n_pts < 1 || k1 < 1 || k1 > FLOODER_MAX_VERTS || n_simplices < 1 || zero_words < 0 ||
+      (zero_words > 0 && !zero_buf))
+    return fail(FLOODER_E_ARG, "flooder_simplex_prepare_f32: bad argument");
+  const Levels lv = make_levels(n_pts);
+  return dispatch_dim<WeightOp>(dim, nodes, lv, verts, k1, n_simplices, weight, plane_scratch, zero_buf, zero_words,
+                                (hipStream_t)stream);
 }

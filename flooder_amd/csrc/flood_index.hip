@@ -526,7 +526,9 @@ int64_t flooder_index_sort_bytes(int64_t n_pts) {
   e = rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes32, k32, ko32, rocprim::counting_iterator<uint32_t>(0u), vo,
                                 (size_t)n_pts, 0u, 32u, (hipStream_t)0);
   if (e != hipSuccess) return -1;
-  return (int64_t)(bytes > bytes32 ? bytes : bytes32) + 256;
+  const size_t own = (size_t)n_pts * 8;   // (flooder_index_sort_zeroed: keys and row numbers of the odd passes)
+  bytes = bytes > bytes32 ? bytes : bytes32;
+  return (int64_t)(bytes > own ? bytes : own) + 256;
 }
 
 int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
@@ -548,6 +550,107 @@ int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_
                                   (hipStream_t)stream);
   if (e != hipSuccess) return fail(FLOODER_E_LAUNCH, hipGetErrorString(e));
   return check_launch("index_sort");
+}
+
+}  // extern "C"
+
+// ---- the same sort without its seven fill launches ------------------------------------------------------------------
+// rocprim::radix_sort_pairs resets its state on the way: the digit histograms once, and per 8-bit pass the look-back
+// states of the decoupled scan and the ticket counter that hands out block numbers - seven memset launches of ~4 us for
+// the three passes of a 24-bit curve code, a sixth of cfg 2's index build.  flooder_index_sort_zeroed launches the
+// library's own device functions (rocprim::detail::onesweep_histograms / onesweep_scan_histograms / onesweep_iteration,
+// the tuned gfx950 configuration: same kernels, same stable order, same bits) on state the CALLER has zeroed - the
+// curve-code kernel does it on its way (flooder_morton_zero_f32's zero_buf) - with one look-back array and one
+// ticket per pass.  Narrow keys (<= 32 bits), values = row numbers, fewer than 2^30 rows; anything else: flooder_index_sort.
+namespace {
+namespace rpd = rocprim::detail;
+constexpr rpd::radix_sort_onesweep_config_params OSP =
+    rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint32_t, uint32_t>::architecture_config<
+        rpd::target_arch::gfx950>::params;
+constexpr unsigned OS_BITS = OSP.radix_bits_per_place, OS_RADIX = 1u << OS_BITS;
+constexpr unsigned OS_HB = OSP.histogram.block_size, OS_HI = OSP.histogram.items_per_thread;
+constexpr unsigned OS_SB = OSP.sort.block_size, OS_SI = OSP.sort.items_per_thread;
+using OsTicket = rpd::block_id_wrapper<unsigned int, true>;   // (gfx950: blocks take their number from an atomic ticket)
+static_assert(sizeof(rpd::onesweep_lookback_state) == sizeof(uint32_t), "one word per look-back state");
+
+__global__ __launch_bounds__(OS_HB) void os_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
+                                                             uint32_t n, uint32_t full_blocks, unsigned end_bit) {
+  rpd::onesweep_histograms<OS_HB, OS_HI, OS_BITS, false>(keys, counts, n, full_blocks, rocprim::identity_decomposer{}, 0u,
+                                                         end_bit);
+}
+
+__global__ __launch_bounds__(OS_HB) void os_scan_kernel(uint32_t* __restrict__ counts) {
+  rpd::onesweep_scan_histograms<OS_HB, OS_BITS>(counts);
+}
+
+template <class ValuesIn>
+__global__ __launch_bounds__(OS_SB) void os_pass_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
+                                                        ValuesIn values_in, uint32_t* __restrict__ values_out, uint32_t n,
+                                                        uint32_t* offsets, uint32_t* offsets_out,
+                                                        rpd::onesweep_lookback_state* states, unsigned bit,
+                                                        unsigned bits_now, uint32_t full_blocks, OsTicket ticket) {
+  rpd::onesweep_iteration<OS_SB, OS_SI, OS_BITS, false, OSP.radix_rank_algorithm>(
+      keys_in, keys_out, values_in, values_out, n, offsets, offsets_out, states, rocprim::identity_decomposer{}, bit,
+      bits_now, full_blocks, ticket);
+}
+
+inline unsigned os_places(int key_bits) { return ((unsigned)key_bits + OS_BITS - 1) / OS_BITS; }
+inline uint32_t os_blocks(int64_t n) { return (uint32_t)((n + (int64_t)OS_SB * OS_SI - 1) / ((int64_t)OS_SB * OS_SI)); }
+}  // namespace
+
+extern "C" {
+
+int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits) {
+  if (n_pts < 1 || n_pts >= (1LL << 30) || key_bits < 1 || key_bits > 32) return 0;   // (0: use flooder_index_sort)
+  const int64_t places = os_places(key_bits);
+  // histograms of every digit place | one look-back array per pass | one ticket per pass | the last block's offsets
+  return places * OS_RADIX + places * (int64_t)OS_RADIX * os_blocks(n_pts) + places + OS_RADIX;
+}
+
+int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
+                              void* tmp, int64_t tmp_bytes, int32_t* state, void* stream) {
+  if (n_pts == 0) return FLOODER_OK;
+  if (!codes || !codes_sorted || !order || !tmp || !state || n_pts < 0 || n_pts >= (1LL << 30) || key_bits < 1 ||
+      key_bits > 32 || tmp_bytes < 8 * n_pts || (reinterpret_cast<uintptr_t>(tmp) & 3u))
+    return fail(FLOODER_E_ARG, "flooder_index_sort_zeroed: bad argument (narrow keys, fewer than 2^30 rows, 8 n bytes of tmp)");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)n_pts;
+  const unsigned places = os_places(key_bits);
+  const uint32_t blocks = os_blocks(n_pts);
+  const uint32_t full_blocks = n % (OS_SB * OS_SI) == 0 ? blocks : blocks - 1;
+  uint32_t* counts = reinterpret_cast<uint32_t*>(state);
+  auto* states = reinterpret_cast<rpd::onesweep_lookback_state*>(counts + places * OS_RADIX);
+  uint32_t* tickets = counts + places * OS_RADIX + (size_t)places * OS_RADIX * blocks;
+  uint32_t* offsets_out = tickets + places;
+  const uint32_t* keys_in = reinterpret_cast<const uint32_t*>(codes);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(codes_sorted);
+  uint32_t* vals_out = reinterpret_cast<uint32_t*>(order);
+  uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(tmp);
+  uint32_t* vals_tmp = keys_tmp + n;
+  {
+    const uint32_t hb = (uint32_t)(((int64_t)n + OS_HB * OS_HI - 1) / (OS_HB * OS_HI));
+    const uint32_t hfull = n % (OS_HB * OS_HI) == 0 ? hb : hb - 1;
+    hipLaunchKernelGGL(os_histogram_kernel, dim3(hb), dim3(OS_HB), 0, st, keys_in, counts, n, hfull, (unsigned)key_bits);
+    hipLaunchKernelGGL(os_scan_kernel, dim3(places), dim3(OS_HB), 0, st, counts);
+  }
+  bool to_output = (places - 1) % 2 == 0;   // (the last pass lands in the output arrays)
+  for (unsigned place = 0, bit = 0; place < places; ++place, bit += OS_BITS) {
+    const unsigned bits_now = (unsigned)key_bits - bit < OS_BITS ? (unsigned)key_bits - bit : OS_BITS;
+    uint32_t* ko = to_output ? keys_out : keys_tmp;
+    uint32_t* vo = to_output ? vals_out : vals_tmp;
+    OsTicket ticket = OsTicket::create(tickets + place);
+    if (place == 0)
+      hipLaunchKernelGGL((os_pass_kernel<rocprim::counting_iterator<uint32_t>>), dim3(blocks), dim3(OS_SB), 0, st, keys_in, ko,
+                         rocprim::counting_iterator<uint32_t>(0u), vo, n, counts, offsets_out, states, bit, bits_now,
+                         full_blocks, ticket);
+    else
+      hipLaunchKernelGGL((os_pass_kernel<const uint32_t*>), dim3(blocks), dim3(OS_SB), 0, st,
+                         (const uint32_t*)(to_output ? keys_tmp : keys_out), ko,
+                         (const uint32_t*)(to_output ? vals_tmp : vals_out), vo, n, counts + place * OS_RADIX, offsets_out,
+                         states + (size_t)place * OS_RADIX * blocks, bit, bits_now, full_blocks, ticket);
+    to_output = !to_output;
+  }
+  return check_launch("index_sort_zeroed");
 }
 
 int64_t flooder_kd_order_bytes(int64_t n_pts) {

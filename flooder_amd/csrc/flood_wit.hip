@@ -1053,16 +1053,21 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
 }
 
 // The simplices the witness sweep tries (0 <= weight <= limit), heaviest class first (the long items - time goes with
-// the points around a simplex - start first, the light ones fill the tail): one block, ballot scans.  A persistent
+// the points around a simplex - start first, the light ones fill the tail): one block.  A persistent
 // workgroup that pops a simplex only to find it too heavy pays an atomic round trip and two barriers for nothing -
 // 77 us per launch where every simplex is heavy.
 constexpr int WCLASSES = 4;
-constexpr int WLIST_PER = 32;  // simplices per thread whose class is held in registers, 4 bits each (n <= 32768: one global round trip in all)
+// A stable counting sort in one block: every thread owns a RUN of consecutive simplices (their weights staged in LDS by
+// coalesced loads first - a run read straight from memory is a chain of cache misses), counts its classes, one
+// block-wide exclusive scan per class (wave scans + partial sums through LDS), and writes its run: two barriers.
+// (The first version took the simplices in strides of 1024 and ran ballots and two barriers per stride: 16 us for
+// cfg 2's 6052 simplices, a launch that every step waits for.)
+constexpr int WLIST_LDS = 8192;   // weights staged; more simplices: the runs are read from memory
 __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict__ weight, int n, float limit,
                                                         int32_t* __restrict__ list, int32_t* __restrict__ count,
                                                         const int32_t* __restrict__ kind, int surface_pct) {
   __shared__ int s_cnt[WCLASSES][16];
-  __shared__ int s_base[WCLASSES + 1];
+  __shared__ float s_w[WLIST_LDS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (kind != nullptr) {   // a cloud on a surface: an empty list, the sweep's workgroups leave at once
     const int inner = kind[2], all = kind[3];
@@ -1075,81 +1080,58 @@ __global__ __launch_bounds__(1024) void wit_list_kernel(const float* __restrict_
     if (!(w >= 0.f) || !(w <= limit)) return -1;
     return w > 0.5f * limit ? 0 : (w > 0.25f * limit ? 1 : (w > 0.125f * limit ? 2 : 3));
   };
-  const int steps = (n + 1023) / 1024;
-  const bool in_regs = steps <= WLIST_PER;
-  uint32_t c_pack[WLIST_PER / 8];   // class + 1 of simplex step * 1024 + tid, 4 bits each
+  const bool staged = n <= WLIST_LDS;
+  if (staged) {
 #pragma unroll
-  for (int g = 0; g < WLIST_PER / 8; ++g) {
-    float w8[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {   // (eight loads in flight together)
-      const int i = (g * 8 + u) * 1024 + (int)threadIdx.x;
-      w8[u] = (in_regs && i < n) ? weight[i] : -1.f;
+    for (int u = 0; u < WLIST_LDS / 1024; ++u) {   // (eight loads in flight)
+      const int i = u * 1024 + (int)threadIdx.x;
+      if (i < n) s_w[i] = weight[i];
     }
-    uint32_t pk = 0u;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) pk |= (uint32_t)(cls(w8[u]) + 1) << (4 * u);
-    c_pack[g] = pk;
+    __syncthreads();
   }
-  auto class_of = [&](int step, int i) -> int {
-    if (in_regs) {
-      uint32_t pk = 0u;
+  const int per = ((n + 1023) / 1024) | 1;   // (odd: the runs start in different LDS banks)
+  const int i0 = (int)threadIdx.x * per < n ? (int)threadIdx.x * per : n;
+  const int i1 = i0 + per < n ? i0 + per : n;
+  int cnt[WCLASSES];
 #pragma unroll
-      for (int g = 0; g < WLIST_PER / 8; ++g) pk = (step >> 3) == g ? c_pack[g] : pk;
-      return (int)((pk >> (4 * (step & 7))) & 15u) - 1;
-    }
-    return i < n ? cls(weight[i]) : -1;
-  };
-  // totals per class
-  int tot[WCLASSES];
+  for (int k = 0; k < WCLASSES; ++k) cnt[k] = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int c = cls(staged ? s_w[i] : weight[i]);
 #pragma unroll
-  for (int c = 0; c < WCLASSES; ++c) tot[c] = 0;
-  for (int st = 0; st < steps; ++st) {
-    const int c = class_of(st, st * 1024 + (int)threadIdx.x);
-#pragma unroll
-    for (int k = 0; k < WCLASSES; ++k) tot[k] += c == k ? 1 : 0;
+    for (int k = 0; k < WCLASSES; ++k) cnt[k] += c == k ? 1 : 0;
   }
+  int excl[WCLASSES];   // simplices of the class in the threads before this one
 #pragma unroll
   for (int k = 0; k < WCLASSES; ++k) {
+    int v = cnt[k];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot[k] += __shfl_xor(tot[k], o);
-    if (lane == 0) s_cnt[k][wv] = tot[k];
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o);
+      v += lane >= o ? t : 0;
+    }
+    excl[k] = v - cnt[k];
+    if (lane == 63) s_cnt[k][wv] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < WCLASSES; ++k) {
-      s_base[k] = run;
-      for (int w = 0; w < 16; ++w) run += s_cnt[k][w];
+  int base = 0;   // classes in order, heaviest first
+#pragma unroll
+  for (int k = 0; k < WCLASSES; ++k) {
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_cnt[k][w];
+      before += w < wv ? c : 0;
+      total += c;
     }
-    s_base[WCLASSES] = run;
-    count[0] = run;
+    excl[k] += base + before;
+    base += total;
   }
-  __syncthreads();
-  int pos[WCLASSES];
+  if (threadIdx.x == 0) count[0] = base;
+  for (int i = i0; i < i1; ++i) {   // (order kept inside a class)
+    const int c = cls(staged ? s_w[i] : weight[i]);
 #pragma unroll
-  for (int k = 0; k < WCLASSES; ++k) pos[k] = s_base[k];
-  for (int st = 0; st < steps; ++st) {  // (order kept inside a class)
-    const int i = st * 1024 + (int)threadIdx.x;
-    const int c = class_of(st, i);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < WCLASSES; ++k) {
-      const unsigned long long m = __ballot(c == k);
-      if (lane == 0) s_cnt[k][wv] = __popcll(m);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < WCLASSES; ++k) {
-      int before = 0, total = 0;
-      for (int w = 0; w < 16; ++w) {
-        before += w < wv ? s_cnt[k][w] : 0;
-        total += s_cnt[k][w];
-      }
-      const unsigned long long m = __ballot(c == k);
-      if (c == k) list[pos[k] + before + lane_rank(m)] = i;
-      pos[k] += total;
-    }
+    for (int k = 0; k < WCLASSES; ++k)
+      if (c == k) list[excl[k]++] = i;
   }
 }
 
@@ -1160,8 +1142,10 @@ struct WitOp {
                  int32_t* item_count, WitOut out, FaceAcc acc, unsigned long long* stats, const int32_t* kind,
                  hipStream_t st) {
     if constexpr (DIM == 2 || DIM == 3) {
-      const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
-      if (rc != FLOODER_OK) return rc;
+      if (!planes_are_done(verts, plane_tab, ns, st)) {   // (flooder_simplex_prepare_f32 may have written the rows already)
+        const int rc = launch_simplex_planes(DIM, verts, k1, ns, plane_tab, st);
+        if (rc != FLOODER_OK) return rc;
+      }
       planes_done_for(verts, plane_tab, ns, st);   // (the cell sweep's entry, next on this stream, need not repeat it)
       hipLaunchKernelGGL(wit_list_kernel, dim3(1), dim3(1024), 0, st, out.weight, (int)ns, (float)g_wit_weight, item_list,
                          item_count, g_wit_surface_pct > 0 ? kind : nullptr, g_wit_surface_pct);

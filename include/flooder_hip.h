@@ -190,6 +190,16 @@ int64_t flooder_index_sort_bytes(int64_t n_pts);
 int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
                        void* tmp, int64_t tmp_bytes, void* stream);
 
+/* The same sort (same library kernels, same stable order) without the seven fill launches the library call makes for
+ * three 8-bit passes: its state - digit histograms, one look-back array and one block ticket per pass - is
+ * `flooder_index_sort_state_words(n_pts, key_bits)` int32 words that the CALLER has zeroed on this stream before the
+ * call (the curve-code kernel does it on its way: hand flooder_morton_zero_f32 a zero_buf that ends in them).  Keys
+ * of at most 32 bits and fewer than 2^30 rows (state_words returns 0 otherwise: use flooder_index_sort); tmp: 8 * n_pts
+ * bytes (flooder_index_sort_bytes is enough).  cfg 2's index build: 7 launches and ~25 us less. */
+int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits);
+int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
+                              void* tmp, int64_t tmp_bytes, int32_t* state, void* stream);
+
 /* Order of a balanced k-d tree over the cloud (default of the point index above 3 dimensions; core.KD_ORDER_ABOVE_DIM):
  * order[j] = index of the point at row j, such that every ALIGNED group of 16 * 2^i rows - the leaves and inner nodes
  * of the implicit box tree - is a cell of the tree (each level splits every group along the widest axis of its box at
@@ -462,6 +472,15 @@ int flooder_face_values_f32(const uint32_t* face_bits, int64_t n, float* out_fac
  * as the work order (the order of the simplices never changes a value). */
 int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
                                int64_t n_simplices, float* weight, void* stream);
+
+/* The same launch PREPARING a fused sweep: weights as above, plus (plane_scratch != NULL, dim 2 / 3) the face-plane rows
+ * the witness and the cell sweep read - their entry points, next on this stream with the same verts / plane_scratch /
+ * n_simplices, then skip their own plane launch - plus a zero fill of zero_words int32 words at zero_buf (the control
+ * words, queue heads and face words the sweep's launches start from; NULL / 0: none).  One launch instead of three
+ * (fill, weights, planes): ~8 us of cfg 2's step. */
+int flooder_simplex_prepare_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
+                                int64_t n_simplices, float* weight, float* plane_scratch, int32_t* zero_buf,
+                                int64_t zero_words, void* stream);
 
 /* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
 int flooder_selftest(const float* in64, float* out128, void* stream);

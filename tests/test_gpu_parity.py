@@ -867,6 +867,21 @@ def test_index_sort_is_a_stable_sort(dev):
                                              _native.ptr(tmp), nb, 0), "flooder_index_sort")
         torch.cuda.synchronize()
         assert np.array_equal(order.cpu().numpy().astype(np.int64), want), (n, bits)
+        # the same library kernels on state the caller zeroes (no fill launches): same permutation, same sorted codes,
+        # three times over (stale state of an earlier call must not matter once it is zeroed again)
+        words = int(lib.flooder_index_sort_state_words(n, bits))
+        assert (words > 0) == (bits <= 32)
+        for rep in range(3 if words else 0):
+            state = torch.full((words,), -1 if rep else 7, dtype=torch.int32, device=dev)
+            state.zero_()
+            order2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            out2 = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            _native.check(lib.flooder_index_sort_zeroed(_native.ptr(buf), n, bits, _native.ptr(out2), _native.ptr(order2),
+                                                        _native.ptr(tmp), nb, _native.ptr(state), 0),
+                          "flooder_index_sort_zeroed")
+            torch.cuda.synchronize()
+            assert torch.equal(order2, order), (n, bits, rep)
+            assert torch.equal(out2.view(torch.int32)[:n], out.view(torch.int32)[:n]), (n, bits, rep)
 
 
 def test_index_of_a_modified_cloud_is_refused(dev):

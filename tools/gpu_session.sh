@@ -111,6 +111,31 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:22]:
     print(f"{k:62s} n={len(v):4d} mean {sum(v)/len(v):9.1f} us")
 PY
             rm -rf $OUT/trace_$wl ;;
+    timeline:*) # every dispatch of ONE step (back-to-back steps, the last but one): offset, duration, gap to the previous end
+            wl=${s#timeline:}
+            ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$wl -- python3 $R/bench.py --workload $wl --steps 12 --warmup 3 --no-cpu-baseline --no-cold --no-e2e > $OUT/tl_$wl.json 2> $OUT/tl_$wl.err )
+            python - $OUT/tl_$wl > $OUT/timeline_$wl.txt <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(nm):
+    nm = nm.split("(anonymous namespace)::")[1] if "(anonymous namespace)::" in nm else nm
+    return nm.split("(")[0][:70]
+starts = [i for i, r in enumerate(rows) if "bbox_partial" in r["Kernel_Name"]]
+# back-to-back timed steps: the longest run of equal spacing near the end; take the 4th step from the end
+i0, i1 = starts[-5], starts[-4]
+t0 = int(rows[i0]["Start_Timestamp"]); prev_end = None; busy = 0
+print(f"one step = {i1 - i0} dispatches, {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.1f} us start to start")
+for r in rows[i0:i1]:
+    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+    busy += en - st
+    print(f"{(st - t0) / 1e3:9.1f} us  dur {(en - st) / 1e3:8.1f}  gap {gap:6.1f}  {short(r['Kernel_Name'])}  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}")
+    prev_end = max(prev_end or en, en)
+print(f"sum of durations {busy / 1e3:.1f} us")
+PY
+            rm -rf $OUT/tl_$wl; cat $OUT/timeline_$wl.txt ;;
     ctimes:*) IFS=: read -r _ W wl <<< "$s"      # ctimes:<W>[:<workload>]
             FLOODER_HIPCC_FLAGS=-DFLOODER_PHASE_TIMERS python -m flooder_amd.build --out /tmp/libflooder_hip_diag.so > $OUT/build_timers.log 2>&1; export FLOODER_HIP_LIB=/tmp/libflooder_hip_diag.so
             timeout 400 python tools/chunk_times.py $W ${wl:-cfg2} > $OUT/chunk_times_${W}_${wl:-cfg2}.txt 2>&1
