@@ -30,7 +30,7 @@ namespace {
 constexpr float SAFE = 0.99999f;
 
 }  // namespace
-namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 4; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 99; int g_finish_refresh = 16; int g_curve_bits = 0; int g_cell_super_weight = 2000; int g_cell_super_n0 = 480; int g_cell_super_sparse = 600; int g_cell_super_min_chunks = 49152; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; int g_finish_budget = 14; int g_finish_budget_min = 64; int g_finish_wide_points = 4 << 20; int g_cell_surface_pct = 60; int g_finish_order = 1; int g_cell_retry_pct = 50; int g_cell_retry_keep = 200; int g_finish_top = 0; int g_cell_tiles = 0; int g_cell_density_grid = 16; int g_cell_chunks_per_block = 12; int g_cell_min_grid = 384; int g_cell_weight_classes = 1; int g_cell_listed_first = 1; int g_cell_tail_waves = 200; int g_cell_one_pass = 125; int g_cell_chunk_major = 1; int g_cell_chunk_major_max = 262144; int g_cell_drop = 1; int g_cell_queue_block = 5; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
+namespace flooder { int g_bvh_ks = 0; int g_bvh_subs = 16; int g_bvh_grid = 256 * 4; int g_cell_grid = 256 * 4; int g_cell_exh_dense = 64 * 512; int g_bvh_leaf_batch = 1; int g_bvh_refine_pct = 100; int g_cell_exh_sparse = 4 * 480; int g_cell_brute_max = 160; int g_finish_focus_pct = 99; int g_finish_refresh = 16; int g_curve_bits = 0; int g_cell_super_weight = 2000; int g_cell_super_n0 = 480; int g_cell_super_sparse = 600; int g_cell_super_min_chunks = 49152; int g_cell_tries = 2; int g_cell_exh_tries = 3; int g_finish_items_cap = 65536; int g_curve = 1; int g_finish_budget = 14; int g_finish_budget_min = 64; int g_finish_wide_points = 4 << 20; int g_cell_surface_pct = 60; int g_cell_split_launches = 1; int g_finish_order = 1; int g_cell_retry_pct = 50; int g_cell_retry_keep = 200; int g_finish_top = 0; int g_cell_tiles = 0; int g_cell_density_grid = 16; int g_cell_chunks_per_block = 12; int g_cell_min_grid = 384; int g_cell_weight_classes = 1; int g_cell_listed_first = 1; int g_cell_tail_waves = 200; int g_cell_one_pass = 125; int g_cell_chunk_major = 1; int g_cell_chunk_major_max = 262144; int g_cell_drop = 1; int g_cell_queue_block = 5; }  // 0 = by R; else samples per lane (1, 2, 4, 8)
 namespace {
 
 // ------------------------------------------------------------------------------------ morton

@@ -1774,17 +1774,19 @@ __global__ __launch_bounds__(1024) void split_simplices_kernel(const float* __re
 // launch (a quarter of it on cfg 2, half of it on an eighth of cfg 2).
 // Runs of four chunks pay in sparse volumetric clouds (most runs fit the stage); where fewer than half of the simplices
 // are sparse (weight <= sparse_limit), or the caller says so (runs_allowed = 0: a short queue), every simplex is heavy.
+constexpr int SPLIT_THREADS_LONG = 512;  // the one-launch split of a long queue: all simplices, a dozen per thread
 constexpr int SPLIT_THREADS = 256;  // (1024 threads leave 128 VGPRs each: the class arrays spilled, and scratch costs a launch 25 us)
 constexpr int SPLIT_CLASSES = 9;  // weight > limit x 32, 16, 8, 4, 2, 1, 1/2, 1/4, rest
 // (a stable counting sort: every thread owns a run of consecutive simplices, counts its classes, one block-wide
 // exclusive scan per class - wave scans + partial sums through LDS - and every thread writes its run: two barriers)
 // reorder != 0: the heavy list of split_simplices_kernel (counts[1] entries) is put into class order IN PLACE (its
 // entries are staged in LDS first; longer than the stage: left as it is) and the counts are not touched.
-__global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float* __restrict__ weight, int n, float limit,
+template <int NT>
+__global__ __launch_bounds__(NT) void class_order_kernel(const float* __restrict__ weight, int n, float limit,
                                                                float sparse_limit, int runs_allowed, int reorder,
                                                                int32_t* __restrict__ light, int32_t* __restrict__ heavy,
                                                                int32_t* __restrict__ counts) {
-  __shared__ int s_cnt[SPLIT_THREADS / 64][SPLIT_CLASSES + 1];
+  __shared__ int s_cnt[NT / 64][SPLIT_CLASSES + 1];
   constexpr int ID_LDS = 7680;
   __shared__ int s_id[ID_LDS];
   if (reorder) {
@@ -1792,7 +1794,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
     // (no light list: a cloud too dense for runs, every simplex in the given order - measured: reordering those
     // costs cfg 3 20 us and gains nothing)
     if (n > ID_LDS || n < 2 || counts[0] == 0) return;
-    for (int i = threadIdx.x; i < n; i += SPLIT_THREADS) s_id[i] = heavy[i];
+    for (int i = threadIdx.x; i < n; i += NT) s_id[i] = heavy[i];
     __syncthreads();
   }
   // the weights come in coalesced and are read back run by run from LDS (a run of consecutive simplices per thread
@@ -1801,16 +1803,16 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
   __shared__ float s_w[W_LDS];
   const bool staged = n <= W_LDS;
   if (staged) {
-    for (int base = 0; base < n; base += SPLIT_THREADS * 8) {  // (eight loads in flight: the loop is latency, not bytes)
+    for (int base = 0; base < n; base += NT * 8) {  // (eight loads in flight: the loop is latency, not bytes)
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = base + u * SPLIT_THREADS + (int)threadIdx.x;
+        const int i = base + u * NT + (int)threadIdx.x;
         v[u] = i < n ? weight[reorder ? s_id[i] : i] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = base + u * SPLIT_THREADS + (int)threadIdx.x;
+        const int i = base + u * NT + (int)threadIdx.x;
         if (i < n) s_w[i] = v[u];
       }
     }
@@ -1819,6 +1821,11 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
   auto wt = [&](int i) -> float { return staged ? s_w[i] : weight[i]; };  // (reorder: always staged)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool by_class = (runs_allowed & 2) != 0;
+  // runs_allowed & 4: a LONG queue in one launch (what split_simplices_kernel + a reorder launch used to do in two):
+  // the light simplices are ONE class, kept in the given order for the runs of four; without runs every simplex goes
+  // on the heavy list in the given order (a cloud too dense for runs: class order costs cfg 3 20 us and gains nothing)
+  const bool one_light = (runs_allowed & 4) != 0;
+  constexpr int FIRST_LIGHT = 6;  // classes 6, 7, 8: weight <= limit
   auto cls = [&](float w) -> int {  // 0 = heaviest; -1: handled by the witness sweep already (on no list)
     if (w < 0.f) return -1;
     if (!by_class) return w > limit ? 5 : 6;
@@ -1829,9 +1836,9 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
       c += w > t ? 0 : 1;
       t *= 0.5f;
     }
-    return c;
+    return one_light && c > FIRST_LIGHT ? FIRST_LIGHT : c;
   };
-  const int per = ((n + SPLIT_THREADS - 1) / SPLIT_THREADS) | 1;  // (odd: the runs start in different LDS banks)
+  const int per = ((n + NT - 1) / NT) | 1;  // (odd: the runs start in different LDS banks)
   const int i0 = threadIdx.x * per < n ? threadIdx.x * per : n;
   const int i1 = i0 + per < n ? i0 + per : n;
   int cnt[SPLIT_CLASSES + 1];  // [SPLIT_CLASSES]: sparse simplices
@@ -1868,7 +1875,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
   int n_sparse = 0;
 #pragma unroll
   for (int k = 0; k < SPLIT_CLASSES; ++k) { before[k] = 0; total[k] = 0; }
-  for (int w = 0; w < SPLIT_THREADS / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
 #pragma unroll
     for (int k = 0; k < SPLIT_CLASSES; ++k) {
       const int v = s_cnt[w][k];
@@ -1881,19 +1888,25 @@ __global__ __launch_bounds__(SPLIT_THREADS) void class_order_kernel(const float*
 #pragma unroll
   for (int k = 0; k < SPLIT_CLASSES; ++k) n_act += total[k];
   const bool runs = (runs_allowed & 1) != 0 && 2 * n_sparse >= n_act;
-  constexpr int FIRST_LIGHT = 6;  // classes 6, 7, 8: weight <= limit
   const bool flat = !by_class && !runs && n_act == n;  // one list in the given order
+  const bool given = one_light && !runs && !flat;      // ... of the simplices still to be swept
   int pos[SPLIT_CLASSES];  // where this thread's first simplex of the class goes
   int n_light = 0, n_heavy = 0;
+  int pos_given = 0;
 #pragma unroll
   for (int k = 0; k < SPLIT_CLASSES; ++k) {
     const bool is_light = runs && k >= FIRST_LIGHT;
     pos[k] = (is_light ? n_light : n_heavy) + before[k] + excl[k];
+    pos_given += before[k] + excl[k];
     if (is_light) n_light += total[k];
     else n_heavy += total[k];
   }
   if (flat) {
     for (int i = i0; i < i1; ++i) heavy[i] = reorder ? s_id[i] : i;
+  } else if (given) {
+    // (the threads own consecutive runs and the waves consecutive threads: everything before this thread's run)
+    for (int i = i0; i < i1; ++i)
+      if (wt(i) >= 0.f) heavy[pos_given++] = i;
   } else {
     for (int ib = i0; ib < i1; ib += 8) {
       float v[8];
@@ -2001,18 +2014,24 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
   if (!simplex_weight) light_list = heavy_list = nullptr;
   if (simplex_weight) {  // split the simplices (order kept) into the light and the heavy list
     const bool long_queue = n_simplices * (int64_t)((R + 255) / 256) >= (int64_t)g_cell_super_min_chunks;
-    if (long_queue) {
+    if (long_queue && g_cell_split_launches == 2) {   // (the two launches of rounds 3 - 5: kept for A/B runs and the tests)
       hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
                          (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
                          defer_ctl + 2);
       // ... and the heavy list heaviest first: its densest simplices hold the chunks that one wave evaluates
       // exhaustively for 150 us and more, and the last of them to start was the tail of the chunk launch
       if (g_cell_weight_classes)
-        hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
+        hipLaunchKernelGGL(class_order_kernel<SPLIT_THREADS>, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
                            (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, 2, 1, light_list,
                            heavy_list, defer_ctl + 2);
+    } else if (long_queue) {
+      // light list in the given order + heavy list heaviest first (its densest simplices hold the chunks that one wave
+      // evaluates exhaustively for 150 us and more: started last they were the tail of the chunk launch) in ONE launch
+      hipLaunchKernelGGL(class_order_kernel<SPLIT_THREADS_LONG>, dim3(1), dim3(SPLIT_THREADS_LONG), 0, (hipStream_t)stream, simplex_weight,
+                         (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse,
+                         (g_cell_weight_classes ? 2 : 0) | 1 | 4, 0, light_list, heavy_list, defer_ctl + 2);
     } else {
-      hipLaunchKernelGGL(class_order_kernel, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
+      hipLaunchKernelGGL(class_order_kernel<SPLIT_THREADS>, dim3(1), dim3(SPLIT_THREADS), 0, (hipStream_t)stream, simplex_weight,
                          (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse,
                          g_cell_weight_classes ? 2 : 0, 0, light_list, heavy_list, defer_ctl + 2);
     }

@@ -50,6 +50,8 @@ extern int g_cell_retry_pct;  // share (percent) of a chunk's open samples that 
 extern int g_finish_items_cap;
 extern int g_finish_budget_min;  // leaves a tile of a SHORT list may evaluate before it counts as hard
 extern int g_cell_surface_pct;    // cell sweep: one cell size per chunk on clouds with less than this percentage of their points in interior cells of the density grid (0: never)
+extern int g_cell_split_launches;  // cell sweep, long queue: light / heavy lists by 1 launch (class_order_kernel) or the 2 of rounds 3 - 5
+extern int g_sort_shape;  // flooder_index_sort_zeroed: block shape of the radix passes (0: by cloud size; 1 small, 2 the library's, 3 large)
 extern int g_finish_wide_points;  // clouds of at least this many points run the finish's per-wave passes with 8 waves per workgroup (0: never)
 extern int g_finish_budget;  // scale of the leaf budget beyond which a tile of the finish counts as hard (0: off)
 extern int g_finish_top;     // 1: the finish settles one sample per simplex (its largest bound) before everything else

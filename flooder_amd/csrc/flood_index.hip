@@ -569,9 +569,25 @@ constexpr rpd::radix_sort_onesweep_config_params OSP =
         rpd::target_arch::gfx950>::params;
 constexpr unsigned OS_BITS = OSP.radix_bits_per_place, OS_RADIX = 1u << OS_BITS;
 constexpr unsigned OS_HB = OSP.histogram.block_size, OS_HI = OSP.histogram.items_per_thread;
-constexpr unsigned OS_SB = OSP.sort.block_size, OS_SI = OSP.sort.items_per_thread;
 using OsTicket = rpd::block_id_wrapper<unsigned int, true>;   // (gfx950: blocks take their number from an atomic ticket)
 static_assert(sizeof(rpd::onesweep_lookback_state) == sizeof(uint32_t), "one word per look-back state");
+
+// Block shape of a pass by cloud size (measured, tools/time_index.py: whole index build, us)
+//                 0.3 M    1 M    4 M    16 M
+//   1024 x 16      142     166    279     960     the library's shape for gfx950: 62 blocks for a million keys - a
+//   1024 x  8      111     150    284     912     quarter of the CUs, and a look-back chain of 62 long items
+//    512 x  8      108     138    312     976
+//   1024 x  4      100     142    294     970
+// (a second run, 2 M / 8 M keys: 198 / 529 with 512 x 8, 201 / 498 with the library's shape, 182 / 483 with 1024 x 8)
+// -> 512 x 8 below 1.5 M keys, 1024 x 8 from there on; the library's shape is level at 4 M and behind everywhere else
+// (option "sort_shape": 0 by size, 1 / 2 / 3 = 512 x 8 / the library's / 1024 x 8 forced).
+template <unsigned SB, unsigned SI>
+struct OsShape {
+  static constexpr unsigned sb = SB, si = SI, items = SB * SI;
+};
+using OsSmall = OsShape<512, 8>;
+using OsMid = OsShape<OSP.sort.block_size, OSP.sort.items_per_thread>;
+using OsLarge = OsShape<1024, 8>;
 
 __global__ __launch_bounds__(OS_HB) void os_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
                                                              uint32_t n, uint32_t full_blocks, unsigned end_bit) {
@@ -583,20 +599,53 @@ __global__ __launch_bounds__(OS_HB) void os_scan_kernel(uint32_t* __restrict__ c
   rpd::onesweep_scan_histograms<OS_HB, OS_BITS>(counts);
 }
 
-template <class ValuesIn>
-__global__ __launch_bounds__(OS_SB) void os_pass_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
-                                                        ValuesIn values_in, uint32_t* __restrict__ values_out, uint32_t n,
-                                                        uint32_t* offsets, uint32_t* offsets_out,
-                                                        rpd::onesweep_lookback_state* states, unsigned bit,
-                                                        unsigned bits_now, uint32_t full_blocks, OsTicket ticket) {
-  rpd::onesweep_iteration<OS_SB, OS_SI, OS_BITS, false, OSP.radix_rank_algorithm>(
+template <class Shape, class ValuesIn>
+__global__ __launch_bounds__(Shape::sb) void os_pass_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
+                                                            ValuesIn values_in, uint32_t* __restrict__ values_out, uint32_t n,
+                                                            uint32_t* offsets, uint32_t* offsets_out,
+                                                            rpd::onesweep_lookback_state* states, unsigned bit,
+                                                            unsigned bits_now, uint32_t full_blocks, OsTicket ticket) {
+  rpd::onesweep_iteration<Shape::sb, Shape::si, OS_BITS, false, OSP.radix_rank_algorithm>(
       keys_in, keys_out, values_in, values_out, n, offsets, offsets_out, states, rocprim::identity_decomposer{}, bit,
       bits_now, full_blocks, ticket);
 }
 
 inline unsigned os_places(int key_bits) { return ((unsigned)key_bits + OS_BITS - 1) / OS_BITS; }
-inline uint32_t os_blocks(int64_t n) { return (uint32_t)((n + (int64_t)OS_SB * OS_SI - 1) / ((int64_t)OS_SB * OS_SI)); }
+inline int os_shape_of(int64_t n) {   // 1 small, 2 mid, 3 large
+  if (flooder::g_sort_shape >= 1 && flooder::g_sort_shape <= 3) return flooder::g_sort_shape;
+  return n < 1500000 ? 1 : 3;
+}
+inline uint32_t os_items(int shape) { return shape == 1 ? OsSmall::items : (shape == 2 ? OsMid::items : OsLarge::items); }
+inline uint32_t os_blocks(int64_t n, int shape) { return (uint32_t)((n + os_items(shape) - 1) / os_items(shape)); }
+
+template <class Shape>
+void os_passes(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t n,
+               int key_bits, uint32_t* counts, rpd::onesweep_lookback_state* states, uint32_t* tickets, uint32_t* offsets_out,
+               hipStream_t st) {
+  const unsigned places = os_places(key_bits);
+  const uint32_t blocks = (n + Shape::items - 1) / Shape::items;
+  const uint32_t full_blocks = n % Shape::items == 0 ? blocks : blocks - 1;
+  bool to_output = (places - 1) % 2 == 0;   // (the last pass lands in the output arrays)
+  for (unsigned place = 0, bit = 0; place < places; ++place, bit += OS_BITS) {
+    const unsigned bits_now = (unsigned)key_bits - bit < OS_BITS ? (unsigned)key_bits - bit : OS_BITS;
+    uint32_t* ko = to_output ? keys_out : keys_tmp;
+    uint32_t* vo = to_output ? vals_out : vals_tmp;
+    OsTicket ticket = OsTicket::create(tickets + place);
+    if (place == 0)
+      hipLaunchKernelGGL((os_pass_kernel<Shape, rocprim::counting_iterator<uint32_t>>), dim3(blocks), dim3(Shape::sb), 0, st,
+                         keys_in, ko, rocprim::counting_iterator<uint32_t>(0u), vo, n, counts, offsets_out, states, bit,
+                         bits_now, full_blocks, ticket);
+    else
+      hipLaunchKernelGGL((os_pass_kernel<Shape, const uint32_t*>), dim3(blocks), dim3(Shape::sb), 0, st,
+                         (const uint32_t*)(to_output ? keys_tmp : keys_out), ko,
+                         (const uint32_t*)(to_output ? vals_tmp : vals_out), vo, n, counts + place * OS_RADIX, offsets_out,
+                         states + (size_t)place * OS_RADIX * blocks, bit, bits_now, full_blocks, ticket);
+    to_output = !to_output;
+  }
+}
 }  // namespace
+
+namespace flooder { int g_sort_shape = 0; }
 
 extern "C" {
 
@@ -604,7 +653,8 @@ int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits) {
   if (n_pts < 1 || n_pts >= (1LL << 30) || key_bits < 1 || key_bits > 32) return 0;   // (0: use flooder_index_sort)
   const int64_t places = os_places(key_bits);
   // histograms of every digit place | one look-back array per pass | one ticket per pass | the last block's offsets
-  return places * OS_RADIX + places * (int64_t)OS_RADIX * os_blocks(n_pts) + places + OS_RADIX;
+  // (sized for the smallest block shape: the option may change between this call and the sort)
+  return places * OS_RADIX + places * (int64_t)OS_RADIX * os_blocks(n_pts, 1) + places + OS_RADIX;
 }
 
 int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
@@ -616,8 +666,8 @@ int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits,
   hipStream_t st = (hipStream_t)stream;
   const uint32_t n = (uint32_t)n_pts;
   const unsigned places = os_places(key_bits);
-  const uint32_t blocks = os_blocks(n_pts);
-  const uint32_t full_blocks = n % (OS_SB * OS_SI) == 0 ? blocks : blocks - 1;
+  const int shape = os_shape_of(n_pts);
+  const uint32_t blocks = os_blocks(n_pts, shape);
   uint32_t* counts = reinterpret_cast<uint32_t*>(state);
   auto* states = reinterpret_cast<rpd::onesweep_lookback_state*>(counts + places * OS_RADIX);
   uint32_t* tickets = counts + places * OS_RADIX + (size_t)places * OS_RADIX * blocks;
@@ -633,23 +683,12 @@ int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits,
     hipLaunchKernelGGL(os_histogram_kernel, dim3(hb), dim3(OS_HB), 0, st, keys_in, counts, n, hfull, (unsigned)key_bits);
     hipLaunchKernelGGL(os_scan_kernel, dim3(places), dim3(OS_HB), 0, st, counts);
   }
-  bool to_output = (places - 1) % 2 == 0;   // (the last pass lands in the output arrays)
-  for (unsigned place = 0, bit = 0; place < places; ++place, bit += OS_BITS) {
-    const unsigned bits_now = (unsigned)key_bits - bit < OS_BITS ? (unsigned)key_bits - bit : OS_BITS;
-    uint32_t* ko = to_output ? keys_out : keys_tmp;
-    uint32_t* vo = to_output ? vals_out : vals_tmp;
-    OsTicket ticket = OsTicket::create(tickets + place);
-    if (place == 0)
-      hipLaunchKernelGGL((os_pass_kernel<rocprim::counting_iterator<uint32_t>>), dim3(blocks), dim3(OS_SB), 0, st, keys_in, ko,
-                         rocprim::counting_iterator<uint32_t>(0u), vo, n, counts, offsets_out, states, bit, bits_now,
-                         full_blocks, ticket);
-    else
-      hipLaunchKernelGGL((os_pass_kernel<const uint32_t*>), dim3(blocks), dim3(OS_SB), 0, st,
-                         (const uint32_t*)(to_output ? keys_tmp : keys_out), ko,
-                         (const uint32_t*)(to_output ? vals_tmp : vals_out), vo, n, counts + place * OS_RADIX, offsets_out,
-                         states + (size_t)place * OS_RADIX * blocks, bit, bits_now, full_blocks, ticket);
-    to_output = !to_output;
-  }
+  if (shape == 1)
+    os_passes<OsSmall>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
+  else if (shape == 2)
+    os_passes<OsMid>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
+  else
+    os_passes<OsLarge>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
   return check_launch("index_sort_zeroed");
 }
 

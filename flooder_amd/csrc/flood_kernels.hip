@@ -663,6 +663,14 @@ int flooder_set_option(const char* name, int value) {
     g_finish_budget_min = value;
     return FLOODER_OK;
   }
+  if (name && strcmp(name, "sort_shape") == 0 && value >= 0 && value <= 3) {
+    g_sort_shape = value;
+    return FLOODER_OK;
+  }
+  if (name && strcmp(name, "cell_split_launches") == 0 && (value == 1 || value == 2)) {
+    g_cell_split_launches = value;
+    return FLOODER_OK;
+  }
   if (name && strcmp(name, "cell_surface_pct") == 0 && value >= 0 && value <= 100) {
     g_cell_surface_pct = value;
     return FLOODER_OK;

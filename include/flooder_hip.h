@@ -75,7 +75,10 @@ int flooder_device_arch(int device, char* buf, int buflen);
  *                     SIMD at an 80-register cap instead of 4: a search in a deep tree is a longer chain of dependent
  *                     steps; cfg 5 finish 1.68 -> 1.47 ms, no gain at a million points); "fps_switch", "fps_rpl": see flooder_fps_indexed_f32;
  *   "cell_exh_dense": most kept points a dense chunk of the cell sweep evaluates exhaustively before it is
- *                     handed to the tree sweep (default 32768). */
+ *                     handed to the tree sweep (default 32768);
+ *   "cell_split_launches": 1 (default) the light / heavy simplex lists of a long queue come from ONE launch, 2 from the
+ *                     split + reorder pair of rounds 3 - 5 (same lists); "wit_surface_pct", "cell_surface_pct": see
+ *                     flooder_cloud_kind. */
 int flooder_set_option(const char* name, int value);
 
 /* Row stride (floats) of a padded point / candidate row for ambient dimension `dim`:
@@ -195,7 +198,10 @@ int flooder_index_sort(const int64_t* codes, int64_t n_pts, int key_bits, int64_
  * `flooder_index_sort_state_words(n_pts, key_bits)` int32 words that the CALLER has zeroed on this stream before the
  * call (the curve-code kernel does it on its way: hand flooder_morton_zero_f32 a zero_buf that ends in them).  Keys
  * of at most 32 bits and fewer than 2^30 rows (state_words returns 0 otherwise: use flooder_index_sort); tmp: 8 * n_pts
- * bytes (flooder_index_sort_bytes is enough).  cfg 2's index build: 7 launches and ~25 us less. */
+ * bytes (flooder_index_sort_bytes is enough).  cfg 2's index build: 7 launches and ~17 us less.  The passes also run
+ * in a block shape chosen by the cloud's size instead of the library's 1024 x 16 keys (62 blocks for a million keys on
+ * 256 CUs): 512 x 8 below 1.5 M keys, 1024 x 8 above (option "sort_shape" 0; 1 / 2 / 3 force 512 x 8 / 1024 x 16 /
+ * 1024 x 8) - index build 163 -> 136 us at 1 M points, 947 -> 905 us at 16 M.  Same order whatever the shape. */
 int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits);
 int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
                               void* tmp, int64_t tmp_bytes, int32_t* state, void* stream);

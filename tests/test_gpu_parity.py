@@ -720,6 +720,44 @@ def test_fused_face_maxima_equal_unfused(dev, cloud, monkeypatch):
         assert res[True] == res[False], (cloud, kw)
 
 
+@pytest.mark.parametrize("cloud", ["gauss", "torus"])
+def test_long_queue_lists_from_one_launch_equal_the_two_launches(dev, cloud):
+    """Light / heavy simplex lists of a LONG queue (>= 49152 chunks): one class_order_kernel launch against the split +
+    reorder pair it replaces - same list lengths, same face values bit for bit (a simplex lost or listed twice would
+    show), with and without the witness sweep in front (which marks the simplices it handled)."""
+    lib = _native.load()
+    if cloud == "gauss":
+        pts = np.random.default_rng(5).normal(size=(400_000, 3)).astype(np.float32)
+    else:
+        pts = fo.noisy_torus(400_000, seed=5)
+    tp = torch.as_tensor(pts, device=dev)
+    lms = fa.generate_landmarks(tp, 600, start_idx=0)
+    stree, simplices = core._build_complex(lms, 3)
+    verts = lms[torch.as_tensor(simplices[3], device=dev)].contiguous()
+    weights, vertex_idxs, face_idxs = core.generate_grid(30, 3, dev, torch.float32)
+    faces = core._FaceTable(face_idxs, weights.shape[0], dev)
+    assert verts.shape[0] * ((weights.shape[0] + 255) // 256) >= 49152, "not a long queue"
+    index = core.PointIndex(tp)
+    keep = core.WIT_MIN_SIMPLICES, core.CELL_WITNESS
+    try:
+        core.WIT_MIN_SIMPLICES = 0
+        for witness in (True, False):
+            core.CELL_WITNESS = witness
+            got = {}
+            for launches in (1, 2):
+                assert lib.flooder_set_option(b"cell_split_launches", launches) == 0
+                st = torch.zeros(40, dtype=torch.int64, device=dev)
+                out, _ = core._sweep_dimension_cell(index, verts, weights, faces, None, stats=st)
+                torch.cuda.synchronize()
+                got[launches] = (out.clone(), core.LAST_STATS.light_heavy)
+            assert got[1][1] == got[2][1], (cloud, witness, got[1][1], got[2][1])
+            assert sum(got[1][1]) > 0
+            assert torch.equal(got[1][0].view(torch.int32), got[2][0].view(torch.int32)), (cloud, witness)
+    finally:
+        core.WIT_MIN_SIMPLICES, core.CELL_WITNESS = keep
+        assert lib.flooder_set_option(b"cell_split_launches", 1) == 0
+
+
 def test_simplex_weight_orders_dense_simplices_first(dev):
     """flooder_simplex_weight_f32: the estimate tracks the true number of points in each simplex's bounding box."""
     pts = np.random.default_rng(3).normal(size=(400_000, 3)).astype(np.float32)
@@ -871,7 +909,8 @@ def test_index_sort_is_a_stable_sort(dev):
         # three times over (stale state of an earlier call must not matter once it is zeroed again)
         words = int(lib.flooder_index_sort_state_words(n, bits))
         assert (words > 0) == (bits <= 32)
-        for rep in range(3 if words else 0):
+        for rep in range(4 if words else 0):   # (block shape by size, then each of the three forced)
+            assert lib.flooder_set_option(b"sort_shape", rep) == 0
             state = torch.full((words,), -1 if rep else 7, dtype=torch.int32, device=dev)
             state.zero_()
             order2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
@@ -882,6 +921,7 @@ def test_index_sort_is_a_stable_sort(dev):
             torch.cuda.synchronize()
             assert torch.equal(order2, order), (n, bits, rep)
             assert torch.equal(out2.view(torch.int32)[:n], out.view(torch.int32)[:n]), (n, bits, rep)
+        assert lib.flooder_set_option(b"sort_shape", 0) == 0
 
 
 def test_index_of_a_modified_cloud_is_refused(dev):
