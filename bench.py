@@ -503,9 +503,18 @@ def main():
         t0 = time.perf_counter()
         marks[0].record()
         o = None
+        chained = timer is not None and getattr(timer, "chain", False)
+        if chained:
+            timer.note(marks[0])
         for i in range(n_steps):
+            before = timer.last if chained else None
             o = step(timer, index=index)
-            marks[i + 1].record()
+            if chained and timer.last is not None and timer.last is not before:
+                marks[i + 1] = timer.last      # (the end of the step's last span IS the step boundary: no event of its own)
+            else:
+                marks[i + 1].record()
+                if chained:
+                    timer.note(marks[i + 1])
         sync_all()
         el = time.perf_counter() - t0
         if world > 1:
@@ -518,7 +527,7 @@ def main():
         dist.all_reduce(torch.zeros(1, device=dev), op=dist.ReduceOp.MIN)
     for _ in range(max(args.warmup, 0)):
         out = step()
-    timer = core._KernelTimer()
+    timer = core._KernelTimer(chain=True)   # (spans share their boundary events: 5 event records per step, not 9)
     elapsed, step_ms, out_timed = timed_loop(args.steps, timer)   # (out_timed: the LAST TIMED step's values - parity below)
     ms_per_step = elapsed / args.steps * 1e3
     value = w["n"] * S_all / (elapsed / args.steps) / 1e6
@@ -527,12 +536,12 @@ def main():
     # caller pays who sweeps one cloud more than once - and each rank of a multi-GPU run, where the index build is
     # the part that does not divide
     ready_index = build_index()
-    timer_ready = core._KernelTimer() if world > 1 or args.emulate_shard else None
+    timer_ready = core._KernelTimer(chain=True) if world > 1 or args.emulate_shard else None
     elapsed_ci, step_ms_ci, _ = timed_loop(args.steps, timer_ready, index=ready_index)
     ms_cached = elapsed_ci / args.steps * 1e3
 
     # the host's side of the step: wall time until the LAST launch of n steps is enqueued (no synchronize inside), and the
-    # same steps without the per-span HIP events of the timed loop above (8 event records per step) - how far ahead of
+    # same steps without the per-span HIP events of the timed loop above (4 chained event records per step) - how far ahead of
     # the GPU the Python loop runs, and what the instrumentation the roofline needs costs the headline
     host_rec = None
     if world == 1 and not args.emulate_shard:
