@@ -234,6 +234,9 @@ __global__ __launch_bounds__(WTHREADS, WBLOCKS) void wit_sweep_kernel(
   const int tiles64 = (R + 63) >> 6;
   // work counters (diagnostic runs only: stats != NULL) live in LDS - fourteen 64-bit counters in registers cost the
   // kernel 28 VGPRs it does not have
+  // (an empty item list - a cloud on a surface, wit_list_kernel - : 1024 workgroups popping an empty queue through its
+  // shards and barriers were 22 us of cfg 3's step)
+  if (__builtin_amdgcn_readfirstlane(item_count[0]) == 0) return;
   __shared__ unsigned long long s_stat[24];
   enum { ST_HANDLED = 0, ST_HEAVY = 1, ST_OVER = 2, ST_DENSE = 3, ST_STAGED = 4, ST_CCERT = 5, ST_LIVE = 6, ST_ROUNDS = 7,
          ST_UNRES = 8, ST_FLAGGED = 9, ST_PAIRS = 10, ST_BINS = 11, ST_EXACT = 22, ST_EXACT_OVER = 23 };
