@@ -886,8 +886,9 @@ def test_index_sort_is_a_stable_sort(dev):
     stable sort: identical permutations, duplicates included."""
     lib = _native.load()
     g = torch.Generator().manual_seed(9)
-    for n, bits in ((1, 30), (63, 30), (5000, 8), (100_000, 30), (1_000_003, 30), (300_000, 17), (200_000, 36),
-                    (4_000_000, 30)):
+    # (12288 = 3 x 512 x 8 and 1638400 = 200 x 1024 x 8: whole blocks only, in the small and the large block shape)
+    for n, bits in ((1, 30), (63, 30), (5000, 8), (12_288, 24), (100_000, 30), (1_000_003, 30), (300_000, 17),
+                    (200_000, 36), (1_638_400, 24), (4_000_000, 30)):
         keys = torch.randint(0, 1 << bits, (n,), generator=g, dtype=torch.int64)
         if n > 1000:
             keys[: n // 3] = keys[n // 3: 2 * (n // 3)]                     # plenty of duplicates
