@@ -1147,8 +1147,22 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
     plan = plan if plan is not None else SamplePlan(weights, faces)
     w_perm, rows_perm = plan.w_perm, plan.rows_perm
 
-    queue = torch.zeros(QUEUE_WORDS, dtype=torch.int32, device=dev)   # sharded work-queue heads
     sorted_samples = bvh_sorts_samples(index.dim, S, R)
+    # sharded work-queue heads + (sorted samples) the state of the radix sort of the sample keys, one zero fill for both:
+    # flooder_index_sort_zeroed then makes no memset launch of its own (nine for four passes)
+    n_sort_state = (int(lib.flooder_index_sort_state_words(S * R, 32)) if sorted_samples and SORT_STATE_BY_CALLER else 0)
+    queue = torch.zeros(QUEUE_WORDS + n_sort_state, dtype=torch.int32, device=dev)
+    sort_state = queue[QUEUE_WORDS:] if n_sort_state else None
+    queue = queue[:QUEUE_WORDS]
+
+    def sort_sample_keys(keys, n_s, bits, keys_sorted, order, tmp, tmp_bytes):
+        if sort_state is not None:
+            _native.check(lib.flooder_index_sort_zeroed(_native.ptr(keys), n_s, bits, _native.ptr(keys_sorted), _native.ptr(order),
+                                                        _native.ptr(tmp), tmp_bytes, _native.ptr(sort_state), st),
+                          "flooder_index_sort_zeroed (samples)")
+        else:
+            _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, bits, _native.ptr(keys_sorted), _native.ptr(order),
+                                                 _native.ptr(tmp), tmp_bytes, st), "flooder_index_sort (samples)")
     if (sorted_samples and SORTED_FUSED_FACES and not want_dist and reduce_hook is None and plan.memb_all is not None
             and plan.late_rows is not None and tile_shard is None):
         # ---- only the face maxima are wanted: the sorted sweep delivers them itself (no (S, R) buffer, no face-max
@@ -1165,8 +1179,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
             _native.check(lib.flooder_sample_keys_late_f32(_native.ptr(verts), _native.ptr(w_perm), k1, R, S, index.dim,
                                                            _native.ptr(index.box), _native.ptr(plan.late_rows),
                                                            _native.ptr(keys), st), "flooder_sample_keys_late_f32")
-            _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, 32, _native.ptr(keys_sorted), _native.ptr(order),
-                                                 _native.ptr(tmp), tmp_bytes, st), "flooder_index_sort (samples)")
+            sort_sample_keys(keys, n_s, 32, keys_sorted, order, tmp, tmp_bytes)
             blk = _native.SortedSweep(pts_sorted=index.pts, n_pts=index.n, dim=index.dim, k1=k1, nodes=index.nodes, verts=verts,
                                       weights=w_perm, R=R, n_faces=F, n_simplices=S, sample_order=order, queue=queue,
                                       memb=plan.memb_all, face_bits=face_bits, stats=stats)
@@ -1194,9 +1207,7 @@ def _sweep_dimension_bvh(index: PointIndex, verts: torch.Tensor, weights: torch.
             _native.check(lib.flooder_sample_keys_f32(_native.ptr(verts), _native.ptr(w_perm), k1, R, S, index.dim,
                                                       _native.ptr(index.box), _native.ptr(keys), st),
                           "flooder_sample_keys_f32")
-            _native.check(lib.flooder_index_sort(_native.ptr(keys), n_s, int(lib.flooder_sample_key_bits(index.dim)),
-                                                 _native.ptr(keys_sorted), _native.ptr(order), _native.ptr(tmp),
-                                                 tmp_bytes, st), "flooder_index_sort (samples)")
+            sort_sample_keys(keys, n_s, int(lib.flooder_sample_key_bits(index.dim)), keys_sorted, order, tmp, tmp_bytes)
             # (a tile shard: every rank sorts ALL samples - the same order everywhere - and takes a contiguous world-th of
             # the tiles)
             blk = _native.SortedSweep(pts_sorted=index.pts, n_pts=index.n, dim=index.dim, k1=k1, nodes=index.nodes, verts=verts,

@@ -2014,7 +2014,9 @@ int flooder_sweep_cell_faces_f32(const float* pts_sorted, int64_t n_pts, int dim
   if (!simplex_weight) light_list = heavy_list = nullptr;
   if (simplex_weight) {  // split the simplices (order kept) into the light and the heavy list
     const bool long_queue = n_simplices * (int64_t)((R + 255) / 256) >= (int64_t)g_cell_super_min_chunks;
-    if (long_queue && g_cell_split_launches == 2) {   // (the two launches of rounds 3 - 5: kept for A/B runs and the tests)
+    // (more simplices than the one-launch form stages in LDS - its runs would be read from memory, a chain of cache
+    // misses: 50 us for cfg 5's 25 217 - take the pair; option 2: the pair always, for A/B runs and the tests)
+    if (long_queue && (g_cell_split_launches == 2 || n_simplices > 7680)) {
       hipLaunchKernelGGL(split_simplices_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, simplex_weight,
                          (int)n_simplices, (float)g_cell_super_weight, (float)g_cell_super_sparse, light_list, heavy_list,
                          defer_ctl + 2);

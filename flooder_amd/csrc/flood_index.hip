@@ -313,9 +313,12 @@ __global__ __launch_bounds__(256) void kd_box_kernel(const float* __restrict__ p
 template <int DIM>
 __global__ __launch_bounds__(256) void kd_key_kernel(const float* __restrict__ pts, int64_t n, int ld,
                                                      const uint32_t* __restrict__ order, int lg, int cbits,
-                                                     const uint32_t* __restrict__ boxes, uint32_t* __restrict__ keys) {
+                                                     const uint32_t* __restrict__ boxes, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ zero_buf, int64_t zero_words) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const float top = (float)((1u << cbits) - 1u);
+  // (the state of the radix sort that follows - its histograms, look-back arrays, block tickets: os_sort_pairs below)
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < zero_words; j += stride) zero_buf[j] = 0u;
   for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += stride) {
     const int64_t seg = pos >> lg;
     const uint32_t* b = boxes + seg * 16;
@@ -458,6 +461,11 @@ inline int kd_levels(int64_t n, int& log_p) {   // P = 16 << k >= n; levels t = 
 }
 inline int64_t kd_align(int64_t b) { return (b + 255) / 256 * 256; }
 
+// (defined with flooder_index_sort_zeroed below: the library's radix passes on caller-zeroed state, no fill launches)
+int64_t os_state_words(int64_t n, int key_bits);
+int os_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t* keys_tmp,
+                  uint32_t* vals_tmp, uint32_t n, int key_bits, uint32_t* state, hipStream_t st);
+
 template <int DIM>
 struct KdOrderOp {
   static int run(const float* pts, int64_t n, int ld, uint32_t* order_out, uint8_t* tmp, int64_t sort_bytes,
@@ -494,11 +502,24 @@ struct KdOrderOp {
       if (bb > 8192) bb = 8192;
       hipLaunchKernelGGL((kd_box_kernel<DIM>), dim3((int)bb), dim3(256), 0, st, pts, n, ld, cur, lg, R, boxes, direct);
       const int cbits = 32 - t < KD_CBITS ? 32 - t : KD_CBITS;
-      hipLaunchKernelGGL((kd_key_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, cur, lg, cbits, boxes, keys);
-      size_t bytes = (size_t)sort_bytes;
-      hipError_t e = rocprim::radix_sort_pairs<SortCfg>(scratch, bytes, keys, keys2, cur, nxt, (size_t)n, 0u,
-                                                        (unsigned)(t + cbits), st);
-      if (e != hipSuccess) return fail(FLOODER_E_LAUNCH, hipGetErrorString(e));
+      // scratch: keys and rows of the odd passes | the sort's state, cleared by the key kernel on its way (a level's sort
+      // has run when the next level's key kernel starts); clouds of 2^30 rows and more: the library call
+      const int64_t state_words = os_state_words(n, 32);
+      uint32_t* state = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + 2 * kd_align(n * 4));
+      const bool own_sort = state_words > 0 && sort_bytes >= 2 * kd_align(n * 4) + 4 * state_words;
+      hipLaunchKernelGGL((kd_key_kernel<DIM>), dim3((int)blocks), dim3(256), 0, st, pts, n, ld, cur, lg, cbits, boxes, keys,
+                         own_sort ? state : nullptr, own_sort ? state_words : (int64_t)0);
+      if (own_sort) {
+        uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(scratch);
+        uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + kd_align(n * 4));
+        const int rc = os_sort_pairs(keys, keys2, cur, nxt, keys_tmp, vals_tmp, (uint32_t)n, t + cbits, state, st);
+        if (rc != FLOODER_OK) return rc;
+      } else {
+        size_t bytes = (size_t)sort_bytes;
+        hipError_t e = rocprim::radix_sort_pairs<SortCfg>(scratch, bytes, keys, keys2, cur, nxt, (size_t)n, 0u,
+                                                          (unsigned)(t + cbits), st);
+        if (e != hipSuccess) return fail(FLOODER_E_LAUNCH, hipGetErrorString(e));
+      }
       uint32_t* s = cur; cur = nxt; nxt = s;
     }
     hipLaunchKernelGGL((kd_local_kernel<DIM>), dim3((unsigned)((n + KD_LOCAL - 1) / KD_LOCAL)), dim3(256), 0, st, pts, n, ld,
@@ -619,9 +640,9 @@ inline uint32_t os_items(int shape) { return shape == 1 ? OsSmall::items : (shap
 inline uint32_t os_blocks(int64_t n, int shape) { return (uint32_t)((n + os_items(shape) - 1) / os_items(shape)); }
 
 template <class Shape>
-void os_passes(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t n,
-               int key_bits, uint32_t* counts, rpd::onesweep_lookback_state* states, uint32_t* tickets, uint32_t* offsets_out,
-               hipStream_t st) {
+void os_passes(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t* keys_tmp,
+               uint32_t* vals_tmp, uint32_t n, int key_bits, uint32_t* counts, rpd::onesweep_lookback_state* states,
+               uint32_t* tickets, uint32_t* offsets_out, hipStream_t st) {
   const unsigned places = os_places(key_bits);
   const uint32_t blocks = (n + Shape::items - 1) / Shape::items;
   const uint32_t full_blocks = n % Shape::items == 0 ? blocks : blocks - 1;
@@ -631,10 +652,13 @@ void os_passes(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, 
     uint32_t* ko = to_output ? keys_out : keys_tmp;
     uint32_t* vo = to_output ? vals_out : vals_tmp;
     OsTicket ticket = OsTicket::create(tickets + place);
-    if (place == 0)
+    if (place == 0 && vals_in == nullptr)   // (values = row numbers)
       hipLaunchKernelGGL((os_pass_kernel<Shape, rocprim::counting_iterator<uint32_t>>), dim3(blocks), dim3(Shape::sb), 0, st,
                          keys_in, ko, rocprim::counting_iterator<uint32_t>(0u), vo, n, counts, offsets_out, states, bit,
                          bits_now, full_blocks, ticket);
+    else if (place == 0)
+      hipLaunchKernelGGL((os_pass_kernel<Shape, const uint32_t*>), dim3(blocks), dim3(Shape::sb), 0, st, keys_in, ko, vals_in,
+                         vo, n, counts, offsets_out, states, bit, bits_now, full_blocks, ticket);
     else
       hipLaunchKernelGGL((os_pass_kernel<Shape, const uint32_t*>), dim3(blocks), dim3(Shape::sb), 0, st,
                          (const uint32_t*)(to_output ? keys_tmp : keys_out), ko,
@@ -647,14 +671,46 @@ void os_passes(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, 
 
 namespace flooder { int g_sort_shape = 0; }
 
-extern "C" {
-
-int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits) {
-  if (n_pts < 1 || n_pts >= (1LL << 30) || key_bits < 1 || key_bits > 32) return 0;   // (0: use flooder_index_sort)
+namespace {
+int64_t os_state_words(int64_t n, int key_bits) {
+  if (n < 1 || n >= (1LL << 30) || key_bits < 1 || key_bits > 32) return 0;
   const int64_t places = os_places(key_bits);
   // histograms of every digit place | one look-back array per pass | one ticket per pass | the last block's offsets
-  // (sized for the smallest block shape: the option may change between this call and the sort)
-  return places * OS_RADIX + places * (int64_t)OS_RADIX * os_blocks(n_pts, 1) + places + OS_RADIX;
+  // (sized for the smallest block shape: the option may change between the sizing call and the sort)
+  return places * OS_RADIX + places * (int64_t)OS_RADIX * os_blocks(n, 1) + places + OS_RADIX;
+}
+
+// keys_in / vals_in (NULL: row numbers) are only read; the result lands in keys_out / vals_out; keys_tmp / vals_tmp: n
+// words each; state: os_state_words(n, key_bits) words, ZERO when the first launch below starts.
+int os_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t* keys_tmp,
+                  uint32_t* vals_tmp, uint32_t n, int key_bits, uint32_t* state, hipStream_t st) {
+  const unsigned places = os_places(key_bits);
+  const int shape = os_shape_of(n);
+  const uint32_t blocks = os_blocks(n, shape);
+  uint32_t* counts = state;
+  auto* states = reinterpret_cast<rpd::onesweep_lookback_state*>(counts + places * OS_RADIX);
+  uint32_t* tickets = counts + places * OS_RADIX + (size_t)places * OS_RADIX * blocks;
+  uint32_t* offsets_out = tickets + places;
+  {
+    const uint32_t hb = (uint32_t)(((int64_t)n + OS_HB * OS_HI - 1) / (OS_HB * OS_HI));
+    const uint32_t hfull = n % (OS_HB * OS_HI) == 0 ? hb : hb - 1;
+    hipLaunchKernelGGL(os_histogram_kernel, dim3(hb), dim3(OS_HB), 0, st, keys_in, counts, n, hfull, (unsigned)key_bits);
+    hipLaunchKernelGGL(os_scan_kernel, dim3(places), dim3(OS_HB), 0, st, counts);
+  }
+  if (shape == 1)
+    os_passes<OsSmall>(keys_in, keys_out, vals_in, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
+  else if (shape == 2)
+    os_passes<OsMid>(keys_in, keys_out, vals_in, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
+  else
+    os_passes<OsLarge>(keys_in, keys_out, vals_in, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
+  return check_launch("index sort (own launches)");
+}
+}  // namespace
+
+extern "C" {
+
+int64_t flooder_index_sort_state_words(int64_t n_pts, int key_bits) {   // (0: use flooder_index_sort)
+  return os_state_words(n_pts, key_bits);
 }
 
 int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits, int64_t* codes_sorted, int32_t* order,
@@ -663,33 +719,10 @@ int flooder_index_sort_zeroed(const int64_t* codes, int64_t n_pts, int key_bits,
   if (!codes || !codes_sorted || !order || !tmp || !state || n_pts < 0 || n_pts >= (1LL << 30) || key_bits < 1 ||
       key_bits > 32 || tmp_bytes < 8 * n_pts || (reinterpret_cast<uintptr_t>(tmp) & 3u))
     return fail(FLOODER_E_ARG, "flooder_index_sort_zeroed: bad argument (narrow keys, fewer than 2^30 rows, 8 n bytes of tmp)");
-  hipStream_t st = (hipStream_t)stream;
-  const uint32_t n = (uint32_t)n_pts;
-  const unsigned places = os_places(key_bits);
-  const int shape = os_shape_of(n_pts);
-  const uint32_t blocks = os_blocks(n_pts, shape);
-  uint32_t* counts = reinterpret_cast<uint32_t*>(state);
-  auto* states = reinterpret_cast<rpd::onesweep_lookback_state*>(counts + places * OS_RADIX);
-  uint32_t* tickets = counts + places * OS_RADIX + (size_t)places * OS_RADIX * blocks;
-  uint32_t* offsets_out = tickets + places;
-  const uint32_t* keys_in = reinterpret_cast<const uint32_t*>(codes);
-  uint32_t* keys_out = reinterpret_cast<uint32_t*>(codes_sorted);
-  uint32_t* vals_out = reinterpret_cast<uint32_t*>(order);
   uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(tmp);
-  uint32_t* vals_tmp = keys_tmp + n;
-  {
-    const uint32_t hb = (uint32_t)(((int64_t)n + OS_HB * OS_HI - 1) / (OS_HB * OS_HI));
-    const uint32_t hfull = n % (OS_HB * OS_HI) == 0 ? hb : hb - 1;
-    hipLaunchKernelGGL(os_histogram_kernel, dim3(hb), dim3(OS_HB), 0, st, keys_in, counts, n, hfull, (unsigned)key_bits);
-    hipLaunchKernelGGL(os_scan_kernel, dim3(places), dim3(OS_HB), 0, st, counts);
-  }
-  if (shape == 1)
-    os_passes<OsSmall>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
-  else if (shape == 2)
-    os_passes<OsMid>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
-  else
-    os_passes<OsLarge>(keys_in, keys_out, vals_out, keys_tmp, vals_tmp, n, key_bits, counts, states, tickets, offsets_out, st);
-  return check_launch("index_sort_zeroed");
+  return os_sort_pairs(reinterpret_cast<const uint32_t*>(codes), reinterpret_cast<uint32_t*>(codes_sorted), nullptr,
+                       reinterpret_cast<uint32_t*>(order), keys_tmp, keys_tmp + n_pts, (uint32_t)n_pts, key_bits,
+                       reinterpret_cast<uint32_t*>(state), (hipStream_t)stream);
 }
 
 int64_t flooder_kd_order_bytes(int64_t n_pts) {
@@ -703,7 +736,9 @@ int64_t flooder_kd_order_bytes(int64_t n_pts) {
   int log_p = 0;
   const int levels = kd_levels(n_pts, log_p);
   const int64_t box_segs = levels > 0 ? ((int64_t)1 << (levels - 1)) : 1;
-  return 3 * kd_align(n_pts * 4) + kd_align(box_segs * 64) + (int64_t)bytes + 256;
+  // (the sort scratch: what the library call wants, or keys + rows of the odd passes + the state of the own launches)
+  const int64_t own = 2 * kd_align(n_pts * 4) + 4 * os_state_words(n_pts, 32);
+  return 3 * kd_align(n_pts * 4) + kd_align(box_segs * 64) + ((int64_t)bytes > own ? (int64_t)bytes : own) + 256;
 }
 
 int flooder_kd_order_f32(const float* pts, int64_t n_pts, int dim, int ld, int32_t* order, void* tmp, int64_t tmp_bytes,
