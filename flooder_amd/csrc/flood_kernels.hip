@@ -365,7 +365,9 @@ __global__ __launch_bounds__(256) void face_max_small_kernel(const uint32_t* __r
                                                              const int32_t* __restrict__ face_ptr,
                                                              const int32_t* __restrict__ face_rows, int n_faces, int lgF,
                                                              float* __restrict__ out_face, float* __restrict__ out_dist) {
-  __shared__ uint32_t s_v[4][32][64];       // [wave][simplex of the step][row]
+  // [wave][simplex of the step][row]: 4 x U x 64 words of dynamic LDS - a static array for U = 32 was 32 KB per block,
+  // four blocks per CU, when seven faces (U = 8) need 8 KB: the loop is a chain of load latencies and wants the waves
+  extern __shared__ uint32_t s_v_dyn[];
   __shared__ uint8_t s_rows[32 * 64];       // the faces' row lists (every face lists at most R <= 64 rows)
   __shared__ int s_ptr[33];
   for (int f = threadIdx.x; f <= n_faces; f += blockDim.x) s_ptr[f] = face_ptr[f];
@@ -375,19 +377,20 @@ __global__ __launch_bounds__(256) void face_max_small_kernel(const uint32_t* __r
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int U = 64 >> lgF, f = lane & ((1 << lgF) - 1), u_mine = lane >> lgF;
+  uint32_t* s_v = s_v_dyn + (size_t)wv * U * 64;   // s_v[u * 64 + row]
   const int qb = f < n_faces ? s_ptr[f] : 0, qe = f < n_faces ? s_ptr[f + 1] : 0;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t s0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * U; s0 < n_simplices; s0 += waves * U) {
     for (int u = 0; u < U; ++u) {   // (wave-uniform trip count)
       const int64_t s = s0 + u;
       const uint32_t v = (lane < R && s < n_simplices) ? d2[s * (int64_t)R + lane] : 0u;
-      s_v[wv][u][lane] = v;
+      s_v[u * 64 + lane] = v;
       if (out_dist && lane < R && s < n_simplices) out_dist[s * (int64_t)R + lane] = __builtin_sqrtf(__uint_as_float(v));
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t m = 0u;   // (d2 bits of non-negative floats order like the floats)
     for (int q = qb; q < qe; ++q) {
-      const uint32_t t = s_v[wv][u_mine][s_rows[q]];
+      const uint32_t t = s_v[u_mine * 64 + s_rows[q]];
       m = t > m ? t : m;
     }
     const int64_t s = s0 + u_mine;
@@ -944,8 +947,10 @@ int flooder_face_max_f32(const uint32_t* d2, int64_t n_simplices, int R, const i
     while ((1 << lgF) < n_faces) ++lgF;
     const int per_block = 4 * (64 >> lgF);
     int64_t blocks = (n_simplices + per_block - 1) / per_block;
-    if (blocks > 6 * 256) blocks = 6 * 256;
-    hipLaunchKernelGGL(face_max_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d2, n_simplices, R,
+    const size_t lds = (size_t)4 * (64 >> lgF) * 64 * sizeof(uint32_t);   // 2 - 32 KB
+    const int64_t per_cu = lds <= 8192 ? 8 : (lds <= 16384 ? 6 : 4);      // resident blocks (32 waves, 160 KB a CU)
+    if (blocks > per_cu * 256) blocks = per_cu * 256;
+    hipLaunchKernelGGL(face_max_small_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d2, n_simplices, R,
                        face_ptr, face_rows, n_faces, lgF, out_face, out_dist);
     return check_launch("face_max");
   }
