@@ -135,6 +135,7 @@ SIGNATURES = {
     "flooder_wit_max_coarse": (c_int, []),
     "flooder_face_values_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "flooder_simplex_weight_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "flooder_simplex_planes_forget": (None, []),
     "flooder_simplex_prepare_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_int64, c_void_p]),
     "flooder_selftest": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -1372,9 +1372,13 @@ def _sweep_dimension_cell(index: PointIndex, verts: torch.Tensor, weights: torch
             blk.n_coarse, blk.coarse_rows, blk.parents = plan.wit[2], plan.wit[0].data_ptr(), plan.wit[1].data_ptr()
             blk.wit_queue, blk.wit_item_list, blk.wit_stats = qwit.data_ptr(), split[0].data_ptr(), _native.ptr(wst) or None
         with _span(timer, "sweep"):
-            if use_wit:
-                _native.check(lib.flooder_fused_witness(ctypes.byref(blk), st), "flooder_fused_witness")
-            _native.check(lib.flooder_fused_cell(ctypes.byref(blk), st), "flooder_fused_cell")
+            try:
+                if use_wit:
+                    _native.check(lib.flooder_fused_witness(ctypes.byref(blk), st), "flooder_fused_witness")
+                _native.check(lib.flooder_fused_cell(ctypes.byref(blk), st), "flooder_fused_cell")
+            except Exception:
+                lib.flooder_simplex_planes_forget()   # (the note flooder_simplex_prepare_f32 left for these two launches)
+                raise
         with _span(timer, "fallback"):
             _native.check(lib.flooder_fused_finish(ctypes.byref(blk), st), "flooder_fused_finish")
         if stats is not None:  # (diagnostic runs only: a host synchronisation)

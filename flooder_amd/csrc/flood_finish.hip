@@ -927,6 +927,8 @@ extern "C" int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int
                                 (int64_t)0, (hipStream_t)stream);
 }
 
+extern "C" void flooder_simplex_planes_forget(void) { (void)planes_are_done(nullptr, nullptr, 0, nullptr); }
+
 extern "C" int flooder_simplex_prepare_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
                                            int64_t n_simplices, float* weight, float* plane_scratch, int32_t* zero_buf,
                                            int64_t zero_words, void* stream) {

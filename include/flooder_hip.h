@@ -487,6 +487,11 @@ int flooder_simplex_weight_f32(const float* nodes, int64_t n_pts, int dim, const
 int flooder_simplex_prepare_f32(const float* nodes, int64_t n_pts, int dim, const float* verts, int k1,
                                 int64_t n_simplices, float* weight, float* plane_scratch, int32_t* zero_buf,
                                 int64_t zero_words, void* stream);
+/* The note "the plane rows of (verts, plane_scratch, n_simplices) on this stream are written" lives in the calling
+ * thread until the next witness / cell sweep entry point reads it.  A caller that gives up between the two (an error
+ * in between) drops the note with this call - a later sweep with recycled buffers at the same addresses must not
+ * inherit it. */
+void flooder_simplex_planes_forget(void);
 
 /* Device self-test of the 64-lane DPP reductions: out128[0:64] = min(in64), out128[64:128] = max. */
 int flooder_selftest(const float* in64, float* out128, void* stream);
