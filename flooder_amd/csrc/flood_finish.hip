@@ -119,6 +119,11 @@ __global__ __launch_bounds__(TEAM ? 64 * TEAM_WAVES : 64 * WAVES, TEAM ? 4 : (WA
   // a short list goes straight to the last pass (every tile is searched at once anyway; two launches saved)
   if (mode < 2 && n_list <= SHORT_LIST) return;
   const int64_t n_items = TEAM ? n_base : n_base * subs;
+  // a workgroup that will find nothing leaves before it stages the tree top (32 KB from L2): with a wave per item
+  // (the static deal below) those are the workgroups behind the last item - 800 of 1024 on cfg 2's short list -, in a
+  // team launch the workgroups beyond the number of entries (each takes at least one)
+  if (TEAM ? (int64_t)blockIdx.x >= n_items
+           : (n_items <= (int64_t)gridDim.x * NW && (int64_t)blockIdx.x * NW >= n_items)) return;
   const int topl = lv.n_levels - 1;
   // (the split of a hard entry is by level-1 node: a tree without that level has no hard entries)
   const bool budgeted = hl.budget > 0 && hl.ent_out != nullptr && topl >= 1;
