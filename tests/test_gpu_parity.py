@@ -758,6 +758,56 @@ def test_long_queue_lists_from_one_launch_equal_the_two_launches(dev, cloud):
         assert lib.flooder_set_option(b"cell_split_launches", 1) == 0
 
 
+@pytest.mark.parametrize("cloud", ["gauss3d", "torus3d", "eight2d"])
+def test_launch_lean_paths_change_nothing(dev, cloud, monkeypatch):
+    """Round 6's launch-lean forms against the ones they replace: the index with the radix sort on caller-zeroed state
+    (``core.SORT_STATE_BY_CALLER``: same permutation, rows, tree, density grid) and the sweep prepared by ONE launch
+    (``core.SWEEP_PREPARE_FUSED``: zero fill + simplex weights + plane rows; same weights, same face values bit for bit)."""
+    lib = _native.load()
+    if cloud == "gauss3d":
+        pts = np.random.default_rng(11).normal(size=(300_000, 3)).astype(np.float32)
+        n_l, dim = 400, 3
+    elif cloud == "torus3d":
+        pts = fo.noisy_torus(250_000, seed=11)
+        n_l, dim = 300, 3
+    else:
+        pts = fa.generate_figure_eight_points_2d(150_000, noise_std=0.01, seed=11).numpy().astype(np.float32)
+        n_l, dim = 200, 2
+    tp = torch.as_tensor(pts, device=dev)
+    idx = {}
+    for own in (True, False):
+        monkeypatch.setattr(core, "SORT_STATE_BY_CALLER", own)
+        idx[own] = core.PointIndex(tp)
+    torch.cuda.synchronize()
+    for name in ("order32", "pts", "nodes", "dens"):
+        a, b = getattr(idx[True], name), getattr(idx[False], name)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (cloud, name)
+    lms = fa.generate_landmarks(tp, n_l, start_idx=0)
+    stree, simplices = core._build_complex(lms, dim)
+    verts = lms[torch.as_tensor(simplices[dim], device=dev)].contiguous()
+    S = verts.shape[0]
+    # the weights of the prepare launch = flooder_simplex_weight_f32's, its zero fill clears what it is given
+    w_a = torch.empty(S, dtype=torch.float32, device=dev)
+    w_b = torch.empty(S, dtype=torch.float32, device=dev)
+    planes = torch.full((24 * S,), float("nan"), dtype=torch.float32, device=dev)
+    junk = torch.full((5000,), 7, dtype=torch.int32, device=dev)
+    index = idx[True]
+    _native.check(lib.flooder_simplex_weight_f32(_native.ptr(index.nodes), index.n, dim, _native.ptr(verts), dim + 1, S,
+                                                 _native.ptr(w_a), 0), "flooder_simplex_weight_f32")
+    _native.check(lib.flooder_simplex_prepare_f32(_native.ptr(index.nodes), index.n, dim, _native.ptr(verts), dim + 1, S,
+                                                  _native.ptr(w_b), _native.ptr(planes), _native.ptr(junk), junk.numel(), 0),
+                  "flooder_simplex_prepare_f32")
+    lib.flooder_simplex_planes_forget()   # (no sweep follows here)
+    torch.cuda.synchronize()
+    assert torch.equal(w_a.view(torch.int32), w_b.view(torch.int32))
+    assert int(junk.abs().sum()) == 0 and not bool(torch.isnan(planes).any())
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(core, "SWEEP_PREPARE_FUSED", fused)
+        res[fused] = fa.flood_complex(tp, lms, method="cell", points_per_edge=20)
+    assert res[True] == res[False], cloud
+
+
 def test_simplex_weight_orders_dense_simplices_first(dev):
     """flooder_simplex_weight_f32: the estimate tracks the true number of points in each simplex's bounding box."""
     pts = np.random.default_rng(3).normal(size=(400_000, 3)).astype(np.float32)
