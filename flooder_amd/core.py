@@ -1636,7 +1636,8 @@ def flood_complex(
             # the culled sweeps need no bounding balls; the simplices are queued along the widest axis (any order
             # gives the same values), prepared on the host so that nothing here waits for the device
             v_np = lm_np[simplices[d]]
-            order_np = np.argsort(v_np.mean(axis=1)[:, axis], kind="stable")
+            # (by the vertex sum along that axis alone: the mean over all axes first was 0.4 ms of a 6.8 ms call at cfg 2)
+            order_np = np.argsort(v_np[:, :, axis].sum(axis=1), kind="stable")
             simp_h = simplices[d][order_np]
             simplex_vertices = torch.as_tensor(np.ascontiguousarray(v_np[order_np]), device=device)
         else:
